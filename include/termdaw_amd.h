@@ -1,0 +1,170 @@
+/* termdaw_amd.h -- C ABI of the MI355X-native offline render engine for termdaw audio graphs.
+ *
+ * This is the drop-in boundary for termdaw's per-block vertex/graph render path.  The reference
+ * (Rust, /root/reference/src) has no FFI of its own: its "operator API" is the in-process surface
+ * State (state.rs) uses to talk to Graph (graph.rs), SampleBank (sample.rs) and FlowwBank
+ * (floww.rs).  Every entry point below cites the reference item it replaces; INTEGRATION.md shows
+ * the Rust `extern "C"` block a termdaw maintainer would add to bind them.
+ *
+ * Conventions
+ *   - plain C types only; opaque handles are created/destroyed by the library
+ *   - functions returning int: 1 = ok/true, 0 = failed/false (mirrors the reference's bool / Result /
+ *     Option); td_last_error() returns the message of the last failure on the calling thread
+ *   - audio is f32; "frames" are stereo frames; PCM out is interleaved L,R little-endian
+ *   - one host thread per graph handle; handles bound to different GPUs are independent
+ *   - the library never falls back to a CPU implementation: without a usable gfx950 device every
+ *     render call fails with an error
+ */
+#ifndef TERMDAW_AMD_H
+#define TERMDAW_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct td_samplebank td_samplebank;
+typedef struct td_flowwbank td_flowwbank;
+typedef struct td_graph td_graph;
+typedef struct td_state td_state;
+
+/* One event of a floww: the (_, t, note, vel) tuple of the floww crate as used at floww.rs:74-75,
+ * 105-116, 131-135 (field 0 is never read on the render path). vel <= 0.001 means note-off. */
+typedef struct td_event {
+    float t_sec;
+    float note;
+    float vel;
+} td_event;
+
+const char* td_last_error(void);
+/* HIP device selection for handles created afterwards on this thread (one process per GPU). */
+int td_device_count(void);
+int td_set_device(int device);
+
+/* ---- SampleBank (sample.rs:187-348) -------------------------------------------------------- */
+td_samplebank* td_samplebank_new(size_t sample_rate);                    /* SampleBank::new   sample.rs:213 */
+void td_samplebank_free(td_samplebank* sb);
+/* SampleBank::add sample.rs:224-314 (WAV decode -> load mode -> peak normalise -> upload to HBM).
+ * method: "" (stereo) | "left" | "right" | "loudest" | "normalize-seperate" | "mix-down". */
+int td_samplebank_add_file(td_samplebank* sb, const char* name, const char* path, const char* method);
+/* Same pipeline from an already decoded stream (what hound hands to sample.rs:262-274): `linear`
+ * holds n interleaved values, integer PCM cast to f32 without scaling, or float PCM as is. */
+int td_samplebank_add_decoded(td_samplebank* sb, const char* name, const float* linear, size_t n,
+                              int channels, size_t sample_rate, size_t bits, const char* method);
+long td_samplebank_get_index(const td_samplebank* sb, const char* name);  /* get_index sample.rs:338; -1 = None */
+size_t td_samplebank_sample_len(const td_samplebank* sb, size_t index);   /* Sample::len sample.rs:79 */
+/* get_sample sample.rs:342: copies the bank entry back from HBM as planar l / r. */
+int td_samplebank_read(const td_samplebank* sb, size_t index, float* l, float* r);
+void td_samplebank_get_max_sr_bd(const td_samplebank* sb, size_t* max_sr, size_t* max_bd); /* sample.rs:346 */
+
+/* ---- FlowwBank (floww.rs:6-141) ------------------------------------------------------------- */
+td_flowwbank* td_flowwbank_new(size_t sr, size_t bl);                     /* FlowwBank::new floww.rs:19 */
+void td_flowwbank_free(td_flowwbank* fb);
+void td_flowwbank_reset(td_flowwbank* fb);                                /* floww.rs:23-30 */
+/* declare_floww floww.rs:32-38 with the events given directly (add_floww floww.rs:40-48 reads them
+ * from MIDI through the un-vendored floww crate). Returns the floww index, or -1. */
+long td_flowwbank_add_events(td_flowwbank* fb, const char* name, const td_event* events, size_t n);
+long td_flowwbank_declare_stream(td_flowwbank* fb, const char* name);     /* floww.rs:50-53 */
+long td_flowwbank_get_index(const td_flowwbank* fb, const char* name);    /* floww.rs:66-68 */
+void td_flowwbank_set_time(td_flowwbank* fb, size_t t);                   /* floww.rs:83-86 */
+void td_flowwbank_set_time_to_next_block(td_flowwbank* fb);               /* floww.rs:88-91 */
+
+/* ---- Graph (graph.rs:12-238) + vertex constructors (extensions.rs:83-194, state.rs:341-457) -- */
+td_graph* td_graph_new(size_t max_buffer_len, size_t sr);                 /* Graph::new graph.rs:25 */
+void td_graph_free(td_graph* g);
+void td_graph_reset(td_graph* g);                                         /* graph.rs:39-47 */
+/* Graph::add(Vertex::new(bl, gain, angle, wet, VertexExt::<kind>(..)), name).  Argument fix-ups are
+ * those of state.rs:341-457: note < 0 -> any note; lerp_len < 0 -> 0; square z clamped to >= 1e-4;
+ * adsr arrays of 0, 6 or 9 floats (anything else fails, where the reference panics). */
+int td_graph_add_sum(td_graph* g, const char* name, float gain, float angle);
+int td_graph_add_normalize(td_graph* g, const char* name, float gain, float angle);
+int td_graph_add_sampleloop(td_graph* g, const char* name, float gain, float angle, size_t sample_index);
+int td_graph_add_sample_multi(td_graph* g, const char* name, float gain, float angle, size_t sample_index,
+                              size_t floww_index, int note);
+int td_graph_add_sample_lerp(td_graph* g, const char* name, float gain, float angle, size_t sample_index,
+                             size_t floww_index, int note, int lerp_len);
+int td_graph_add_debug_sine(td_graph* g, const char* name, float gain, float angle, size_t floww_index);
+int td_graph_add_synth(td_graph* g, const char* name, float gain, float angle, size_t floww_index,
+                       float square_vel, float square_z, const float* square_adsr, int square_adsr_len,
+                       float topflat_vel, float topflat_z, const float* topflat_adsr, int topflat_adsr_len,
+                       float triangle_vel, const float* triangle_adsr, int triangle_adsr_len);
+int td_graph_add_adsr(td_graph* g, const char* name, float gain, float angle, float wet, size_t floww_index,
+                      int use_off, int use_max, int note, const float* adsr, int adsr_len);
+int td_graph_add_bandpass(td_graph* g, const char* name, float gain, float angle, float wet,
+                          float cut_off_hz_low, float cut_off_hz_high, int pass);
+int td_graph_connect(td_graph* g, const char* a, const char* b);          /* graph.rs:80-96 (+58-78) */
+int td_graph_set_output(td_graph* g, const char* vertex);                 /* graph.rs:141-148 */
+int td_graph_check(const td_graph* g);                                    /* check_graph graph.rs:150-174 */
+void td_graph_set_time(td_graph* g, size_t time);                         /* graph.rs:123-128 */
+size_t td_graph_change_time(td_graph* g, size_t delta, int plus);         /* graph.rs:130-135 */
+size_t td_graph_get_time(const td_graph* g);                              /* graph.rs:137-139 */
+void td_graph_reset_normalize_vertices(td_graph* g);                      /* graph.rs:207-211 */
+float td_graph_get_normalization_value(const td_graph* g, const char* name); /* extensions.rs:301-307 */
+size_t td_graph_vertex_count(const td_graph* g);
+
+/* Graph::render graph.rs:182-193: renders ONE block at the current playhead, advances the playhead by
+ * max_buffer_len, copies the output vertex' block to l / r (max_buffer_len floats each, either may be
+ * NULL).  Returns 0 when there is no output vertex (the reference's None).  Like the reference it
+ * does not advance the FlowwBank -- the caller does (state.rs:572). */
+int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, float* l, float* r);
+
+/* Graph::true_normalize_scan graph.rs:222-237 over `chunks` blocks (whole timeline on the GPU). */
+int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t chunks);
+
+/* The accelerated entry: the body of State::render's loop (state.rs:562-575) for `n_blocks` blocks --
+ * n_blocks x { Graph::render; quantise (x*amplitude) as i16|i32 (state.rs:515-532); fb.set_time_to_next_block }
+ * then Graph::set_time(0).  The whole timeline is rendered by one kernel per vertex batch; the
+ * result stays in HBM.  bits in {8,16,24,32}: <= 16 -> int16 words, otherwise int32 words, exactly the
+ * integers the reference hands to hound.  Returns the number of frames rendered (0 on failure). */
+size_t td_graph_render_all(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits);
+/* Device-resident results of the last td_graph_render_all (valid until the next render on g). */
+const void* td_graph_output_pcm_device(const td_graph* g);    /* int16|int32 interleaved, frames*2 words */
+const float* td_graph_output_f32_device(const td_graph* g);   /* float2 per frame, un-quantised output vertex */
+/* D2H copies of the above (pcm: frames*2 words of 2 or 4 bytes; f32: frames*2 floats). */
+int td_graph_read_pcm(const td_graph* g, void* out, size_t bytes);
+int td_graph_read_f32(const td_graph* g, float* out, size_t n_floats);
+/* Per-block absolute peak of the last render's un-quantised output (n_blocks floats) reduced on the
+ * device to one float: used for the per-project peak table of the multi-GPU batch. */
+float td_graph_output_peak(const td_graph* g);
+/* Timing hook for bench.py: enqueue one full render on the graph's stream without the final host
+ * synchronisation (td_graph_sync waits).  Same work as td_graph_render_all. */
+size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits);
+int td_graph_sync(td_graph* g);
+/* HIP-event timing of the launches of the last render, per kernel family (ms).  names/ms are parallel
+ * arrays of capacity cap; returns the number of entries. Enabled by td_graph_set_profiling(g, 1). */
+void td_graph_set_profiling(td_graph* g, int on);
+size_t td_graph_last_kernel_times(const td_graph* g, const char** names, float* ms, size_t* launches, size_t cap);
+/* HBM bytes allocated for edge buffers / tables by this graph handle. */
+size_t td_graph_device_bytes(const td_graph* g);
+
+/* ---- Project front-end: State (state.rs:27-578) -------------------------------------------- */
+/* State{..} as constructed at main.rs:75-98 (render_sr 48000, bd 16, output "outp.wav"). */
+td_state* td_state_new(const char* wdir, size_t project_samplerate, size_t buffer_length);
+/* Reads <wdir>/project.toml ([settings] main, buffer_length=1024, project_samplerate=44100; config.rs:19-76). */
+td_state* td_state_open(const char* wdir);
+void td_state_free(td_state* s);
+/* State::refresh state.rs:50-471 on the given Lua source / on <wdir>/<main>. 1 = loaded. */
+int td_state_refresh_source(td_state* s, const char* lua_source);
+int td_state_refresh(td_state* s);
+int td_state_scan_exact(td_state* s);                                     /* state.rs:473-475 */
+/* State::render state.rs:477-577: renders cs blocks and writes the integer WAV to output_file
+ * (relative paths resolve against wdir). path_override may be NULL. */
+int td_state_render(td_state* s, const char* path_override);
+/* Same render, PCM left in memory: copies frames*2 words to out (may be NULL to query the size). */
+size_t td_state_render_to_memory(td_state* s, void* out, size_t bytes);
+size_t td_state_chunk_count(const td_state* s);                            /* cs, state.rs:104 */
+size_t td_state_render_samplerate(const td_state* s);
+size_t td_state_bitdepth(const td_state* s);
+const char* td_state_output_file(const td_state* s);
+td_graph* td_state_graph(td_state* s);
+td_samplebank* td_state_samplebank(td_state* s);
+td_flowwbank* td_state_flowwbank(td_state* s);
+/* The recorded script calls in call order, one per line, canonical text (host-logic tests). */
+const char* td_state_dump_calls(td_state* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TERMDAW_AMD_H */

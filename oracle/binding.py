@@ -1,0 +1,276 @@
+"""ctypes binding of the CPU oracle (oracle/libtermdaw_oracle.so).
+
+TEST INFRASTRUCTURE ONLY.  Importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never from termdaw_amd/.  The classes expose the same method names as
+termdaw_amd.api (which in turn mirror the reference's SampleBank / FlowwBank / Graph, see
+/root/reference/src/{sample,floww,graph}.rs) so one project script can be replayed into either.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libtermdaw_oracle.so")
+
+
+def build(force=False):
+    """Compile the oracle with g++ (oracle/Makefile)."""
+    src = os.path.join(_HERE, "termdaw_oracle.cpp")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libtermdaw_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(_LIB_PATH)
+    f32, sz, vp, cp, i32, lng = C.c_float, C.c_size_t, C.c_void_p, C.c_char_p, C.c_int, C.c_long
+    fp = C.POINTER(C.c_float)
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("orc_last_error", cp)
+    sig("orc_build_adsr_conf", i32, fp, i32, fp)
+    for n in ("orc_apply_ads", "orc_apply_adsr"):
+        sig(n, f32, fp, f32)
+    sig("orc_apply_r", f32, fp, f32, f32)
+    sig("orc_apply_r_rt", f32, fp, f32, f32)
+    sig("orc_adsr_max_vel", f32, fp)
+    sig("orc_lerp", f32, f32, f32, f32)
+    sig("orc_square_sine_sample", f32, f32, f32, f32)
+    sig("orc_topflat_sine_sample", f32, f32, f32, f32)
+    sig("orc_triangle_sample", f32, f32, f32)
+    sig("orc_note_hz", f32, f32)
+    sig("orc_chunk_count", sz, sz, f32, sz)
+    sig("orc_pan_amps", None, f32, fp, fp)
+    sig("orc_bandpass_gamma", f32, f32, sz)
+    sig("orc_amplitude", f32, sz)
+    sig("orc_quantise16", C.c_int16, f32, f32)
+    sig("orc_quantise32", C.c_int32, f32, f32)
+    sig("orc_frame_of", sz, f32, sz)
+    sig("orc_sb_new", vp, sz)
+    sig("orc_sb_free", None, vp)
+    sig("orc_sb_add_decoded", i32, vp, cp, fp, sz, i32, sz, sz, cp)
+    sig("orc_sb_add_file", i32, vp, cp, cp, cp)
+    sig("orc_sb_get_index", lng, vp, cp)
+    sig("orc_sb_len", sz, vp, sz)
+    sig("orc_sb_read", None, vp, sz, fp, fp)
+    sig("orc_fb_new", vp, sz, sz)
+    sig("orc_fb_free", None, vp)
+    sig("orc_fb_add_events", lng, vp, cp, fp, sz)
+    sig("orc_fb_get_index", lng, vp, cp)
+    sig("orc_fb_set_time", None, vp, sz)
+    sig("orc_fb_set_time_to_next_block", None, vp)
+    sig("orc_fb_start_block", None, vp, sz)
+    sig("orc_fb_get_block_drum", i32, vp, sz, sz, fp, fp)
+    sig("orc_fb_get_block_simple", sz, vp, sz, sz, fp, sz)
+    sig("orc_graph_new", vp, sz, sz)
+    sig("orc_graph_free", None, vp)
+    sig("orc_graph_add_sum", None, vp, cp, f32, f32)
+    sig("orc_graph_add_normalize", None, vp, cp, f32, f32)
+    sig("orc_graph_add_sampleloop", None, vp, cp, f32, f32, sz)
+    sig("orc_graph_add_sample_multi", None, vp, cp, f32, f32, sz, sz, i32)
+    sig("orc_graph_add_sample_lerp", None, vp, cp, f32, f32, sz, sz, i32, i32)
+    sig("orc_graph_add_debug_sine", None, vp, cp, f32, f32, sz)
+    sig("orc_graph_add_synth", i32, vp, cp, f32, f32, sz, f32, f32, fp, i32, f32, f32, fp, i32, f32, fp, i32)
+    sig("orc_graph_add_adsr", i32, vp, cp, f32, f32, f32, sz, i32, i32, i32, fp, i32)
+    sig("orc_graph_add_bandpass", None, vp, cp, f32, f32, f32, f32, f32, i32)
+    sig("orc_graph_connect", i32, vp, cp, cp)
+    sig("orc_graph_set_output", i32, vp, cp)
+    sig("orc_graph_check", i32, vp)
+    sig("orc_graph_set_time", None, vp, sz)
+    sig("orc_graph_get_time", sz, vp)
+    sig("orc_graph_reset_normalize_vertices", None, vp)
+    sig("orc_graph_get_normalization_value", f32, vp, cp)
+    sig("orc_graph_render", i32, vp, vp, vp, fp, fp)
+    sig("orc_graph_true_normalize_scan", None, vp, vp, vp, sz)
+    sig("orc_state_render", sz, vp, vp, vp, sz, sz, vp, fp)
+    _lib = L
+    return L
+
+
+def _fa(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _err():
+    return lib().orc_last_error().decode()
+
+
+class SampleBank:
+    """sample.rs:187-348"""
+
+    def __init__(self, sample_rate):
+        self.h = lib().orc_sb_new(sample_rate)
+        self.sample_rate = sample_rate
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_sb_free(self.h)
+            self.h = None
+
+    def add_decoded(self, name, values, channels, sr, bits, method=""):
+        a, p = _fa(values)
+        if not lib().orc_sb_add_decoded(self.h, name.encode(), p, a.size, channels, sr, bits, method.encode()):
+            raise ValueError(_err())
+
+    def add(self, name, file, method=""):
+        if not lib().orc_sb_add_file(self.h, name.encode(), file.encode(), method.encode()):
+            raise ValueError(_err())
+
+    def get_index(self, name):
+        i = lib().orc_sb_get_index(self.h, name.encode())
+        return None if i < 0 else i
+
+    def get_sample(self, index):
+        n = lib().orc_sb_len(self.h, index)
+        l = np.empty(n, np.float32)
+        r = np.empty(n, np.float32)
+        lib().orc_sb_read(self.h, index, l.ctypes.data_as(C.POINTER(C.c_float)),
+                          r.ctypes.data_as(C.POINTER(C.c_float)))
+        return l, r
+
+
+class FlowwBank:
+    """floww.rs:6-141"""
+
+    def __init__(self, sr, bl):
+        self.h = lib().orc_fb_new(sr, bl)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_fb_free(self.h)
+            self.h = None
+
+    def add_events(self, name, events):
+        a, p = _fa(np.asarray(events, dtype=np.float32).reshape(-1, 3))
+        return lib().orc_fb_add_events(self.h, name.encode(), p, a.shape[0])
+
+    def get_index(self, name):
+        i = lib().orc_fb_get_index(self.h, name.encode())
+        return None if i < 0 else i
+
+    def set_time(self, t):
+        lib().orc_fb_set_time(self.h, t)
+
+    def set_time_to_next_block(self):
+        lib().orc_fb_set_time_to_next_block(self.h)
+
+    def start_block(self, index):
+        lib().orc_fb_start_block(self.h, index)
+
+    def get_block_drum(self, index, offset):
+        n, v = C.c_float(), C.c_float()
+        if lib().orc_fb_get_block_drum(self.h, index, offset, C.byref(n), C.byref(v)):
+            return (n.value, v.value)
+        return None
+
+    def get_block_simple(self, index, offset):
+        buf = np.zeros(3 * 64, np.float32)
+        cnt = lib().orc_fb_get_block_simple(self.h, index, offset, buf.ctypes.data_as(C.POINTER(C.c_float)), 64)
+        return [(bool(buf[3 * i]), float(buf[3 * i + 1]), float(buf[3 * i + 2])) for i in range(min(cnt, 64))]
+
+
+class Graph:
+    """graph.rs:12-238 + the vertex constructors of extensions.rs:83-194 / state.rs:341-457"""
+
+    def __init__(self, bl, sr):
+        self.h = lib().orc_graph_new(bl, sr)
+        self.bl = bl
+        self.sr = sr
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_graph_free(self.h)
+            self.h = None
+
+    def add_sum(self, name, gain, angle):
+        lib().orc_graph_add_sum(self.h, name.encode(), gain, angle)
+
+    def add_normalize(self, name, gain, angle):
+        lib().orc_graph_add_normalize(self.h, name.encode(), gain, angle)
+
+    def add_sampleloop(self, name, gain, angle, sample_index):
+        lib().orc_graph_add_sampleloop(self.h, name.encode(), gain, angle, sample_index)
+
+    def add_sample_multi(self, name, gain, angle, sample_index, floww_index, note):
+        lib().orc_graph_add_sample_multi(self.h, name.encode(), gain, angle, sample_index, floww_index, note)
+
+    def add_sample_lerp(self, name, gain, angle, sample_index, floww_index, note, lerp_len):
+        lib().orc_graph_add_sample_lerp(self.h, name.encode(), gain, angle, sample_index, floww_index, note,
+                                        lerp_len)
+
+    def add_debug_sine(self, name, gain, angle, floww_index):
+        lib().orc_graph_add_debug_sine(self.h, name.encode(), gain, angle, floww_index)
+
+    def add_synth(self, name, gain, angle, floww_index, sq_vel, sq_z, sq_adsr, tf_vel, tf_z, tf_adsr, tr_vel,
+                  tr_adsr):
+        a1, p1 = _fa(sq_adsr)
+        a2, p2 = _fa(tf_adsr)
+        a3, p3 = _fa(tr_adsr)
+        if not lib().orc_graph_add_synth(self.h, name.encode(), gain, angle, floww_index, sq_vel, sq_z, p1,
+                                         a1.size, tf_vel, tf_z, p2, a2.size, tr_vel, p3, a3.size):
+            raise ValueError(_err())
+
+    def add_adsr(self, name, gain, angle, wet, floww_index, use_off, use_max, note, adsr):
+        a, p = _fa(adsr)
+        if not lib().orc_graph_add_adsr(self.h, name.encode(), gain, angle, wet, floww_index, int(use_off),
+                                        int(use_max), note, p, a.size):
+            raise ValueError(_err())
+
+    def add_bandpass(self, name, gain, angle, wet, lo_hz, hi_hz, pass_):
+        lib().orc_graph_add_bandpass(self.h, name.encode(), gain, angle, wet, lo_hz, hi_hz, int(pass_))
+
+    def connect(self, a, b):
+        return bool(lib().orc_graph_connect(self.h, a.encode(), b.encode()))
+
+    def set_output(self, name):
+        return bool(lib().orc_graph_set_output(self.h, name.encode()))
+
+    def check_graph(self):
+        return bool(lib().orc_graph_check(self.h))
+
+    def set_time(self, t):
+        lib().orc_graph_set_time(self.h, t)
+
+    def get_time(self):
+        return lib().orc_graph_get_time(self.h)
+
+    def reset_normalize_vertices(self):
+        lib().orc_graph_reset_normalize_vertices(self.h)
+
+    def get_normalization_value(self, name):
+        return lib().orc_graph_get_normalization_value(self.h, name.encode())
+
+    def render(self, sb, fb):
+        l = np.empty(self.bl, np.float32)
+        r = np.empty(self.bl, np.float32)
+        ok = lib().orc_graph_render(self.h, sb.h, fb.h, l.ctypes.data_as(C.POINTER(C.c_float)),
+                                    r.ctypes.data_as(C.POINTER(C.c_float)))
+        return (l, r) if ok else None
+
+    def true_normalize_scan(self, sb, fb, chunks):
+        lib().orc_graph_true_normalize_scan(self.h, sb.h, fb.h, chunks)
+
+    def render_all(self, sb, fb, cs, bd=16, want_f32=True, want_pcm=True):
+        """State::render loop (state.rs:562-575). Returns (pcm[frames,2] int16|int32, f32[frames,2])."""
+        frames = cs * self.bl
+        pcm = np.zeros((frames, 2), np.int32 if bd > 16 else np.int16) if want_pcm else None
+        f = np.zeros((frames, 2), np.float32) if want_f32 else None
+        n = lib().orc_state_render(self.h, sb.h, fb.h, cs, bd,
+                                   pcm.ctypes.data_as(C.c_void_p) if want_pcm else None,
+                                   f.ctypes.data_as(C.POINTER(C.c_float)) if want_f32 else None)
+        assert n == frames or n == 0
+        return pcm, f

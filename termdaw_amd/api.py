@@ -1,0 +1,397 @@
+"""ctypes binding of the C ABI (include/termdaw_amd.h -> termdaw_amd/lib/libtermdaw_amd.so).
+
+The classes keep the reference's names and method meanings (SampleBank sample.rs:187-348, FlowwBank
+floww.rs:6-141, Graph graph.rs:12-238, State state.rs:27-578) so that parity tests read like tests of
+the reference.  Everything renders on the GPU through the HIP library; there is no CPU fallback --
+a missing library or missing device raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libtermdaw_amd.so")
+
+
+class TermdawError(RuntimeError):
+    pass
+
+
+class td_event(C.Structure):
+    _fields_ = [("t_sec", C.c_float), ("note", C.c_float), ("vel", C.c_float)]
+
+
+_lib = None
+
+# name -> (restype, argtypes); also used by the symbol-export test
+_f32, _sz, _vp, _cp, _i32, _lng = C.c_float, C.c_size_t, C.c_void_p, C.c_char_p, C.c_int, C.c_long
+_fp = C.POINTER(C.c_float)
+SIGNATURES = {
+    "td_last_error": (_cp, []),
+    "td_device_count": (_i32, []),
+    "td_set_device": (_i32, [_i32]),
+    "td_samplebank_new": (_vp, [_sz]),
+    "td_samplebank_free": (None, [_vp]),
+    "td_samplebank_add_file": (_i32, [_vp, _cp, _cp, _cp]),
+    "td_samplebank_add_decoded": (_i32, [_vp, _cp, _fp, _sz, _i32, _sz, _sz, _cp]),
+    "td_samplebank_get_index": (_lng, [_vp, _cp]),
+    "td_samplebank_sample_len": (_sz, [_vp, _sz]),
+    "td_samplebank_read": (_i32, [_vp, _sz, _fp, _fp]),
+    "td_samplebank_get_max_sr_bd": (None, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
+    "td_flowwbank_new": (_vp, [_sz, _sz]),
+    "td_flowwbank_free": (None, [_vp]),
+    "td_flowwbank_reset": (None, [_vp]),
+    "td_flowwbank_add_events": (_lng, [_vp, _cp, C.POINTER(td_event), _sz]),
+    "td_flowwbank_declare_stream": (_lng, [_vp, _cp]),
+    "td_flowwbank_get_index": (_lng, [_vp, _cp]),
+    "td_flowwbank_set_time": (None, [_vp, _sz]),
+    "td_flowwbank_set_time_to_next_block": (None, [_vp]),
+    "td_graph_new": (_vp, [_sz, _sz]),
+    "td_graph_free": (None, [_vp]),
+    "td_graph_reset": (None, [_vp]),
+    "td_graph_add_sum": (_i32, [_vp, _cp, _f32, _f32]),
+    "td_graph_add_normalize": (_i32, [_vp, _cp, _f32, _f32]),
+    "td_graph_add_sampleloop": (_i32, [_vp, _cp, _f32, _f32, _sz]),
+    "td_graph_add_sample_multi": (_i32, [_vp, _cp, _f32, _f32, _sz, _sz, _i32]),
+    "td_graph_add_sample_lerp": (_i32, [_vp, _cp, _f32, _f32, _sz, _sz, _i32, _i32]),
+    "td_graph_add_debug_sine": (_i32, [_vp, _cp, _f32, _f32, _sz]),
+    "td_graph_add_synth": (_i32, [_vp, _cp, _f32, _f32, _sz, _f32, _f32, _fp, _i32, _f32, _f32, _fp, _i32, _f32, _fp, _i32]),
+    "td_graph_add_adsr": (_i32, [_vp, _cp, _f32, _f32, _f32, _sz, _i32, _i32, _i32, _fp, _i32]),
+    "td_graph_add_bandpass": (_i32, [_vp, _cp, _f32, _f32, _f32, _f32, _f32, _i32]),
+    "td_graph_connect": (_i32, [_vp, _cp, _cp]),
+    "td_graph_set_output": (_i32, [_vp, _cp]),
+    "td_graph_check": (_i32, [_vp]),
+    "td_graph_set_time": (None, [_vp, _sz]),
+    "td_graph_change_time": (_sz, [_vp, _sz, _i32]),
+    "td_graph_get_time": (_sz, [_vp]),
+    "td_graph_reset_normalize_vertices": (None, [_vp]),
+    "td_graph_get_normalization_value": (_f32, [_vp, _cp]),
+    "td_graph_vertex_count": (_sz, [_vp]),
+    "td_graph_render_block": (_i32, [_vp, _vp, _vp, _fp, _fp]),
+    "td_graph_normalize_scan": (_i32, [_vp, _vp, _vp, _sz]),
+    "td_graph_render_all": (_sz, [_vp, _vp, _vp, _sz, _i32]),
+    "td_graph_output_pcm_device": (_vp, [_vp]),
+    "td_graph_output_f32_device": (_vp, [_vp]),
+    "td_graph_read_pcm": (_i32, [_vp, _vp, _sz]),
+    "td_graph_read_f32": (_i32, [_vp, _fp, _sz]),
+    "td_graph_output_peak": (_f32, [_vp]),
+    "td_graph_render_all_async": (_sz, [_vp, _vp, _vp, _sz, _i32]),
+    "td_graph_sync": (_i32, [_vp]),
+    "td_graph_set_profiling": (None, [_vp, _i32]),
+    "td_graph_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
+    "td_graph_device_bytes": (_sz, [_vp]),
+    "td_state_new": (_vp, [_cp, _sz, _sz]),
+    "td_state_open": (_vp, [_cp]),
+    "td_state_free": (None, [_vp]),
+    "td_state_refresh_source": (_i32, [_vp, _cp]),
+    "td_state_refresh": (_i32, [_vp]),
+    "td_state_scan_exact": (_i32, [_vp]),
+    "td_state_render": (_i32, [_vp, _cp]),
+    "td_state_render_to_memory": (_sz, [_vp, _vp, _sz]),
+    "td_state_chunk_count": (_sz, [_vp]),
+    "td_state_render_samplerate": (_sz, [_vp]),
+    "td_state_bitdepth": (_sz, [_vp]),
+    "td_state_output_file": (_cp, [_vp]),
+    "td_state_graph": (_vp, [_vp]),
+    "td_state_samplebank": (_vp, [_vp]),
+    "td_state_flowwbank": (_vp, [_vp]),
+    "td_state_dump_calls": (_cp, [_vp]),
+}
+
+
+def lib():
+    """Loads the HIP library. Raises if it has not been built (python __graft_entry__.py / make -C termdaw_amd)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TermdawError("%s is missing: build it with `make -C termdaw_amd` (hipcc, gfx950); "
+                               "there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error():
+    return lib().td_last_error().decode(errors="replace")
+
+
+def _check(ok):
+    if not ok:
+        raise TermdawError(last_error())
+    return ok
+
+
+def _fa(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, a.ctypes.data_as(_fp)
+
+
+def device_count():
+    return lib().td_device_count()
+
+
+def set_device(i):
+    _check(lib().td_set_device(i))
+
+
+class SampleBank:
+    def __init__(self, sample_rate, _handle=None):
+        self.h = _handle or lib().td_samplebank_new(sample_rate)
+        self._own = _handle is None
+        self.sample_rate = sample_rate
+
+    def __del__(self):
+        if getattr(self, "h", None) and self._own:
+            lib().td_samplebank_free(self.h)
+            self.h = None
+
+    def add_decoded(self, name, values, channels, sr, bits, method=""):
+        a, p = _fa(values)
+        _check(lib().td_samplebank_add_decoded(self.h, name.encode(), p, a.size, channels, sr, bits, method.encode()))
+
+    def add(self, name, file, method=""):
+        _check(lib().td_samplebank_add_file(self.h, name.encode(), file.encode(), method.encode()))
+
+    def get_index(self, name):
+        i = lib().td_samplebank_get_index(self.h, name.encode())
+        return None if i < 0 else i
+
+    def get_sample(self, index):
+        n = lib().td_samplebank_sample_len(self.h, index)
+        l = np.empty(n, np.float32)
+        r = np.empty(n, np.float32)
+        _check(lib().td_samplebank_read(self.h, index, l.ctypes.data_as(_fp), r.ctypes.data_as(_fp)))
+        return l, r
+
+    def get_max_sr_bd(self):
+        a, b = _sz(), _sz()
+        lib().td_samplebank_get_max_sr_bd(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+
+class FlowwBank:
+    def __init__(self, sr, bl, _handle=None):
+        self.h = _handle or lib().td_flowwbank_new(sr, bl)
+        self._own = _handle is None
+
+    def __del__(self):
+        if getattr(self, "h", None) and self._own:
+            lib().td_flowwbank_free(self.h)
+            self.h = None
+
+    def add_events(self, name, events):
+        ev = np.ascontiguousarray(np.asarray(events, dtype=np.float32).reshape(-1, 3))
+        return lib().td_flowwbank_add_events(self.h, name.encode(), ev.ctypes.data_as(C.POINTER(td_event)), ev.shape[0])
+
+    def declare_stream(self, name):
+        return lib().td_flowwbank_declare_stream(self.h, name.encode())
+
+    def get_index(self, name):
+        i = lib().td_flowwbank_get_index(self.h, name.encode())
+        return None if i < 0 else i
+
+    def set_time(self, t):
+        lib().td_flowwbank_set_time(self.h, t)
+
+    def set_time_to_next_block(self):
+        lib().td_flowwbank_set_time_to_next_block(self.h)
+
+
+class Graph:
+    def __init__(self, bl, sr, _handle=None):
+        self.h = _handle or lib().td_graph_new(bl, sr)
+        self._own = _handle is None
+        self.bl = bl
+        self.sr = sr
+
+    def __del__(self):
+        if getattr(self, "h", None) and self._own:
+            lib().td_graph_free(self.h)
+            self.h = None
+
+    def add_sum(self, name, gain, angle):
+        _check(lib().td_graph_add_sum(self.h, name.encode(), gain, angle))
+
+    def add_normalize(self, name, gain, angle):
+        _check(lib().td_graph_add_normalize(self.h, name.encode(), gain, angle))
+
+    def add_sampleloop(self, name, gain, angle, sample_index):
+        _check(lib().td_graph_add_sampleloop(self.h, name.encode(), gain, angle, sample_index))
+
+    def add_sample_multi(self, name, gain, angle, sample_index, floww_index, note):
+        _check(lib().td_graph_add_sample_multi(self.h, name.encode(), gain, angle, sample_index, floww_index, note))
+
+    def add_sample_lerp(self, name, gain, angle, sample_index, floww_index, note, lerp_len):
+        _check(lib().td_graph_add_sample_lerp(self.h, name.encode(), gain, angle, sample_index, floww_index, note, lerp_len))
+
+    def add_debug_sine(self, name, gain, angle, floww_index):
+        _check(lib().td_graph_add_debug_sine(self.h, name.encode(), gain, angle, floww_index))
+
+    def add_synth(self, name, gain, angle, floww_index, sq_vel, sq_z, sq_adsr, tf_vel, tf_z, tf_adsr, tr_vel, tr_adsr):
+        a1, p1 = _fa(sq_adsr)
+        a2, p2 = _fa(tf_adsr)
+        a3, p3 = _fa(tr_adsr)
+        _check(lib().td_graph_add_synth(self.h, name.encode(), gain, angle, floww_index, sq_vel, sq_z, p1, a1.size,
+                                        tf_vel, tf_z, p2, a2.size, tr_vel, p3, a3.size))
+
+    def add_adsr(self, name, gain, angle, wet, floww_index, use_off, use_max, note, adsr):
+        a, p = _fa(adsr)
+        _check(lib().td_graph_add_adsr(self.h, name.encode(), gain, angle, wet, floww_index, int(use_off), int(use_max),
+                                       note, p, a.size))
+
+    def add_bandpass(self, name, gain, angle, wet, lo_hz, hi_hz, pass_):
+        _check(lib().td_graph_add_bandpass(self.h, name.encode(), gain, angle, wet, lo_hz, hi_hz, int(pass_)))
+
+    def connect(self, a, b):
+        return bool(lib().td_graph_connect(self.h, a.encode(), b.encode()))
+
+    def set_output(self, name):
+        return bool(lib().td_graph_set_output(self.h, name.encode()))
+
+    def check_graph(self):
+        return bool(lib().td_graph_check(self.h))
+
+    def set_time(self, t):
+        lib().td_graph_set_time(self.h, t)
+
+    def change_time(self, delta, plus):
+        return lib().td_graph_change_time(self.h, delta, int(plus))
+
+    def get_time(self):
+        return lib().td_graph_get_time(self.h)
+
+    def reset_normalize_vertices(self):
+        lib().td_graph_reset_normalize_vertices(self.h)
+
+    def get_normalization_value(self, name):
+        return lib().td_graph_get_normalization_value(self.h, name.encode())
+
+    def render(self, sb, fb):
+        """Graph::render: one block at the playhead -> (l, r) or None."""
+        l = np.empty(self.bl, np.float32)
+        r = np.empty(self.bl, np.float32)
+        ok = lib().td_graph_render_block(self.h, sb.h, fb.h, l.ctypes.data_as(_fp), r.ctypes.data_as(_fp))
+        if not ok:
+            if last_error() and "output vertex" not in last_error():
+                raise TermdawError(last_error())
+            return None
+        return l, r
+
+    def true_normalize_scan(self, sb, fb, chunks):
+        _check(lib().td_graph_normalize_scan(self.h, sb.h, fb.h, chunks))
+
+    def render_all(self, sb, fb, cs, bd=16, want_f32=True, want_pcm=True):
+        """State::render loop on the GPU. Returns (pcm[frames,2], f32[frames,2])."""
+        n = lib().td_graph_render_all(self.h, sb.h, fb.h, cs, bd)
+        if cs and not n:
+            raise TermdawError(last_error())
+        frames = cs * self.bl
+        pcm = f = None
+        if want_pcm:
+            pcm = np.zeros((frames, 2), np.int32 if bd > 16 else np.int16)
+            if frames:
+                _check(lib().td_graph_read_pcm(self.h, pcm.ctypes.data_as(_vp), pcm.nbytes))
+        if want_f32:
+            f = np.zeros((frames, 2), np.float32)
+            if frames:
+                _check(lib().td_graph_read_f32(self.h, f.ctypes.data_as(_fp), f.size))
+        return pcm, f
+
+    # -- bench hooks --
+    def render_all_async(self, sb, fb, cs, bd=16):
+        n = lib().td_graph_render_all_async(self.h, sb.h, fb.h, cs, bd)
+        if cs and not n:
+            raise TermdawError(last_error())
+        return n
+
+    def sync(self):
+        _check(lib().td_graph_sync(self.h))
+
+    def set_profiling(self, on):
+        lib().td_graph_set_profiling(self.h, int(on))
+
+    def kernel_times(self):
+        cap = 32
+        names = (_cp * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (_sz * cap)()
+        n = lib().td_graph_last_kernel_times(self.h, names, ms, cnt, cap)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+    def output_peak(self):
+        return lib().td_graph_output_peak(self.h)
+
+    def device_bytes(self):
+        return lib().td_graph_device_bytes(self.h)
+
+
+class State:
+    """State (state.rs:27-578): project script -> banks + graph -> render to WAV."""
+
+    def __init__(self, wdir="", project_samplerate=44100, buffer_length=1024, open_dir=None):
+        if open_dir is not None:
+            self.h = lib().td_state_open(open_dir.encode())
+        else:
+            self.h = lib().td_state_new(wdir.encode(), project_samplerate, buffer_length)
+        if not self.h:
+            raise TermdawError(last_error())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().td_state_free(self.h)
+            self.h = None
+
+    def refresh(self, source=None):
+        ok = lib().td_state_refresh(self.h) if source is None else lib().td_state_refresh_source(self.h, source.encode())
+        return bool(ok)
+
+    def scan_exact(self):
+        _check(lib().td_state_scan_exact(self.h))
+
+    def render(self, path=None):
+        _check(lib().td_state_render(self.h, path.encode() if path else None))
+
+    def render_to_memory(self):
+        nbytes = lib().td_state_render_to_memory(self.h, None, 0)
+        bd = self.bd
+        out = np.zeros(nbytes // (4 if bd > 16 else 2), np.int32 if bd > 16 else np.int16)
+        if nbytes:
+            if not lib().td_state_render_to_memory(self.h, out.ctypes.data_as(_vp), out.nbytes):
+                raise TermdawError(last_error())
+        return out.reshape(-1, 2)
+
+    @property
+    def cs(self):
+        return lib().td_state_chunk_count(self.h)
+
+    @property
+    def render_sr(self):
+        return lib().td_state_render_samplerate(self.h)
+
+    @property
+    def bd(self):
+        return lib().td_state_bitdepth(self.h)
+
+    @property
+    def output_file(self):
+        return lib().td_state_output_file(self.h).decode()
+
+    def dump_calls(self):
+        return lib().td_state_dump_calls(self.h).decode()
+
+    @property
+    def g(self):
+        return Graph(0, 0, _handle=lib().td_state_graph(self.h))
+
+    @property
+    def sb(self):
+        return SampleBank(0, _handle=lib().td_state_samplebank(self.h))
+
+    @property
+    def fb(self):
+        return FlowwBank(0, 0, _handle=lib().td_state_flowwbank(self.h))

@@ -1,0 +1,1527 @@
+// engine.cpp -- graph model, chunk compiler and launch scheduler behind the C ABI.
+//
+// Reference items are cited as file:line relative to /root/reference/src.  This file holds the
+// *host* half of the path: graph construction rules (graph.rs:49-174), the FlowwBank cursor
+// (floww.rs:70-141) and the sequential per-vertex bookkeeping (voice lists, f32 envelope clocks,
+// one-shot cursors) that the reference interleaves with its per-sample loops.  Everything that is
+// per-sample runs on the GPU (kernels.hip).  There is no CPU render fallback: every render entry
+// point fails when no HIP device is usable.
+#include "engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <limits>
+
+#include "wav.h"
+
+using namespace tdk;
+
+namespace tde {
+
+thread_local std::string g_error;
+int fail(const std::string& msg) {
+    g_error = msg;
+    return 0;
+}
+
+#define TD_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            g_error = std::string("HIP error: ") + hipGetErrorString(_e) + " at " #expr;  \
+            return 0;                                                                     \
+        }                                                                                 \
+    } while (0)
+
+size_t f32_as_usize(float x) {   // Rust `x as usize`
+    if (!(x == x)) return 0;
+    if (x <= 0.0f) return 0;
+    if (x >= 18446744073709551616.0f) return std::numeric_limits<size_t>::max();
+    return (size_t)x;
+}
+
+static thread_local int t_device = 0;
+
+static int ensure_device(int dev) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail("termdaw_amd: no HIP device available (the render path has no CPU fallback)");
+    if (dev >= n) return fail("termdaw_amd: device index out of range");
+    TD_HIP(hipSetDevice(dev));
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// sample load pipeline (sample.rs:38-77, 125-147, 252-313) -- load-time, host side
+// ------------------------------------------------------------------------------------------------
+static float absmax_of(const std::vector<float>& s) {   // sample.rs:8-14
+    float m = 0.0f;
+    for (float v : s) {
+        float a = fabsf(v);
+        if (a > m) m = a;
+    }
+    return m;
+}
+static float mean_energy(const std::vector<float>& s) {   // sample.rs:16-22
+    if (s.empty()) return 0.0f;
+    float sum = 0.0f;
+    for (float v : s) sum += fabsf(v);
+    return sum / (float)s.size();
+}
+
+enum LoadMethod { LM_STEREO, LM_LEFT, LM_RIGHT, LM_LOUDEST, LM_NORM, LM_MIX };
+static LoadMethod method_from(const char* s) {   // sample.rs:199-210
+    std::string m = s ? s : "";
+    if (m == "left") return LM_LEFT;
+    if (m == "right") return LM_RIGHT;
+    if (m == "loudest") return LM_LOUDEST;
+    if (m == "normalize-seperate") return LM_NORM;
+    if (m == "mix-down") return LM_MIX;
+    return LM_STEREO;
+}
+
+static int bank_add_decoded(td_samplebank* sb, const std::string& name, const std::vector<float>& linear,
+                            int channels, size_t sr, size_t bd, LoadMethod method) {
+    if (sb->names.count(name))
+        return fail("TermDaw: SampleBank: there is already a sample with name \"" + name + "\" present.");
+    if (method == LM_STEREO && channels != 2)
+        return fail("TermDaw: SampleBank: only 2 channel samples are supported for stereo samples.");
+    if (method != LM_STEREO && channels > 2)
+        return fail("TermDaw: SampleBank: only 1,2 channel samples are supported for left or right samples.");
+    sb->max_sr = std::max(sb->max_sr, sr);
+    sb->max_bd = std::max(sb->max_bd, bd);
+    std::vector<float> l, r;
+    if (channels == 1) {
+        (method == LM_LEFT ? l : r) = linear;
+    } else {
+        size_t half = linear.size() / 2;
+        l.resize(half);
+        r.resize(half);
+        for (size_t i = 0; i < half; ++i) {
+            l[i] = linear[2 * i];
+            r[i] = linear[2 * i + 1];
+        }
+        if (linear.size() > half * 2) l.push_back(linear.back());
+    }
+    // Sample::from
+    switch (method) {
+        case LM_LEFT:
+            if (l.empty()) return fail("TermDaw: Sample::from: l has length 0.");
+            r = l;
+            break;
+        case LM_RIGHT:
+            if (r.empty()) return fail("TermDaw: Sample::from: r has length 0.");
+            l = r;
+            break;
+        case LM_LOUDEST:
+            if (mean_energy(l) > mean_energy(r)) r = l; else l = r;
+            break;
+        default:
+            if (l.size() != r.size()) return fail("TermDaw: Sample::from: l and r do not have the same length.");
+            if (l.empty()) return fail("TermDaw: Sample::from: l and r have length 0.");
+    }
+    if (method == LM_NORM) {   // normalize_seperate
+        float sl = 1.0f / absmax_of(l), sr_ = 1.0f / absmax_of(r);
+        for (auto& v : l) v *= sl;
+        for (auto& v : r) v *= sr_;
+    } else if (method == LM_MIX) {   // mix_down
+        size_t n = std::min(l.size(), r.size());
+        std::vector<float> mix(n);
+        for (size_t i = 0; i < n; ++i) mix[i] = l[i] + r[i];
+        float sc = 1.0f / absmax_of(mix);
+        for (auto& v : mix) v *= sc;
+        l = mix;
+        r = mix;
+    } else {   // normalize(usize::MAX)
+        float sc = 1.0f / fmaxf(absmax_of(l), absmax_of(r));
+        for (auto& v : l) v *= sc;
+        for (auto& v : r) v *= sc;
+    }
+    if (sr != sb->sample_rate)
+        return fail("termdaw_amd: sample \"" + name + "\" has sample rate " + std::to_string(sr) +
+                    " != project rate; the reference resamples with the un-vendored rubato crate "
+                    "(sample.rs:305-310) -- not supported (parity unpinned), author assets at the project rate");
+    if (l.size() != r.size()) return fail("termdaw_amd: channel lengths differ after load");
+    if (!ensure_device(sb->device)) return 0;
+    size_t n = l.size();
+    std::vector<float2> inter(n + (n & 1));
+    for (size_t i = 0; i < n; ++i) inter[i] = make_float2(l[i], r[i]);
+    if (n & 1) inter[n] = make_float2(0.f, 0.f);
+    SampleEntry e;
+    e.len = n;
+    TD_HIP(hipMalloc(&e.d, inter.size() * sizeof(float2)));
+    TD_HIP(hipMemcpy(e.d, inter.data(), inter.size() * sizeof(float2), hipMemcpyHostToDevice));
+    sb->samples.push_back(e);
+    sb->names[name] = sb->samples.size() - 1;
+    return 1;
+}
+
+}  // namespace tde
+
+using namespace tde;
+
+// ------------------------------------------------------------------------------------------------
+// FlowwBank cursor (floww.rs:70-91)
+// ------------------------------------------------------------------------------------------------
+void td_flowwbank::set_start_indices_to_frame(size_t t_frame, bool do_skip) {
+    for (size_t i = 0; i < flowws.size(); ++i) {
+        const auto& fl = flowws[i];
+        for (size_t j = do_skip ? start_indices[i] : 0; j < fl.size(); ++j) {
+            if (frame_of(fl[j]) >= t_frame) {
+                start_indices[i] = j;
+                break;
+            }
+        }
+    }
+}
+void td_flowwbank::set_time(size_t t) {
+    set_start_indices_to_frame(t, false);
+    frame = t;
+}
+void td_flowwbank::set_time_to_next_block() {
+    frame += bl;
+    set_start_indices_to_frame(frame, true);
+}
+
+namespace tde {
+
+// ------------------------------------------------------------------------------------------------
+// event pulls, one reference block at a time
+// ------------------------------------------------------------------------------------------------
+// get_block_drum (floww.rs:99-121) called for offsets 0..bl-1: events before the wanted frame are
+// skipped, only the FIRST on-event (vel > 0.001) of a frame is delivered, note-offs are dropped.
+template <class Hit>
+static void drum_block(const std::vector<td_event>& ev, const td_flowwbank& fb, size_t frame, size_t start,
+                       size_t bl, Hit on_hit) {
+    size_t p = start, i = 0;
+    while (p < ev.size() && i < bl) {
+        const size_t f = fb.frame_of(ev[p]);
+        const size_t target = frame + i;
+        if (f < target) { ++p; continue; }
+        if (f == target) {
+            const td_event e = ev[p++];
+            if (e.vel > 0.001f) {
+                on_hit(i, e.note, e.vel);
+                ++i;   // the next pull is for the next offset
+            }
+            continue;
+        }
+        if (f - frame >= bl) break;
+        i = f - frame;
+    }
+}
+// get_block_simple (floww.rs:124-141): ALL events of the wanted frame, in order; never skips a stale
+// event (an event behind the cursor blocks the rest of the block).
+template <class Ev, class Done>
+static void simple_block(const std::vector<td_event>& ev, const td_flowwbank& fb, size_t frame, size_t start,
+                         size_t bl, Ev on_event, Done offset_done) {
+    size_t p = start, i = 0;
+    bool any = false;
+    while (p < ev.size()) {
+        const size_t f = fb.frame_of(ev[p]);
+        const size_t target = frame + i;
+        if (f == target) {
+            const td_event e = ev[p++];
+            on_event(i, e.vel > 0.001f, e.note, e.vel);
+            any = true;
+            continue;
+        }
+        if (any) { offset_done(i); any = false; }
+        if (f < target || f - frame >= bl) break;
+        i = f - frame;
+    }
+    if (any) offset_done(i);
+}
+
+struct BlockCursor {
+    size_t frame;
+    std::vector<size_t> start;
+};
+
+struct IntervalBuilder {
+    std::vector<uint32_t> istart, ivoff;
+    std::vector<float4> voices;
+    uint32_t limit = 0;
+    bool open = false;
+    bool begin(size_t m) {
+        if (m >= limit) { open = false; return false; }
+        if (!istart.empty() && istart.back() == (uint32_t)m) {
+            voices.resize(ivoff.back());
+        } else {
+            istart.push_back((uint32_t)m);
+            ivoff.push_back((uint32_t)voices.size());
+        }
+        open = true;
+        return true;
+    }
+    void push(float a, float b, float c, float d) { if (open) voices.push_back(make_float4(a, b, c, d)); }
+    void finish() { ivoff.push_back((uint32_t)voices.size()); }
+};
+
+static inline float note_hz(float note) { return 440.0f * powf(2.0f, (note - 69.0f) / 12.0f); }   // extensions.rs:451,503
+
+struct Staging {
+    std::vector<uint8_t> b;
+    size_t alloc(size_t n) {
+        size_t o = (b.size() + 15) & ~(size_t)15;
+        b.resize(o + n);
+        return o;
+    }
+    template <class T>
+    size_t put(const std::vector<T>& v) {
+        size_t o = alloc(v.size() * sizeof(T) + 16);   // never zero-sized
+        if (!v.empty()) memcpy(&b[o], v.data(), v.size() * sizeof(T));
+        return o;
+    }
+};
+
+struct VTables {   // per-vertex compile result: offsets into the staging arena
+    size_t hits_off = 0;
+    uint32_t n_hits = 0;
+    size_t istart_off = 0, ivoff_off = 0, voices_off = 0;
+    uint32_t n_int = 0;
+    uint64_t t0 = 0;
+};
+
+static PanGain make_pg(float gain, float angle) {
+    PanGain pg{1.0f, 1.0f, 1.0f, 0u};
+    if (!(fabsf(angle) < 0.001f)) {   // sample.rs:98
+        const float angle_rad = angle * 0.5f * 0.01745329f;
+        const float k = 0.707106781186547524400844362104849039f;   // FRAC_1_SQRT_2
+        pg.l_amp = k * (cosf(angle_rad) + sinf(angle_rad));
+        pg.r_amp = k * (cosf(angle_rad) - sinf(angle_rad));
+        pg.flags |= 1u;
+    }
+    if (!(fabsf(gain - 1.0f) < 0.001f)) {   // sample.rs:109
+        pg.gain = gain;
+        pg.flags |= 2u;
+    }
+    return pg;
+}
+
+static const std::vector<td_event>& floww_of(const td_flowwbank* fb, size_t idx) {
+    static const std::vector<td_event> empty;
+    return idx < fb->flowws.size() ? fb->flowws[idx] : empty;
+}
+static size_t start_of(const BlockCursor& c, size_t idx) { return idx < c.start.size() ? c.start[idx] : 0; }
+
+// ---- SampleMulti (extensions.rs:344-381) ----
+static void compile_multi(Vertex& v, size_t L, const td_flowwbank* fb, const std::vector<BlockCursor>& cur,
+                          size_t bl, Staging& st, VTables& vt) {
+    const size_t M = cur.size() * bl;
+    std::vector<MultiHit> hits;
+    for (auto& tv : v.ts) hits.push_back({-tv.first, tv.second, 0.f});
+    const auto& ev = floww_of(fb, v.floww_index);
+    for (size_t b = 0; b < cur.size(); ++b) {
+        drum_block(ev, *fb, cur[b].frame, start_of(cur[b], v.floww_index), bl, [&](size_t i, float note, float vel) {
+            const bool ok = v.has_note ? fabsf(note - (float)v.note) < 0.01f : true;
+            if (ok) hits.push_back({(int64_t)(b * bl + i), vel, 0.f});
+        });
+    }
+    v.ts.clear();
+    for (auto& h : hits)
+        if (h.origin + (int64_t)L > (int64_t)M) v.ts.push_back({(int64_t)M - h.origin, h.vel});
+    vt.n_hits = (uint32_t)hits.size();
+    vt.hits_off = st.put(hits);
+}
+
+// ---- SampleLerp (extensions.rs:384-421) ----
+static void compile_lerp(Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl,
+                         Staging& st, VTables& vt) {
+    const int64_t M = (int64_t)(cur.size() * bl);
+    const int64_t never = std::numeric_limits<int64_t>::min();
+    std::vector<LerpHit> hits;
+    hits.push_back({never, -v.g_off, never / 2, v.g_vel, 0.f});
+    hits.push_back({never, -v.p_off, (int64_t)v.countdown - (int64_t)v.lerp_len, v.p_vel, 0.f});
+    const auto& ev = floww_of(fb, v.floww_index);
+    for (size_t b = 0; b < cur.size(); ++b) {
+        drum_block(ev, *fb, cur[b].frame, start_of(cur[b], v.floww_index), bl, [&](size_t i, float note, float vel) {
+            const bool ok = v.has_note ? fabsf(note - (float)v.note) < 0.01f : true;
+            if (ok) {
+                const int64_t m = (int64_t)(b * bl + i);
+                hits.push_back({m, m, m, vel, 0.f});
+            }
+        });
+    }
+    const LerpHit& p = hits.back();
+    const LerpHit& g = hits[hits.size() - 2];
+    const int64_t since = M - p.fade;
+    v.countdown = since < (int64_t)v.lerp_len ? (uint64_t)((int64_t)v.lerp_len - since) : 0;
+    v.p_off = M - p.origin;
+    v.p_vel = p.vel;
+    v.g_off = M - g.origin;
+    v.g_vel = g.vel;
+    vt.n_hits = (uint32_t)hits.size();
+    vt.hits_off = st.put(hits);
+}
+
+static void put_intervals(IntervalBuilder& ib, Staging& st, VTables& vt) {
+    ib.finish();
+    vt.n_int = (uint32_t)ib.istart.size();
+    vt.istart_off = st.put(ib.istart);
+    vt.ivoff_off = st.put(ib.ivoff);
+    vt.voices_off = st.put(ib.voices);
+}
+
+// ---- DebugSine (extensions.rs:423-457) ----
+static void compile_sine(Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl,
+                         Staging& st, VTables& vt) {
+    IntervalBuilder ib;
+    ib.limit = (uint32_t)(cur.size() * bl);
+    auto emit = [&](size_t m) {
+        if (!ib.begin(m)) return;
+        for (auto& n : v.sine_notes) ib.push(note_hz(n.note), n.vel, 0.f, 0.f);
+    };
+    const auto& ev = floww_of(fb, v.floww_index);
+    for (size_t b = 0; b < cur.size(); ++b) {
+        emit(b * bl);
+        simple_block(ev, *fb, cur[b].frame, start_of(cur[b], v.floww_index), bl,
+            [&](size_t, bool on, float note, float vel) {
+                if (on) {
+                    bool has = false;
+                    for (auto& n : v.sine_notes)
+                        if (fabsf(n.note - note) < 0.001f) { n.vel = vel; has = true; break; }
+                    if (!has) v.sine_notes.push_back({note, vel});
+                } else {
+                    v.sine_notes.erase(std::remove_if(v.sine_notes.begin(), v.sine_notes.end(),
+                                                      [&](const SineNote& x) { return !(fabsf(x.note - note) > 0.001f); }),
+                                       v.sine_notes.end());
+                }
+            },
+            [&](size_t i) { emit(b * bl + i); });
+    }
+    put_intervals(ib, st, vt);
+}
+
+// ---- Synth (extensions.rs:460-529) ----
+static float synth_release_sec(const Vertex& v) {   // extensions.rs:469-478
+    float release_sec = 0.0f;
+    if (v.square.volume > 0.0f) release_sec = v.square.adsr.release_sec;
+    if (v.topflat.volume > 0.0f) release_sec = fmaxf(release_sec, v.topflat.adsr.release_sec);
+    if (v.triangle.volume > 0.0f) release_sec = fmaxf(release_sec, v.triangle.adsr.release_sec);
+    return release_sec;
+}
+static int compile_synth(Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl,
+                         size_t sr, Staging& st, VTables& vt) {
+    IntervalBuilder ib;
+    ib.limit = (uint32_t)(cur.size() * bl);
+    const float release_sec = synth_release_sec(v);
+    auto emit = [&](size_t m) {
+        if (!ib.begin(m)) return;
+        for (auto& n : v.notes) ib.push(note_hz(n.note), n.vel, n.env_t, n.rel_t);
+    };
+    const auto& ev = floww_of(fb, v.floww_index);
+    bool impossible = false;
+    for (size_t b = 0; b < cur.size(); ++b) {
+        emit(b * bl);
+        simple_block(ev, *fb, cur[b].frame, start_of(cur[b], v.floww_index), bl,
+            [&](size_t i, bool on, float note, float vel) {
+                const float off = (float)i / (float)sr;
+                if (on) {
+                    v.notes.push_back({note, vel, -off, 0.0f});
+                } else {
+                    v.notes.erase(std::remove_if(v.notes.begin(), v.notes.end(),
+                                                 [&](const SynthNote& x) {
+                                                     return !(fabsf(x.note - note) > 0.001f || x.rel_t == 0.0f);
+                                                 }),
+                                  v.notes.end());
+                    for (auto& x : v.notes) {
+                        if (fabsf(x.note - note) > 0.001f) continue;
+                        if (x.rel_t == 0.0f) {
+                            x.rel_t = x.env_t + off;
+                            x.env_t = -off;
+                        } else {
+                            impossible = true;   // the reference panics here (extensions.rs:492)
+                        }
+                    }
+                }
+            },
+            [&](size_t i) { emit(b * bl + i); });
+        for (auto& x : v.notes) x.env_t += (float)bl / (float)sr;
+        v.notes.erase(std::remove_if(v.notes.begin(), v.notes.end(),
+                                     [&](const SynthNote& x) { return !(x.rel_t == 0.0f || x.env_t <= release_sec); }),
+                      v.notes.end());
+    }
+    if (impossible) return fail("Synth: impossible release stage note");
+    put_intervals(ib, st, vt);
+    return 1;
+}
+
+// ---- Adsr vertex (extensions.rs:593-651) ----
+static void compile_adsr(Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl,
+                         size_t sr, Staging& st, VTables& vt) {
+    IntervalBuilder ib;
+    ib.limit = (uint32_t)(cur.size() * bl);
+    auto emit = [&](size_t m, float skip) {
+        if (!ib.begin(m)) return;
+        ib.push(v.ap.t, v.ap.vel, v.ap.rel, skip);
+        ib.push(v.ag.t, v.ag.vel, v.ag.rel, 0.f);
+    };
+    const auto& ev = floww_of(fb, v.floww_index);
+    for (size_t b = 0; b < cur.size(); ++b) {
+        emit(b * bl, 0.f);
+        if (v.use_off) {
+            simple_block(ev, *fb, cur[b].frame, start_of(cur[b], v.floww_index), bl,
+                [&](size_t i, bool on, float n, float vel) {
+                    if (v.has_note && fabsf((float)v.note - n) > 0.01f) return;   // :606-608
+                    const float off = (float)i / (float)sr;
+                    if (on) {
+                        v.ag = v.ap;
+                        v.ap = {-off, vel, 0.0f};
+                    } else if (v.ag.rel == 0.0f) {
+                        v.ag.t = -off;
+                        v.ag.rel = apply_ads(v.conf, v.ag.t + off) * v.ag.vel;
+                    } else {
+                        v.ap.t = -off;
+                        v.ap.rel = apply_ads(v.conf, v.ap.t + off) * v.ap.vel;
+                    }
+                },
+                [&](size_t i) { emit(b * bl + i, 0.f); });
+        } else {
+            drum_block(ev, *fb, cur[b].frame, start_of(cur[b], v.floww_index), bl, [&](size_t i, float n, float vel) {
+                if (v.has_note && fabsf((float)v.note - n) > 0.01f) {
+                    // :632-635 `continue`: this frame is left un-enveloped, state unchanged
+                    emit(b * bl + i, 1.f);
+                    if (i + 1 < bl) emit(b * bl + i + 1, 0.f);
+                    return;
+                }
+                v.ag = v.ap;
+                v.ap = {-((float)i / (float)sr), vel, 0.0f};
+                emit(b * bl + i, 0.f);
+            });
+        }
+        v.ap.t += (float)bl / (float)sr;
+        v.ag.t += (float)bl / (float)sr;
+    }
+    put_intervals(ib, st, vt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// plan: reachable set, topological levels (graph.rs:98-108 visits exactly the vertices that reach the
+// output; others never run and never advance -- quirk Q12)
+// ------------------------------------------------------------------------------------------------
+static void build_plan(td_graph* g) {
+    const size_t n = g->vertices.size();
+    g->level.assign(n, -1);
+    g->order.clear();
+    g->n_levels = 0;
+    if (g->output_vertex >= 0) {
+        // iterative post-order DFS over reverse edges
+        std::vector<char> seen(n, 0);
+        std::vector<std::pair<size_t, size_t>> stack;
+        stack.push_back({(size_t)g->output_vertex, 0});
+        seen[(size_t)g->output_vertex] = 1;
+        while (!stack.empty()) {
+            auto& top = stack.back();
+            const size_t v = top.first;
+            if (top.second < g->edges[v].size()) {
+                const size_t u = g->edges[v][top.second++];
+                if (!seen[u]) {
+                    seen[u] = 1;
+                    stack.push_back({u, 0});
+                }
+            } else {
+                int lv = 0;
+                for (size_t u : g->edges[v]) lv = std::max(lv, g->level[u] + 1);
+                g->level[v] = lv;
+                g->n_levels = std::max(g->n_levels, lv + 1);
+                g->order.push_back(v);
+                stack.pop_back();
+            }
+        }
+    }
+    g->plan_dirty = false;
+}
+
+static int ensure_graph_device(td_graph* g) {
+    if (!ensure_device(g->device)) return 0;
+    if (!g->stream) {
+        TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        TD_HIP(hipEventCreateWithFlags(&g->arena_copied, hipEventDisableTiming));
+        TD_HIP(hipMalloc(&g->d_scalar, 256));
+    }
+    return 1;
+}
+
+static int ensure_state_slots(td_graph* g) {
+    const size_t need = g->hstate.size();
+    if (need > g->dstate_cap) {
+        const size_t cap = std::max<size_t>(64, need * 2);
+        StateSlot* nd = nullptr;
+        TD_HIP(hipMalloc(&nd, cap * sizeof(StateSlot)));
+        if (g->dstate) {
+            TD_HIP(hipStreamSynchronize(g->stream));
+            TD_HIP(hipMemcpy(nd, g->dstate, g->dstate_cap * sizeof(StateSlot), hipMemcpyDeviceToDevice));
+            TD_HIP(hipFree(g->dstate));
+        }
+        g->dstate = nd;
+        g->dstate_cap = cap;
+    }
+    if (g->state_host_dirty && need) {
+        // host mirror is authoritative only right after construction / explicit host edits
+        TD_HIP(hipStreamSynchronize(g->stream));
+        TD_HIP(hipMemcpy(g->dstate, g->hstate.data(), need * sizeof(StateSlot), hipMemcpyHostToDevice));
+        g->state_host_dirty = false;
+    }
+    return 1;
+}
+
+static int pull_state(td_graph* g) {
+    if (g->state_dev_dirty && g->dstate && !g->hstate.empty()) {
+        if (!ensure_device(g->device)) return 0;
+        TD_HIP(hipStreamSynchronize(g->stream));
+        TD_HIP(hipMemcpy(g->hstate.data(), g->dstate, g->hstate.size() * sizeof(StateSlot), hipMemcpyDeviceToHost));
+        g->state_dev_dirty = false;
+    }
+    return 1;
+}
+
+static int ensure_buffers(td_graph* g, size_t frames) {
+    frames += frames & 1;
+    if (frames > g->cap_frames) {
+        TD_HIP(hipStreamSynchronize(g->stream));
+        for (float2* p : g->pool) {
+            (void)hipFree(p);
+            g->device_bytes -= g->cap_frames * sizeof(float2);
+        }
+        g->pool.clear();
+        g->cap_frames = frames;
+    }
+    g->free_bufs = g->pool;
+    return 1;
+}
+static float2* take_buffer(td_graph* g) {
+    if (!g->free_bufs.empty()) {
+        float2* p = g->free_bufs.back();
+        g->free_bufs.pop_back();
+        return p;
+    }
+    float2* p = nullptr;
+    if (hipMalloc(&p, g->cap_frames * sizeof(float2)) != hipSuccess) return nullptr;
+    g->pool.push_back(p);
+    g->device_bytes += g->cap_frames * sizeof(float2);
+    return p;
+}
+
+static int ensure_arena(td_graph* g, size_t bytes) {
+    if (bytes <= g->arena_cap) return 1;
+    const size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
+    TD_HIP(hipStreamSynchronize(g->stream));
+    if (g->harena) (void)hipHostFree(g->harena);
+    if (g->darena) {
+        (void)hipFree(g->darena);
+        g->device_bytes -= g->arena_cap;
+    }
+    g->harena = nullptr;
+    g->darena = nullptr;
+    TD_HIP(hipHostMalloc(&g->harena, cap, hipHostMallocDefault));
+    TD_HIP(hipMalloc(&g->darena, cap));
+    g->arena_cap = cap;
+    g->device_bytes += cap;
+    g->arena_inflight = false;
+    return 1;
+}
+
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SUM, F_PREFIX, F_SCALE, F_ADSR, F_BAND, F_QUANT, F_COUNT };
+static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
+                                           "k_synth",       "k_sum",          "k_prefix_max",  "k_scale",
+                                           "k_adsr",        "k_band_pass",    "k_quantise"};
+
+static hipEvent_t get_event(td_graph* g) {
+    if (!g->ev_free.empty()) {
+        hipEvent_t e = g->ev_free.back();
+        g->ev_free.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Prof {
+    td_graph* g;
+    int fam;
+    hipEvent_t a = nullptr, b = nullptr;
+    Prof(td_graph* g_, int fam_) : g(g_), fam(fam_) {
+        if (g->profiling) {
+            a = get_event(g);
+            b = get_event(g);
+            (void)hipEventRecord(a, g->stream);
+        }
+    }
+    ~Prof() {
+        if (g->profiling) {
+            (void)hipEventRecord(b, g->stream);
+            g->ev_pending.push_back({a, b, fam});
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// one chunk: compile tables, upload, launch level by level
+// ------------------------------------------------------------------------------------------------
+static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
+                     const std::vector<BlockCursor>& cur, uint64_t t0, bool is_scan, void* pcm_dst, int qmode,
+                     float amplitude) {
+    const size_t bl = g->bl, sr = g->sr;
+    const size_t nb = cur.size();
+    const size_t M = nb * bl;
+    if (M == 0) return 1;
+    if (M > 0xFFFFFFF0ull) return fail("termdaw_amd: chunk too long");
+    const size_t nv = g->vertices.size();
+
+    // ---- 1. host compile: sequential bookkeeping -> tables
+    Staging st;
+    std::vector<VTables> vt(nv);
+    for (size_t vi : g->order) {
+        Vertex& v = g->vertices[vi];
+        vt[vi].t0 = t0;
+        switch (v.kind) {
+            case K_SAMPLE_LOOP:
+                if (v.sample_index >= sb->samples.size()) return fail("sampleloop: sample index out of range");
+                vt[vi].t0 = v.loop_t;
+                v.loop_t += M;   // *t += len per block (extensions.rs:340)
+                break;
+            case K_SAMPLE_MULTI:
+                if (v.sample_index >= sb->samples.size()) return fail("sample_multi: sample index out of range");
+                compile_multi(v, sb->samples[v.sample_index].len, fb, cur, bl, st, vt[vi]);
+                break;
+            case K_SAMPLE_LERP:
+                if (v.sample_index >= sb->samples.size()) return fail("sample_lerp: sample index out of range");
+                compile_lerp(v, fb, cur, bl, st, vt[vi]);
+                break;
+            case K_DEBUG_SINE: compile_sine(v, fb, cur, bl, st, vt[vi]); break;
+            case K_SYNTH:
+                if (!compile_synth(v, fb, cur, bl, sr, st, vt[vi])) return 0;
+                break;
+            case K_ADSR:
+                if (!(v.wet < 0.0001f)) compile_adsr(v, fb, cur, bl, sr, st, vt[vi]);   // :598 early return keeps clocks
+                break;
+            default: break;
+        }
+    }
+
+    // ---- 2. descriptors: walk levels, assign edge buffers
+    if (!ensure_buffers(g, M)) return 0;
+    g->vbuf.assign(nv, nullptr);
+    std::vector<int> last_use(nv, -1);
+    for (size_t vi : g->order)
+        for (size_t u : g->edges[vi]) last_use[u] = std::max(last_use[u], g->level[vi]);
+
+    struct Launch { int fam; size_t off; int n; };
+    std::vector<Launch> launches;
+    std::vector<std::vector<size_t>> by_level(g->n_levels);
+    for (size_t vi : g->order) by_level[g->level[vi]].push_back(vi);
+
+    // scratch (device-only) region is laid out after the uploaded region
+    size_t scratch_bytes = 0;
+    auto scratch = [&](size_t n) { size_t o = scratch_bytes; scratch_bytes += (n + 255) & ~(size_t)255; return o; };
+    struct Fix { size_t at; size_t scratch_off; };   // pointer fields patched once the upload size is known
+    std::vector<Fix> fixes;
+    struct PtrFix { size_t at; size_t staging_off; };   // pointers into the uploaded region
+    std::vector<PtrFix> pfix;
+
+    auto ptr_field = [&](size_t desc_off, size_t field_off, size_t staging_off) {
+        pfix.push_back({desc_off + field_off, staging_off});
+    };
+    auto scratch_field = [&](size_t desc_off, size_t field_off, size_t s_off) { fixes.push_back({desc_off + field_off, s_off}); };
+
+    std::vector<size_t> peaks_to_zero;   // scratch offsets needing a memset
+    const bool peaks_need_zero = !(bl == (size_t)kTileFrames);
+
+    for (int lv = 0; lv < g->n_levels; ++lv) {
+        std::vector<size_t> fam_v[F_COUNT];
+        for (size_t vi : by_level[lv]) {
+            Vertex& v = g->vertices[vi];
+            g->vbuf[vi] = take_buffer(g);
+            if (!g->vbuf[vi]) return fail("termdaw_amd: out of device memory for edge buffers");
+            switch (v.kind) {
+                case K_SAMPLE_LOOP: fam_v[F_LOOP].push_back(vi); break;
+                case K_SAMPLE_MULTI: fam_v[F_MULTI].push_back(vi); break;
+                case K_SAMPLE_LERP: fam_v[F_LERP].push_back(vi); break;
+                case K_DEBUG_SINE: fam_v[F_SINE].push_back(vi); break;
+                case K_SYNTH: fam_v[F_SYNTH].push_back(vi); break;
+                case K_SUM: fam_v[F_SUM].push_back(vi); break;
+                case K_NORMALIZE: fam_v[F_SUM].push_back(vi); fam_v[F_PREFIX].push_back(vi); fam_v[F_SCALE].push_back(vi); break;
+                case K_ADSR: fam_v[(v.wet < 0.0001f) ? F_SUM : F_ADSR].push_back(vi); break;
+                case K_BAND_PASS:
+                    fam_v[(v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) ? F_SUM : F_BAND].push_back(vi);
+                    break;
+                default: break;
+            }
+        }
+        // input pointer tables
+        std::map<size_t, size_t> ins_off;
+        for (size_t vi : by_level[lv]) {
+            if (!g->vertices[vi].has_input()) continue;
+            std::vector<const float2*> ins;
+            for (size_t u : g->edges[vi]) ins.push_back(g->vbuf[u]);
+            ins_off[vi] = st.put(ins);
+        }
+        std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, rscale)
+        for (int fam = 0; fam < F_COUNT; ++fam) {
+            auto& vs = fam_v[fam];
+            if (vs.empty()) continue;
+            size_t off = 0;
+            switch (fam) {
+                case F_LOOP: {
+                    std::vector<LoopDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        const SampleEntry& s = sb->samples[v.sample_index];
+                        d.push_back({s.d, g->vbuf[vi], s.len, vt[vi].t0, make_pg(v.gain, v.angle)});
+                    }
+                    off = st.put(d);
+                } break;
+                case F_MULTI: {
+                    std::vector<MultiDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        const SampleEntry& s = sb->samples[v.sample_index];
+                        d.push_back({s.d, g->vbuf[vi], nullptr, s.len, vt[vi].n_hits, 0, make_pg(v.gain, v.angle)});
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i)
+                        ptr_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, hits), vt[vs[i]].hits_off);
+                } break;
+                case F_LERP: {
+                    std::vector<LerpDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        const SampleEntry& s = sb->samples[v.sample_index];
+                        d.push_back({s.d, g->vbuf[vi], nullptr, s.len, vt[vi].n_hits, (uint32_t)v.lerp_len,
+                                     make_pg(v.gain, v.angle)});
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i)
+                        ptr_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, hits), vt[vs[i]].hits_off);
+                } break;
+                case F_SINE: {
+                    std::vector<SineDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        SineDesc x{};
+                        x.tab.n_int = vt[vi].n_int;
+                        x.out = g->vbuf[vi];
+                        x.t0 = t0;
+                        x.sr = (uint32_t)sr;
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(SineDesc) + offsetof(SineDesc, tab);
+                        ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
+                        ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                    }
+                } break;
+                case F_SYNTH: {
+                    std::vector<SynthDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        SynthDesc x{};
+                        x.tab.n_int = vt[vi].n_int;
+                        x.out = g->vbuf[vi];
+                        x.t0 = t0;
+                        x.sr = (uint32_t)sr;
+                        x.bl = (uint32_t)bl;
+                        x.square = v.square;
+                        x.topflat = v.topflat;
+                        x.triangle = v.triangle;
+                        x.osc_amp_multiplier =   // extensions.rs:465-468
+                            1.0f / (v.square.volume * adsr_max_vel(v.square.adsr) +
+                                    v.topflat.volume * adsr_max_vel(v.topflat.adsr) +
+                                    v.triangle.volume * adsr_max_vel(v.triangle.adsr));
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(SynthDesc) + offsetof(SynthDesc, tab);
+                        ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
+                        ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                    }
+                } break;
+                case F_SUM: {
+                    std::vector<SumDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        SumDesc x{};
+                        x.out = g->vbuf[vi];
+                        x.k = (uint32_t)g->edges[vi].size();
+                        x.mode = v.kind == K_NORMALIZE ? 1u : 0u;
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(SumDesc);
+                        ptr_field(o, offsetof(SumDesc, ins), ins_off[vs[i]]);
+                        if (g->vertices[vs[i]].kind == K_NORMALIZE) {
+                            const size_t pk = scratch(nb * sizeof(float)), rs = scratch(nb * sizeof(float));
+                            norm_scratch[vs[i]] = {pk, rs};
+                            scratch_field(o, offsetof(SumDesc, peaks), pk);
+                            if (peaks_need_zero) peaks_to_zero.push_back(pk);
+                        }
+                    }
+                } break;
+                case F_PREFIX: {
+                    std::vector<PrefixMaxDesc> d;
+                    for (size_t vi : vs) d.push_back({nullptr, nullptr, &g->dstate[g->vertices[vi].state_slot].norm});
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(PrefixMaxDesc);
+                        scratch_field(o, offsetof(PrefixMaxDesc, peaks), norm_scratch[vs[i]].first);
+                        scratch_field(o, offsetof(PrefixMaxDesc, rscale), norm_scratch[vs[i]].second);
+                    }
+                } break;
+                case F_SCALE: {
+                    std::vector<ScaleDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        const bool is_out = (long)vi == g->output_vertex && pcm_dst && qmode;
+                        d.push_back({g->vbuf[vi], nullptr, is_out ? pcm_dst : nullptr, amplitude, is_out ? (uint32_t)qmode : 0u,
+                                     make_pg(v.gain, v.angle)});
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i)
+                        scratch_field(off + i * sizeof(ScaleDesc), offsetof(ScaleDesc, rscale), norm_scratch[vs[i]].second);
+                } break;
+                case F_ADSR: {
+                    std::vector<AdsrVDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        AdsrVDesc x{};
+                        x.tab.n_int = vt[vi].n_int;
+                        x.out = g->vbuf[vi];
+                        x.k = (uint32_t)g->edges[vi].size();
+                        x.sr = (uint32_t)sr;
+                        x.bl = (uint32_t)bl;
+                        x.use_off = v.use_off;
+                        x.use_max = v.use_max;
+                        x.wet = v.wet;
+                        x.conf = v.conf;
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(AdsrVDesc);
+                        ptr_field(o, offsetof(AdsrVDesc, ins), ins_off[vs[i]]);
+                        const size_t t = o + offsetof(AdsrVDesc, tab);
+                        ptr_field(t, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(t, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
+                        ptr_field(t, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                    }
+                } break;
+                case F_BAND: {
+                    std::vector<BandDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        BandDesc x{};
+                        x.out = g->vbuf[vi];
+                        x.state = &g->dstate[v.state_slot].band;
+                        x.k = (uint32_t)g->edges[vi].size();
+                        x.pass = v.pass;
+                        x.lgamma = v.lgamma;
+                        x.hgamma = v.hgamma;
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i)
+                        ptr_field(off + i * sizeof(BandDesc), offsetof(BandDesc, ins), ins_off[vs[i]]);
+                } break;
+                default: continue;
+            }
+            launches.push_back({fam, off, (int)vs.size()});
+        }
+        // release buffers whose last consumer sits at this level
+        for (size_t vi : g->order)
+            if (g->vbuf[vi] && last_use[vi] == lv && (long)vi != g->output_vertex) {
+                g->free_bufs.push_back(g->vbuf[vi]);
+                // keep vbuf[vi] for descriptor bookkeeping of this level only
+                last_use[vi] = -2;
+            }
+    }
+    // un-fused quantise when the output vertex is not a Normalize
+    const Vertex& outv = g->vertices[(size_t)g->output_vertex];
+    if (pcm_dst && qmode && outv.kind != K_NORMALIZE) {
+        std::vector<QuantDesc> d{{g->vbuf[(size_t)g->output_vertex], pcm_dst, amplitude, (uint32_t)qmode}};
+        launches.push_back({F_QUANT, st.put(d), 1});
+    }
+
+    // ---- 3. upload
+    const size_t upload = (st.b.size() + 255) & ~(size_t)255;
+    if (!ensure_arena(g, upload + scratch_bytes + 256)) return 0;
+    for (auto& f : pfix) {
+        uint64_t p = (uint64_t)(uintptr_t)(g->darena + f.staging_off);
+        memcpy(&st.b[f.at], &p, 8);
+    }
+    for (auto& f : fixes) {
+        uint64_t p = (uint64_t)(uintptr_t)(g->darena + upload + f.scratch_off);
+        memcpy(&st.b[f.at], &p, 8);
+    }
+    if (g->arena_inflight) TD_HIP(hipEventSynchronize(g->arena_copied));
+    memcpy(g->harena, st.b.data(), st.b.size());
+    TD_HIP(hipMemcpyAsync(g->darena, g->harena, st.b.size(), hipMemcpyHostToDevice, g->stream));
+    TD_HIP(hipEventRecord(g->arena_copied, g->stream));
+    g->arena_inflight = true;
+    for (size_t pk : peaks_to_zero) TD_HIP(hipMemsetAsync(g->darena + upload + pk, 0, nb * sizeof(float), g->stream));
+
+    // ---- 4. launch
+    for (auto& L : launches) {
+        const void* d = g->darena + L.off;
+        Prof prof(g, L.fam);
+        switch (L.fam) {
+            case F_LOOP: launch_sample_loop((const LoopDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_MULTI: launch_sample_multi((const MultiDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_LERP: launch_sample_lerp((const LerpDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, g->stream); break;
+            case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, g->stream); break;
+            case F_PREFIX: launch_prefix_max((const PrefixMaxDesc*)d, L.n, (uint32_t)nb, is_scan ? 1 : 0, g->stream); break;
+            case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, g->stream); break;
+            case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, (uint32_t)M, g->stream); break;
+        }
+    }
+    TD_HIP(hipGetLastError());
+    g->state_dev_dirty = true;
+    return 1;
+}
+
+// Renders n_blocks blocks in chunks.  advance_graph_time: Graph::render semantics (t += bl per block);
+// otherwise the scan's explicit j*bl clock starting at scan_t0 (graph.rs:229-233).  The FlowwBank is
+// advanced one block at a time exactly like state.rs:572 / graph.rs:232.
+int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
+                        int bits, bool advance_graph_time, size_t scan_t0, bool want_pcm) {
+    if (!ensure_graph_device(g)) return 0;
+    if (g->output_vertex < 0) return fail("TermDaw: error: output vertex not found.");
+    if (g->plan_dirty) build_plan(g);
+    if (!ensure_state_slots(g)) return 0;
+    const size_t bl = g->bl;
+    if (bl == 0) return fail("termdaw_amd: buffer length 0");
+    const size_t total = n_blocks * bl;
+    size_t chunk_blocks = std::max<size_t>(1, g->max_chunk_frames / bl);
+    chunk_blocks = std::min(chunk_blocks, std::max<size_t>(n_blocks, 1));
+    const bool multi = n_blocks > chunk_blocks;
+    int qmode = 0;
+    float amplitude = 0.f;
+    size_t word = 0;
+    if (want_pcm) {
+        if (!(bits == 8 || bits == 16 || bits == 24 || bits == 32))   // state.rs:495-501
+            return fail("Bitdepth not supported: choose bitdepth in {8, 16, 24, 32}.");
+        qmode = bits > 16 ? 2 : 1;                                    // write_16s / write_32s, state.rs:567-571
+        amplitude = bits < 32 ? (float)((1 << (bits - 1)) - 1) : (float)INT32_MAX;   // state.rs:515-516
+        word = qmode == 1 ? 2 : 4;
+        const size_t need = total * 2 * word + 64;
+        if (need > g->pcm_cap) {
+            TD_HIP(hipStreamSynchronize(g->stream));
+            if (g->d_pcm) { (void)hipFree(g->d_pcm); g->device_bytes -= g->pcm_cap; }
+            TD_HIP(hipMalloc(&g->d_pcm, need));
+            g->pcm_cap = need;
+            g->device_bytes += need;
+        }
+        g->pcm_bytes = total * 2 * word;
+    }
+    if (multi) {
+        const size_t need = (total + 2) * sizeof(float2);
+        if (need > g->out_f32_cap) {
+            TD_HIP(hipStreamSynchronize(g->stream));
+            if (g->d_out_f32) { (void)hipFree(g->d_out_f32); g->device_bytes -= g->out_f32_cap; }
+            TD_HIP(hipMalloc(&g->d_out_f32, need));
+            g->out_f32_cap = need;
+            g->device_bytes += need;
+        }
+    }
+    size_t done = 0;
+    while (done < n_blocks) {
+        const size_t nb = std::min(chunk_blocks, n_blocks - done);
+        std::vector<BlockCursor> cur(nb);
+        for (size_t b = 0; b < nb; ++b) {
+            cur[b].frame = fb->frame;
+            cur[b].start = fb->start_indices;
+            fb->set_time_to_next_block();
+        }
+        const uint64_t t0 = advance_graph_time ? g->t : scan_t0 + done * bl;
+        void* pcm_dst = want_pcm ? (uint8_t*)g->d_pcm + done * bl * 2 * word : nullptr;
+        if (!run_chunk(g, sb, fb, cur, t0, is_scan, pcm_dst, qmode, amplitude)) return 0;
+        if (advance_graph_time) g->t += nb * bl;
+        if (multi)
+            TD_HIP(hipMemcpyAsync(g->d_out_f32 + done * bl, g->vbuf[(size_t)g->output_vertex], nb * bl * sizeof(float2),
+                                  hipMemcpyDeviceToDevice, g->stream));
+        done += nb;
+    }
+    g->last_out_f32 = multi ? g->d_out_f32 : (n_blocks ? g->vbuf[(size_t)g->output_vertex] : nullptr);
+    g->last_frames = total;
+    g->last_bits = bits;
+    return 1;
+}
+
+static int graph_set_time_impl(td_graph* g, size_t time) {   // graph.rs:123-128 + extensions.rs:196-204
+    g->t = time;
+    for (auto& v : g->vertices) {
+        switch (v.kind) {
+            case K_SAMPLE_LOOP: v.loop_t = time; break;
+            case K_DEBUG_SINE: v.sine_notes.clear(); break;
+            case K_SYNTH: v.notes.clear(); break;
+            case K_BAND_PASS:
+                if (v.state_slot >= 0) {
+                    g->hstate[v.state_slot].band.first = 1u;
+                    if (g->dstate && (size_t)v.state_slot < g->dstate_cap && !g->state_host_dirty) {
+                        if (!ensure_device(g->device)) return 0;
+                        TD_HIP(hipMemsetD32Async((hipDeviceptr_t)&g->dstate[v.state_slot].band.first, 1, 1, g->stream));
+                    }
+                }
+                break;
+            default: break;
+        }
+    }
+    return 1;
+}
+
+}  // namespace tde
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" {
+
+const char* td_last_error(void) { return g_error.c_str(); }
+
+int td_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int td_set_device(int device) {
+    if (!ensure_device(device)) return 0;
+    t_device = device;
+    return 1;
+}
+
+// ---- SampleBank ----
+td_samplebank* td_samplebank_new(size_t sample_rate) {
+    td_samplebank* sb = new td_samplebank();
+    sb->sample_rate = sample_rate;
+    sb->device = t_device;
+    return sb;
+}
+void td_samplebank_free(td_samplebank* sb) {
+    if (!sb) return;
+    if (!sb->samples.empty() && hipSetDevice(sb->device) == hipSuccess)
+        for (auto& e : sb->samples) (void)hipFree(e.d);
+    delete sb;
+}
+int td_samplebank_add_decoded(td_samplebank* sb, const char* name, const float* linear, size_t n, int channels,
+                              size_t sample_rate, size_t bits, const char* method) {
+    std::vector<float> v(linear, linear + n);
+    return bank_add_decoded(sb, name, v, channels, sample_rate, bits, method_from(method));
+}
+int td_samplebank_add_file(td_samplebank* sb, const char* name, const char* path, const char* method) {
+    if (sb->names.count(name))
+        return fail(std::string("TermDaw: SampleBank: there is already a sample with name \"") + name + "\" present.");
+    tdw::WavData w;
+    std::string err;
+    if (!tdw::read_wav(path, &w, &err)) return fail(err);
+    return bank_add_decoded(sb, name, w.linear, w.channels, w.sample_rate, w.bits, method_from(method));
+}
+long td_samplebank_get_index(const td_samplebank* sb, const char* name) {
+    auto it = sb->names.find(name);
+    return it == sb->names.end() ? -1 : (long)it->second;
+}
+size_t td_samplebank_sample_len(const td_samplebank* sb, size_t index) {
+    return index < sb->samples.size() ? sb->samples[index].len : 0;
+}
+int td_samplebank_read(const td_samplebank* sb, size_t index, float* l, float* r) {
+    if (index >= sb->samples.size()) return fail("sample index out of range");
+    if (!ensure_device(sb->device)) return 0;
+    const SampleEntry& e = sb->samples[index];
+    std::vector<float2> tmp(e.len);
+    TD_HIP(hipMemcpy(tmp.data(), e.d, e.len * sizeof(float2), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < e.len; ++i) {
+        l[i] = tmp[i].x;
+        r[i] = tmp[i].y;
+    }
+    return 1;
+}
+void td_samplebank_get_max_sr_bd(const td_samplebank* sb, size_t* max_sr, size_t* max_bd) {
+    if (max_sr) *max_sr = sb->max_sr;
+    if (max_bd) *max_bd = sb->max_bd;
+}
+
+// ---- FlowwBank ----
+td_flowwbank* td_flowwbank_new(size_t sr, size_t bl) {
+    td_flowwbank* fb = new td_flowwbank();
+    fb->sr = sr;
+    fb->bl = bl;
+    return fb;
+}
+void td_flowwbank_free(td_flowwbank* fb) { delete fb; }
+void td_flowwbank_reset(td_flowwbank* fb) {
+    fb->frame = 0;
+    fb->flowws.clear();
+    fb->start_indices.clear();
+    fb->names.clear();
+    fb->stream_list.clear();
+}
+long td_flowwbank_add_events(td_flowwbank* fb, const char* name, const td_event* events, size_t n) {
+    fb->flowws.emplace_back(events, events + n);
+    fb->start_indices.push_back(0);
+    const size_t index = fb->flowws.size() - 1;
+    fb->names[name] = index;
+    return (long)index;
+}
+long td_flowwbank_declare_stream(td_flowwbank* fb, const char* name) {
+    long i = td_flowwbank_add_events(fb, name, nullptr, 0);
+    fb->stream_list.push_back((size_t)i);
+    return i;
+}
+long td_flowwbank_get_index(const td_flowwbank* fb, const char* name) {
+    auto it = fb->names.find(name);
+    return it == fb->names.end() ? -1 : (long)it->second;
+}
+void td_flowwbank_set_time(td_flowwbank* fb, size_t t) { fb->set_time(t); }
+void td_flowwbank_set_time_to_next_block(td_flowwbank* fb) { fb->set_time_to_next_block(); }
+
+// ---- Graph ----
+td_graph* td_graph_new(size_t max_buffer_len, size_t sr) {
+    td_graph* g = new td_graph();
+    g->bl = max_buffer_len;
+    g->sr = sr;
+    g->device = t_device;
+    return g;
+}
+void td_graph_free(td_graph* g) {
+    if (!g) return;
+    if (g->stream && hipSetDevice(g->device) == hipSuccess) {
+        (void)hipStreamSynchronize(g->stream);
+        for (float2* p : g->pool) (void)hipFree(p);
+        if (g->dstate) (void)hipFree(g->dstate);
+        if (g->harena) (void)hipHostFree(g->harena);
+        if (g->darena) (void)hipFree(g->darena);
+        if (g->d_pcm) (void)hipFree(g->d_pcm);
+        if (g->d_out_f32) (void)hipFree(g->d_out_f32);
+        if (g->d_scalar) (void)hipFree(g->d_scalar);
+        for (auto& e : g->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        for (auto e : g->ev_free) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(g->arena_copied);
+        (void)hipStreamDestroy(g->stream);
+    }
+    delete g;
+}
+void td_graph_reset(td_graph* g) {
+    g->vertices.clear();
+    g->edges.clear();
+    g->name_map.clear();
+    g->output_vertex = -1;
+    g->t = 0;
+    g->hstate.clear();
+    g->state_host_dirty = true;
+    g->state_dev_dirty = false;
+    g->plan_dirty = true;
+}
+
+static Vertex& add_vertex(td_graph* g, const char* name, float gain, float angle, float wet, Kind kind) {
+    Vertex v;
+    v.kind = kind;
+    v.name = name;
+    v.gain = gain;
+    v.angle = fmaxf(fminf(angle, 90.0f), -90.0f);   // graph.rs:255
+    v.wet = fmaxf(fminf(wet, 1.0f), 0.0f);          // graph.rs:256
+    g->vertices.push_back(v);
+    g->edges.emplace_back();
+    g->name_map[name] = g->vertices.size() - 1;     // later duplicates overwrite (graph.rs:54)
+    g->plan_dirty = true;
+    return g->vertices.back();
+}
+static int new_slot(td_graph* g) {
+    // a freshly constructed slot makes the host mirror authoritative: fetch device values first
+    pull_state(g);
+    StateSlot s;
+    memset(&s, 0, sizeof s);
+    g->hstate.push_back(s);
+    g->state_host_dirty = true;
+    return (int)g->hstate.size() - 1;
+}
+static bool conf_from(const float* arr, int n, AdsrConfD* c) {   // adsr.rs:94-114
+    if (n == 0) { *c = AdsrConfD{0, 0, 0, 0, 0, 0, 0, 0, 0}; return true; }
+    if (n == 6) { *c = AdsrConfD{0.0f, arr[0], 1.0f, arr[1], arr[2], arr[3], arr[4], arr[5], 0.0f}; return true; }
+    if (n == 9) { *c = AdsrConfD{arr[0], arr[1], arr[2], arr[3], arr[4], arr[5], arr[6], arr[7], arr[8]}; return true; }
+    return false;
+}
+
+int td_graph_add_sum(td_graph* g, const char* name, float gain, float angle) {
+    add_vertex(g, name, gain, angle, 0.0f, K_SUM);
+    return 1;
+}
+int td_graph_add_normalize(td_graph* g, const char* name, float gain, float angle) {
+    const int slot = new_slot(g);
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_NORMALIZE);
+    v.state_slot = slot;
+    g->hstate[slot].norm = {0.0f, 0.0f};   // extensions.rs:87-92
+    return 1;
+}
+int td_graph_add_sampleloop(td_graph* g, const char* name, float gain, float angle, size_t sample_index) {
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SAMPLE_LOOP);
+    v.sample_index = sample_index;
+    return 1;
+}
+int td_graph_add_sample_multi(td_graph* g, const char* name, float gain, float angle, size_t sample_index,
+                              size_t floww_index, int note) {
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SAMPLE_MULTI);
+    v.sample_index = sample_index;
+    v.floww_index = floww_index;
+    v.has_note = !(note < 0);   // state.rs:358-359
+    v.note = v.has_note ? (size_t)note : 0;
+    return 1;
+}
+int td_graph_add_sample_lerp(td_graph* g, const char* name, float gain, float angle, size_t sample_index,
+                             size_t floww_index, int note, int lerp_len) {
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SAMPLE_LERP);
+    v.sample_index = sample_index;
+    v.floww_index = floww_index;
+    v.has_note = !(note < 0);   // state.rs:368-369
+    v.note = v.has_note ? (size_t)note : 0;
+    v.lerp_len = (size_t)std::max(lerp_len, 0);   // state.rs:370
+    return 1;
+}
+int td_graph_add_debug_sine(td_graph* g, const char* name, float gain, float angle, size_t floww_index) {
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_DEBUG_SINE);
+    v.floww_index = floww_index;
+    return 1;
+}
+int td_graph_add_synth(td_graph* g, const char* name, float gain, float angle, size_t floww_index, float square_vel,
+                       float square_z, const float* square_adsr, int square_adsr_len, float topflat_vel,
+                       float topflat_z, const float* topflat_adsr, int topflat_adsr_len, float triangle_vel,
+                       const float* triangle_adsr, int triangle_adsr_len) {
+    AdsrConfD sq, tf, tr;
+    if (!conf_from(square_adsr, square_adsr_len, &sq) || !conf_from(topflat_adsr, topflat_adsr_len, &tf) ||
+        !conf_from(triangle_adsr, triangle_adsr_len, &tr))
+        return fail("ADSR config must have 6 or 9 elements");   // state.rs:393 panics
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SYNTH);
+    v.floww_index = floww_index;
+    v.square = {square_vel, fmaxf(square_z, 0.0001f), sq};   // state.rs:400
+    v.topflat = {topflat_vel, topflat_z, tf};
+    v.triangle = {triangle_vel, 0.0f, tr};
+    return 1;
+}
+int td_graph_add_adsr(td_graph* g, const char* name, float gain, float angle, float wet, size_t floww_index,
+                      int use_off, int use_max, int note, const float* adsr, int adsr_len) {
+    AdsrConfD c;
+    if (!conf_from(adsr, adsr_len, &c)) return fail("ADSR config must have 6 or 9 elements");   // state.rs:444
+    Vertex& v = add_vertex(g, name, gain, angle, wet, K_ADSR);
+    v.floww_index = floww_index;
+    v.use_off = use_off != 0;
+    v.use_max = use_max != 0;
+    v.has_note = !(note < 0);   // state.rs:439-440
+    v.note = v.has_note ? (size_t)note : 0;
+    v.conf = c;
+    return 1;
+}
+static float band_gamma(float hz, size_t sampling_hz) {   // extensions.rs:176-183
+    const float co = fmaxf(fminf(hz, 20000.0f), 0.0f);
+    return 1.0f - powf(2.71828182845904523536f, -2.0f * 3.14159274101257324f * co / (float)sampling_hz);
+}
+int td_graph_add_bandpass(td_graph* g, const char* name, float gain, float angle, float wet, float cut_off_hz_low,
+                          float cut_off_hz_high, int pass) {
+    const int slot = new_slot(g);
+    Vertex& v = add_vertex(g, name, gain, angle, wet, K_BAND_PASS);
+    v.lgamma = band_gamma(cut_off_hz_low, g->sr);
+    v.hgamma = band_gamma(cut_off_hz_high, g->sr);
+    v.pass = pass != 0;
+    v.state_slot = slot;
+    g->hstate[slot].band = {0.f, 0.f, 0.f, 0.f, 1u, {0, 0, 0}};
+    return 1;
+}
+
+static bool has_loop(size_t x, size_t b, const std::vector<std::vector<size_t>>& edges) {   // graph.rs:66-72
+    if (x == b) return true;
+    for (size_t y : edges[x])
+        if (has_loop(y, b, edges)) return true;
+    return false;
+}
+int td_graph_connect(td_graph* g, const char* a, const char* b) {   // graph.rs:58-96
+    auto ia = g->name_map.find(a), ib = g->name_map.find(b);
+    if (ia == g->name_map.end()) return fail(std::string("TermDaw: warning: vertex \"") + a + "\" cannot be found and thus can't be connected.");
+    if (ib == g->name_map.end()) return fail(std::string("TermDaw: warning: vertex \"") + b + "\" cannot be found and thus can't be connected to.");
+    const size_t ai = ia->second, bi = ib->second;
+    if (ai == bi) return fail("connect: self edge");
+    if (!g->vertices[bi].has_input()) return fail("connect: target vertex takes no input");
+    if (has_loop(ai, bi, g->edges)) return fail("connect: edge would close a loop");
+    g->edges[bi].push_back(ai);
+    g->plan_dirty = true;
+    return 1;
+}
+int td_graph_set_output(td_graph* g, const char* vertex) {
+    auto it = g->name_map.find(vertex);
+    if (it == g->name_map.end()) return fail("set_output: vertex not found");
+    g->output_vertex = (long)it->second;
+    g->plan_dirty = true;
+    return 1;
+}
+int td_graph_check(const td_graph* g) {   // graph.rs:150-174
+    if (g->output_vertex < 0) return fail("TermDaw: error: output vertex not found.");
+    const size_t out = (size_t)g->output_vertex;
+    if (g->edges[out].empty() && g->vertices[out].has_input()) return fail("TermDaw: error: output receives no inputs.");
+    return 1;
+}
+void td_graph_set_time(td_graph* g, size_t time) { graph_set_time_impl(g, time); }
+size_t td_graph_change_time(td_graph* g, size_t delta, int plus) {   // graph.rs:130-135
+    const size_t nt = plus ? g->t + delta : g->t - std::min(delta, g->t);
+    graph_set_time_impl(g, nt);
+    return nt;
+}
+size_t td_graph_get_time(const td_graph* g) { return g->t; }
+void td_graph_reset_normalize_vertices(td_graph* g) {   // extensions.rs:295-299
+    const float v = 0.000001f;
+    uint32_t bits;
+    memcpy(&bits, &v, 4);
+    for (auto& vx : g->vertices) {
+        if (vx.kind != K_NORMALIZE) continue;
+        g->hstate[vx.state_slot].norm.max = v;
+        if (g->dstate && (size_t)vx.state_slot < g->dstate_cap && !g->state_host_dirty && hipSetDevice(g->device) == hipSuccess)
+            (void)hipMemsetD32Async((hipDeviceptr_t)&g->dstate[vx.state_slot].norm.max, (int)bits, 1, g->stream);
+    }
+}
+float td_graph_get_normalization_value(const td_graph* gc, const char* name) {
+    td_graph* g = const_cast<td_graph*>(gc);
+    auto it = g->name_map.find(name);
+    if (it == g->name_map.end()) return -1.0f;
+    const Vertex& v = g->vertices[it->second];
+    if (v.kind != K_NORMALIZE) return -1.0f;
+    pull_state(g);
+    return g->hstate[v.state_slot].norm.max;
+}
+size_t td_graph_vertex_count(const td_graph* g) { return g->vertices.size(); }
+
+int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, float* l, float* r) {
+    if (g->output_vertex < 0) return 0;   // None
+    // Graph::render leaves the FlowwBank alone: run one block on a cursor snapshot
+    const size_t frame = fb->frame;
+    const std::vector<size_t> starts = fb->start_indices;
+    const int ok = graph_render_chunks(g, sb, fb, 1, false, 16, true, 0, false);
+    fb->frame = frame;
+    fb->start_indices = starts;
+    if (!ok) return 0;
+    std::vector<float2> tmp(g->bl);
+    TD_HIP(hipMemcpyAsync(tmp.data(), g->last_out_f32, g->bl * sizeof(float2), hipMemcpyDeviceToHost, g->stream));
+    TD_HIP(hipStreamSynchronize(g->stream));
+    for (size_t i = 0; i < g->bl; ++i) {
+        if (l) l[i] = tmp[i].x;
+        if (r) r[i] = tmp[i].y;
+    }
+    return 1;
+}
+
+int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t chunks) {   // graph.rs:222-237
+    if (g->output_vertex < 0) return 1;
+    if (!ensure_graph_device(g)) return 0;
+    if (g->plan_dirty) build_plan(g);
+    if (!ensure_state_slots(g)) return 0;
+    for (auto& v : g->vertices)   // reset_scan_normalization
+        if (v.kind == K_NORMALIZE)
+            TD_HIP(hipMemsetD32Async((hipDeviceptr_t)&g->dstate[v.state_slot].norm.scan_max, 0, 1, g->stream));
+    fb->set_time(0);
+    if (!graph_render_chunks(g, sb, fb, chunks, true, 16, false, 0, false)) return 0;
+    for (auto& v : g->vertices)   // apply_scan_normalization: max = scan_max
+        if (v.kind == K_NORMALIZE)
+            TD_HIP(hipMemcpyAsync(&g->dstate[v.state_slot].norm.max, &g->dstate[v.state_slot].norm.scan_max, 4,
+                                  hipMemcpyDeviceToDevice, g->stream));
+    g->state_dev_dirty = true;
+    if (!graph_set_time_impl(g, 0)) return 0;
+    fb->set_time(0);
+    TD_HIP(hipStreamSynchronize(g->stream));
+    return 1;
+}
+
+size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits) {
+    if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, true)) return 0;
+    if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
+    return n_blocks * g->bl;
+}
+int td_graph_sync(td_graph* g) {
+    if (!g->stream) return 1;
+    if (!ensure_device(g->device)) return 0;
+    TD_HIP(hipStreamSynchronize(g->stream));
+    return 1;
+}
+size_t td_graph_render_all(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits) {
+    const size_t n = td_graph_render_all_async(g, sb, fb, n_blocks, bits);
+    if (!n) return 0;
+    if (!td_graph_sync(g)) return 0;
+    return n;
+}
+const void* td_graph_output_pcm_device(const td_graph* g) { return g->d_pcm; }
+const float* td_graph_output_f32_device(const td_graph* g) { return (const float*)g->last_out_f32; }
+int td_graph_read_pcm(const td_graph* g, void* out, size_t bytes) {
+    if (!g->d_pcm || bytes > g->pcm_bytes) return fail("read_pcm: nothing rendered / size too large");
+    if (!ensure_device(g->device)) return 0;
+    TD_HIP(hipStreamSynchronize(g->stream));
+    TD_HIP(hipMemcpy(out, g->d_pcm, bytes, hipMemcpyDeviceToHost));
+    return 1;
+}
+int td_graph_read_f32(const td_graph* g, float* out, size_t n_floats) {
+    if (!g->last_out_f32 || n_floats > g->last_frames * 2) return fail("read_f32: nothing rendered / size too large");
+    if (!ensure_device(g->device)) return 0;
+    TD_HIP(hipStreamSynchronize(g->stream));
+    TD_HIP(hipMemcpy(out, g->last_out_f32, n_floats * sizeof(float), hipMemcpyDeviceToHost));
+    return 1;
+}
+float td_graph_output_peak(const td_graph* gc) {
+    td_graph* g = const_cast<td_graph*>(gc);
+    if (!g->last_out_f32 || !g->last_frames) return 0.0f;
+    if (!ensure_device(g->device)) return 0.0f;
+    launch_absmax((const float*)g->last_out_f32, (uint32_t)std::min<size_t>(g->last_frames * 2, 0xFFFFFFFFu), g->d_scalar,
+                  g->stream);
+    float v = 0.0f;
+    if (hipMemcpyAsync(&v, g->d_scalar, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return 0.0f;
+    (void)hipStreamSynchronize(g->stream);
+    return v;
+}
+void td_graph_set_profiling(td_graph* g, int on) {
+    g->profiling = on != 0;
+    for (auto& e : g->ev_pending) { g->ev_free.push_back(e.a); g->ev_free.push_back(e.b); }
+    g->ev_pending.clear();
+    g->last_times.clear();
+}
+size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float* ms, size_t* launches, size_t cap) {
+    td_graph* g = const_cast<td_graph*>(gc);
+    if (g->stream && hipSetDevice(g->device) == hipSuccess) {
+        (void)hipStreamSynchronize(g->stream);
+        if (g->last_times.empty()) {
+            g->last_times.resize(F_COUNT);
+            for (int f = 0; f < F_COUNT; ++f) g->last_times[f].name = kFamilyName[f];
+        }
+        for (auto& e : g->ev_pending) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {
+                g->last_times[e.fam].ms += t;
+                g->last_times[e.fam].launches += 1;
+            }
+            g->ev_free.push_back(e.a);
+            g->ev_free.push_back(e.b);
+        }
+        g->ev_pending.clear();
+    }
+    size_t n = 0;
+    for (auto& kt : g->last_times) {
+        if (!kt.launches) continue;
+        if (n < cap) {
+            names[n] = kt.name.c_str();
+            ms[n] = kt.ms;
+            launches[n] = kt.launches;
+        }
+        ++n;
+    }
+    return std::min(n, cap);
+}
+size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes; }
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// engine.h -- host-side data model behind the C ABI (include/termdaw_amd.h).
+//
+// The reference renders block by block with a recursive DFS (graph.rs:98-121, 182-193).  Here the
+// graph is *compiled* per chunk of whole blocks: a host pass replays only the cheap, inherently
+// sequential bookkeeping of the reference (event cursors floww.rs:70-141, voice lists, f32 envelope
+// clocks) into small tables, and every per-sample operation runs in the HIP kernels of kernels.hip,
+// one batched launch per (topological level, vertex kind).
+#pragma once
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/termdaw_amd.h"
+#include "kernels.h"
+
+namespace tde {
+
+extern thread_local std::string g_error;
+int fail(const std::string& msg);   // sets g_error, returns 0
+
+// ---- Rust cast emulation (saturating, truncating, NaN -> 0) ----
+size_t f32_as_usize(float x);
+
+struct SampleEntry {
+    float2* d = nullptr;   // interleaved frames in HBM
+    size_t len = 0;
+};
+
+}  // namespace tde
+
+struct td_samplebank {
+    size_t sample_rate = 0;
+    std::vector<tde::SampleEntry> samples;
+    std::map<std::string, size_t> names;
+    size_t max_sr = 0, max_bd = 0;
+    int device = 0;
+};
+
+struct td_flowwbank {
+    size_t sr = 0, bl = 0, frame = 0;
+    std::vector<std::vector<td_event>> flowws;
+    std::vector<size_t> start_indices;
+    std::map<std::string, size_t> names;
+    std::vector<size_t> stream_list;
+    size_t frame_of(const td_event& e) const { return tde::f32_as_usize(e.t_sec * (float)sr); }
+    void set_start_indices_to_frame(size_t t_frame, bool do_skip);
+    void set_time(size_t t);
+    void set_time_to_next_block();
+};
+
+namespace tde {
+
+enum Kind { K_SUM, K_NORMALIZE, K_SAMPLE_LOOP, K_SAMPLE_MULTI, K_SAMPLE_LERP, K_DEBUG_SINE, K_SYNTH,
+            K_ADSR, K_BAND_PASS, K_COUNT };
+
+struct SineNote { float note, vel; };
+struct SynthNote { float note, vel, env_t, rel_t; };
+struct Voice3 { float t, vel, rel; };
+
+struct Vertex {
+    Kind kind = K_SUM;
+    std::string name;
+    float gain = 1, angle = 0, wet = 0;
+    // parameters
+    size_t sample_index = 0, floww_index = 0;
+    bool has_note = false;
+    size_t note = 0;
+    size_t lerp_len = 0;
+    tdk::OscConfD square{}, topflat{}, triangle{};
+    tdk::AdsrConfD conf{};
+    bool use_off = false, use_max = false, pass = true;
+    float lgamma = 0, hgamma = 0;
+    // carried host state (what the reference keeps inside VertexExt, extensions.rs:15-80)
+    uint64_t loop_t = 0;
+    std::deque<std::pair<int64_t, float>> ts;
+    int64_t p_off = 0, g_off = 0;
+    float p_vel = 0, g_vel = 0;
+    uint64_t countdown = 0;
+    std::vector<SineNote> sine_notes;
+    std::vector<SynthNote> notes;
+    Voice3 ap{0, 0, 0}, ag{0, 0, 0};
+    // carried device state slot (Normalize / BandPass), index into Graph::dstate
+    int state_slot = -1;
+    bool has_input() const {
+        return kind == K_SUM || kind == K_NORMALIZE || kind == K_ADSR || kind == K_BAND_PASS;
+    }
+};
+
+// 32-byte slot: NormState or BandState
+union StateSlot {
+    tdk::NormState norm;
+    tdk::BandState band;
+};
+
+struct KernelTime { std::string name; float ms = 0; size_t launches = 0; };
+
+}  // namespace tde
+
+struct td_graph {
+    // graph.rs:12-22
+    std::vector<tde::Vertex> vertices;
+    std::vector<std::vector<size_t>> edges;   // reverse edges: edges[b] = [a...] in connect() order
+    std::map<std::string, size_t> name_map;
+    long output_vertex = -1;
+    size_t bl = 0, sr = 0, t = 0;
+
+    // ---- device side ----
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool plan_dirty = true;
+    std::vector<size_t> order;                // reachable vertices, topological (inputs first)
+    std::vector<int> level;                   // per vertex, -1 = unreachable
+    int n_levels = 0;
+    std::vector<float2*> pool;                // every edge buffer ever allocated (cap_frames each)
+    std::vector<float2*> free_bufs;
+    size_t cap_frames = 0;
+    std::vector<float2*> vbuf;                // per vertex, buffer for the current chunk
+    // carried device state
+    std::vector<tde::StateSlot> hstate;       // host mirror
+    tde::StateSlot* dstate = nullptr;
+    size_t dstate_cap = 0;
+    bool state_host_dirty = true, state_dev_dirty = false;
+    // per-chunk table arena (pinned host + device)
+    uint8_t* harena = nullptr;
+    uint8_t* darena = nullptr;
+    size_t arena_cap = 0;
+    hipEvent_t arena_copied = nullptr;
+    bool arena_inflight = false;
+    // outputs of the last render
+    void* d_pcm = nullptr;
+    size_t pcm_cap = 0, pcm_bytes = 0;
+    float2* d_out_f32 = nullptr;              // owned only for multi-chunk renders
+    size_t out_f32_cap = 0;
+    const float2* last_out_f32 = nullptr;
+    size_t last_frames = 0;
+    int last_bits = 16;
+    float* d_scalar = nullptr;
+    size_t device_bytes = 0;
+    size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)
+    // profiling
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; int fam; };
+    std::vector<EvPair> ev_pending;
+    std::vector<hipEvent_t> ev_free;
+    std::vector<tde::KernelTime> last_times;
+};
+
+namespace tde {
+int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
+                        int bits, bool advance_graph_time, size_t scan_t0, bool want_pcm);
+}

@@ -1,0 +1,171 @@
+// kernels.h -- descriptor structs and launch wrappers of the gfx950 vertex kernels.
+//
+// Layout contract (DESIGN.md "Data layout"): every edge buffer is `frames` interleaved stereo frames
+// (float2 = {l, r}) in HBM; a kernel launch covers a contiguous run of whole reference blocks
+// ("chunk") and is batched over same-kind vertices of one topological level through blockIdx.y, each
+// vertex described by one descriptor in a device-resident table.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "adsr_math.h"
+
+namespace tdk {
+
+constexpr int kThreads = 256;       // 4 wave64 per workgroup
+constexpr int kTileFrames = 1024;   // frames per workgroup tile: 2 x float4 (2 frames each) per thread
+
+// Vertex epilogue: Sample::apply_angle then Sample::apply_gain (sample.rs:97-114, order fixed at
+// extensions.rs:262-263).  Amplitudes are computed on the host with libm; flags carry the skip
+// thresholds (|angle| < 0.001, |gain-1| < 0.001).
+struct PanGain {
+    float l_amp, r_amp, gain;
+    uint32_t flags;  // bit0: apply pan, bit1: apply gain
+};
+
+// sum_inputs (extensions.rs:310-319), optionally + per-reference-block absolute peak
+// (normalize_gen's scan_max, extensions.rs:322 / sample.rs:116-118).
+struct SumDesc {
+    const float2* const* ins;  // k input edge buffers, in connect() order
+    float2* out;
+    float* peaks;              // [n_blocks] (mode 1)
+    uint32_t k;
+    uint32_t mode;             // 0: Sum vertex (epilogue applied), 1: Normalize pass A (raw sum + peaks)
+    PanGain pg;
+};
+
+// Running-peak bookkeeping of normalize_gen (extensions.rs:321-329) over the chunk's blocks.
+struct NormState { float max, scan_max; };
+struct PrefixMaxDesc {
+    const float* peaks;   // [n_blocks]
+    float* rscale;        // [n_blocks]  1.0f / max used for block b
+    NormState* state;     // carried across chunks / passes
+};
+
+// Normalize pass B: buf.scale(len, 1.0 / max) (extensions.rs:328) + epilogue, optional fused quantise.
+struct ScaleDesc {
+    float2* buf;          // in place
+    const float* rscale;
+    void* pcm;            // optional int16/int32 interleaved output
+    float amplitude;
+    uint32_t qmode;       // 0 none, 1 int16, 2 int32
+    PanGain pg;
+};
+
+struct QuantDesc {
+    const float2* in;
+    void* pcm;
+    float amplitude;
+    uint32_t qmode;
+};
+
+// sample_loop_gen (extensions.rs:331-341): out[m] = sample[(t0 + m) % len]
+struct LoopDesc {
+    const float2* sample;
+    float2* out;
+    uint64_t len;
+    uint64_t t0;
+    PanGain pg;
+};
+
+// sample_multi_gen (extensions.rs:344-381): hits in onset order; a voice with origin o sounds on frames
+// [o, o + len) reading sample[m - o].  Origins are chunk-relative and may be negative (carried voices).
+struct MultiHit { int64_t origin; float vel; float pad; };
+struct MultiDesc {
+    const float2* sample;
+    float2* out;
+    const MultiHit* hits;
+    uint64_t len;
+    uint32_t n_hits;
+    uint32_t pad;
+    PanGain pg;
+};
+
+// sample_lerp_gen (extensions.rs:384-421).  key = frame from which the entry is `primary` (INT64_MIN for
+// the two carried entries), origin = frame of sample position 0, fade = frame at which countdown was set
+// to lerp_len.
+struct LerpHit { int64_t key, origin, fade; float vel; float pad; };
+struct LerpDesc {
+    const float2* sample;
+    float2* out;
+    const LerpHit* hits;   // >= 2 entries; [0] = initial ghost, [1] = initial primary
+    uint64_t len;
+    uint32_t n_hits;
+    uint32_t lerp_len;
+    PanGain pg;
+};
+
+// Interval tables for the voice-list vertices: the chunk is cut at block starts and event frames into
+// intervals inside which the voice list is constant.  istart[i] = first frame (chunk-relative),
+// ivoff[i]..ivoff[i+1] = voice records.
+struct IntervalTab {
+    const uint32_t* istart;
+    const uint32_t* ivoff;
+    const float4* voices;
+    uint32_t n_int;
+    uint32_t pad;
+};
+
+struct OscConfD { float volume, param; AdsrConfD adsr; };
+
+// debug_sine_gen (extensions.rs:423-457): voice = (hz, vel, -, -)
+struct SineDesc {
+    IntervalTab tab;
+    float2* out;
+    uint64_t t0;   // graph time of the chunk's first frame
+    uint32_t sr, pad;
+    PanGain pg;
+};
+
+// synth_gen (extensions.rs:460-529): voice = (hz, vel, env_t at block start, rel_t)
+struct SynthDesc {
+    IntervalTab tab;
+    float2* out;
+    uint64_t t0;
+    uint32_t sr, bl;
+    OscConfD square, topflat, triangle;
+    float osc_amp_multiplier;
+    PanGain pg;
+};
+
+// adsr_gen (extensions.rs:593-651): two voice records per interval: primary, ghost = (t_off, vel,
+// release_val, skip) -- skip != 0 on the primary record marks a frame the reference leaves untouched
+// (the `continue` at extensions.rs:632-635).
+struct AdsrVDesc {
+    IntervalTab tab;
+    const float2* const* ins;
+    float2* out;
+    uint32_t k;
+    uint32_t sr, bl;
+    uint32_t use_off, use_max, bypass;  // bypass: wet < 1e-4 -> summed input passes through
+    float wet;
+    AdsrConfD conf;
+    PanGain pg;
+};
+
+// band_pass_gen (extensions.rs:654-689), exact sequential form.
+struct BandState { float lprevl, lprevr, hprevl, hprevr; uint32_t first; uint32_t pad[3]; };
+struct BandDesc {
+    const float2* const* ins;
+    float2* out;
+    BandState* state;   // carried across chunks
+    uint32_t k;
+    uint32_t bypass;    // wet < 1e-4 or both gammas 0
+    uint32_t pass;
+    float lgamma, hgamma;
+    PanGain pg;
+};
+
+void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
+void launch_prefix_max(const PrefixMaxDesc* d, int n_desc, uint32_t n_blocks, int is_scan, hipStream_t s);
+void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
+void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_sample_multi(const MultiDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_sample_lerp(const LerpDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_debug_sine(const SineDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
+void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_absmax(const float* peaks, uint32_t n, float* out, hipStream_t s);
+
+}  // namespace tdk

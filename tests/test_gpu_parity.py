@@ -1,0 +1,113 @@
+"""GPU parity: the HIP engine (through the C ABI) against the CPU oracle on identical projects.
+
+Bar: bit-exact int PCM *and* bit-exact f32 edge values for the integer/index/IEEE-only vertex kinds
+(sum, normalize, sampleloop, sample_multi, sample_lerp, adsr vertex, bandpass); for the kinds that
+evaluate sinf (debug_sine, synth) the tolerance is 1e-6 RMS on the f32 output and +-1 LSB on PCM.
+"""
+import numpy as np
+import pytest
+
+from termdaw_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def assert_bit_exact(got, ref):
+    gp, gf = got
+    rp, rf = ref
+    assert gp.shape == rp.shape
+    bad = np.nonzero(_bits(gf) != _bits(rf))
+    assert bad[0].size == 0, "f32 mismatch at frames %s: got %s ref %s" % (bad[0][:5], gf[bad][:5], rf[bad][:5])
+    assert np.array_equal(gp, rp)
+
+
+def assert_close(got, ref, rms_tol=1e-6):
+    gp, gf = got
+    rp, rf = ref
+    assert gp.shape == rp.shape
+    assert not np.isnan(gf).any()
+    rms = float(np.sqrt(np.mean((gf.astype(np.float64) - rf.astype(np.float64)) ** 2)))
+    assert rms <= rms_tol, "rms %g" % rms
+    assert np.abs(gp.astype(np.int64) - rp.astype(np.int64)).max() <= 1
+
+
+@pytest.mark.parametrize("scan", [False, True])
+def test_config1_readme_project(gpu_api, oracle, scan):
+    p = W.config1()
+    assert p.cs == 141
+    assert_bit_exact(p.render(gpu_api, scan=scan), p.render(oracle, scan=scan))
+
+
+@pytest.mark.parametrize("scan", [False, True])
+def test_config2_small(gpu_api, oracle, scan):
+    p = W.config2(seconds=2.0, n_src=64)
+    assert_bit_exact(p.render(gpu_api, scan=scan), p.render(oracle, scan=scan))
+
+
+def test_config2_odd_fanin_and_duplicate_edges(gpu_api, oracle):
+    p = W.config2(seconds=0.5, n_src=7)
+    p.connect("vs03", "sum")   # duplicate connect -> summed twice (graph.rs:76)
+    p.connect("sum", "sum")    # self edge rejected
+    p.connect("nope", "sum")   # unknown vertex rejected
+    assert_bit_exact(p.render(gpu_api), p.render(oracle))
+
+
+@pytest.mark.parametrize("scan", [False, True])
+def test_drum_project(gpu_api, oracle, scan):
+    p = W.drum_project()
+    assert_bit_exact(p.render(gpu_api, scan=scan), p.render(oracle, scan=scan))
+
+
+@pytest.mark.parametrize("bl", [64, 1000, 1024, 2048, 333])
+def test_drum_project_block_lengths(gpu_api, oracle, bl):
+    p = W.drum_project(seconds=1.0, bl=bl)
+    assert_bit_exact(p.render(gpu_api), p.render(oracle))
+
+
+@pytest.mark.parametrize("scan", [False, True])
+def test_synth_project(gpu_api, oracle, scan):
+    p = W.synth_project()
+    assert_close(p.render(gpu_api, scan=scan), p.render(oracle, scan=scan))
+
+
+def test_config3_short(gpu_api, oracle):
+    p = W.config3(seconds=4.0)
+    assert_close(p.render(gpu_api), p.render(oracle))
+
+
+def test_render_twice_carries_state(gpu_api, oracle):
+    """A second render without refresh continues from the carried vertex state (quirks Q4/Q14)."""
+    p = W.drum_project(seconds=1.5)
+    gb = p.build(gpu_api)
+    ob = p.build(oracle)
+    for _ in range(2):
+        assert_bit_exact(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
+
+
+def test_block_pull_matches_reference_render(gpu_api, oracle):
+    """td_graph_render_block == Graph::render, block by block, incl. the caller-driven FlowwBank."""
+    p = W.drum_project(seconds=0.3)
+    gsb, gfb, gg = p.build(gpu_api)
+    osb, ofb, og = p.build(oracle)
+    for b in range(p.cs):
+        gl, gr = gg.render(gsb, gfb)
+        ol, orr = og.render(osb, ofb)
+        assert np.array_equal(_bits(gl), _bits(ol)) and np.array_equal(_bits(gr), _bits(orr)), "block %d" % b
+        gfb.set_time_to_next_block()
+        ofb.set_time_to_next_block()
+    assert gg.get_time() == og.get_time() == p.cs * p.bl
+
+
+def test_normalization_value_after_scan(gpu_api, oracle):
+    p = W.config1(seconds=1.0)
+    gsb, gfb, gg = p.build(gpu_api)
+    osb, ofb, og = p.build(oracle)
+    assert gg.get_normalization_value("sum") == og.get_normalization_value("sum") == np.float32(0.000001)
+    gg.true_normalize_scan(gsb, gfb, p.cs)
+    og.true_normalize_scan(osb, ofb, p.cs)
+    assert gg.get_normalization_value("sum") == og.get_normalization_value("sum")
+    assert gg.get_normalization_value("one") == -1.0
