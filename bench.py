@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- offline render throughput of the HIP engine on BASELINE config 2.
+
+A "step" is one complete fresh render of the project (64 sampleloop vertices -> one normalize,
+60 s @ 48 kHz, bl 1024 = 2,880,512 stereo frames) from sample PCM resident in HBM to the 16-bit PCM
+buffer in HBM: reset normalize vertices, rewind the FlowwBank, compile + launch every vertex kernel.
+At N > 1 every rank renders its own project (seed offset 64 x rank, BASELINE config 5's sharding: no
+data-path collective) and the ranks exchange only the per-project peak table with one RCCL
+all-reduce(max) inside the timed region.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (by HIP-event time measured
+live on the engine's stream during the timed steps); `kernels` lists every kernel family the same
+way.  `cpu_baseline` times the CPU oracle (oracle/, a C++ restatement of the reference's block-serial
+algorithm -- NOT the Rust reference, which cannot be built here) single-threaded on the same project.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0      # ... 6.29 TB/s measured float4 copy
+
+SECONDS = 60.0
+N_SRC = 64
+
+
+def algorithmic_bytes_per_frame(k):
+    """8-byte stereo f32 per edge read and per vertex write."""
+    return {
+        "k_sample_loop": 16.0 * k,        # per source: 8 B sample read + 8 B edge write, k sources per launch
+        "k_sum": 8.0 * k + 8.0,           # Normalize pass A: k edge reads + raw sum write (+ 4 B / 1024 frames peak)
+        "k_prefix_max": 8.0 / 1024.0,     # per block: peak read + scale write
+        "k_scale": 8.0 + 8.0 + 4.0,       # Normalize pass B with fused int16 quantise
+    }
+
+
+def cpu_baseline(project, frames, runs=5):
+    """Oracle ("port" of the reference algorithm) on one host core: whole config-2 project per run."""
+    from oracle import binding as oracle
+    times = []
+    for r in range(runs + 1):
+        built = project.build(oracle)
+        t0 = time.perf_counter()
+        project.render(oracle, built=built, want_f32=False)
+        dt = time.perf_counter() - t0
+        if r:
+            times.append(dt)
+    med = float(np.median(times))
+    return {
+        "value": round(frames / med / 1e6, 4),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "full workload (64 sampleloop -> normalize, %d frames) x %d runs, median; 1 thread of %d host cores; "
+                  "C++ restatement of the reference algorithm (oracle/), not the Rust binary" % (frames, runs, os.cpu_count()),
+        "seconds_per_render": round(med, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--seconds", type=float, default=SECONDS, help=argparse.SUPPRESS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+
+    import torch
+    import torch.distributed as dist
+    from termdaw_amd import api, workloads
+
+    if api.device_count() < 1 or not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    api.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    # ---- build this rank's project: config 2 with seed offset 64 * rank (config 5 sharding) ----
+    project = workloads.config2(seconds=args.seconds, n_src=N_SRC, seed_offset=64 * rank)
+    sb, fb, g = project.build(api)
+    cs, bl = project.cs, project.bl
+    frames = cs * bl
+    peaks = torch.zeros(world, dtype=torch.float32, device="cuda")
+
+    def step():
+        g.reset_normalize_vertices()   # fresh-after-refresh state (state.rs:467)
+        fb.set_time(0)
+        g.render_all_async(sb, fb, cs, 16)
+
+    def barrier():
+        g.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    g.set_profiling(True)   # HIP events around every launch on the engine's stream
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    g.sync()
+    peaks[rank] = g.get_normalization_value("sum")   # pre-normalisation peak of this rank's project
+    if world > 1:
+        dist.all_reduce(peaks, op=dist.ReduceOp.MAX)   # the path's only exchange: per-project peak table
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = g.kernel_times()
+    g.set_profiling(False)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        total_frames = frames * args.steps * world
+        value = total_frames / dt / 1e6
+        abf = algorithmic_bytes_per_frame(N_SRC)
+        kernels = []
+        for name, (ms, launches) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
+            avg_ms = ms / max(launches, 1)
+            bytes_per_launch = abf.get(name, 0.0) * frames
+            gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+            kernels.append({"kernel": name, "avg_ms": round(avg_ms, 5), "launches": int(launches),
+                            "algorithmic_bytes_per_launch": int(bytes_per_launch), "achieved_GBs": round(gbs, 1),
+                            "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 4)})
+        dom = kernels[0] if kernels else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if dom and os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom["kernel"])
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "offline render Msamples/sec (stereo 48 kHz) + % HBM roofline, 64-vertex graph",
+            "value": round(value, 2),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: 64 sampleloop -> 1 normalize, %g s @48 kHz, bl 1024, 16-bit PCM out "
+                                   "(one project per GPU, seed offset 64*rank)" % args.seconds,
+                       "frames_per_step_per_gpu": frames, "vertices": N_SRC + 1,
+                       "parallelism": "projects sharded 1 per GPU; RCCL all-reduce(max) of the peak table only"},
+            "roofline": None if not dom else {
+                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": dom["frac_of_8TBs"], "frac_of_measured_copy_6.29TBs": dom["frac_of_measured_copy"], "traffic": traffic},
+            "kernels": kernels,
+            "peak_table": [round(float(x), 6) for x in peaks.tolist()],
+            "device_bytes": g.device_bytes(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(project, frames)
+            out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
