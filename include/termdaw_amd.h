@@ -150,7 +150,7 @@ int td_state_refresh_source(td_state* s, const char* lua_source);
 int td_state_refresh(td_state* s);
 int td_state_scan_exact(td_state* s);                                     /* state.rs:473-475 */
 /* State::render state.rs:477-577: renders cs blocks and writes the integer WAV to output_file
- * (relative paths resolve against wdir). path_override may be NULL. */
+ * (relative to the process working directory, like hound::WavWriter::create at state.rs:514). path_override may be NULL. */
 int td_state_render(td_state* s, const char* path_override);
 /* Same render, PCM left in memory: copies frames*2 words to out (may be NULL to query the size). */
 size_t td_state_render_to_memory(td_state* s, void* out, size_t bytes);
