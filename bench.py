@@ -72,10 +72,11 @@ def cpu_baseline(project, frames, runs=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--seconds", type=float, default=SECONDS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fuse", action="store_true", help="edge-buffer model: one HBM buffer per source vertex (no source inlining)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -101,6 +102,7 @@ def main():
     project = workloads.config2(seconds=args.seconds, n_src=N_SRC, seed_offset=64 * rank)
     sb, fb, g = project.build(api)
     cs, bl = project.cs, project.bl
+    g.set_option("fuse_sources", 0 if args.no_fuse else 1)
     frames = cs * bl
 
     def step():
@@ -116,6 +118,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    g.sync()
+    # warm the exchange path too (first CUDA tensor / first collective initialise lazily: not render work)
+    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if world > 1 else None, "cuda")
     barrier()
     g.set_profiling(True)   # HIP events around every launch on the engine's stream
     barrier()
@@ -171,6 +176,7 @@ def main():
             "config": {"workload": "BASELINE config 2: 64 sampleloop -> 1 normalize, %g s @48 kHz, bl 1024, 16-bit PCM out "
                                    "(one project per GPU, seed offset 64*rank)" % args.seconds,
                        "frames_per_step_per_gpu": frames, "vertices": N_SRC + 1,
+                       "source_inlining": not args.no_fuse,
                        "parallelism": "projects sharded 1 per GPU; RCCL all-reduce(max) of the peak table only"},
             "roofline": None if not dom else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -138,6 +138,10 @@ void td_graph_set_profiling(td_graph* g, int on);
 size_t td_graph_last_kernel_times(const td_graph* g, const char** names, float* ms, size_t* launches, size_t cap);
 /* HBM bytes allocated for edge buffers / tables by this graph handle. */
 size_t td_graph_device_bytes(const td_graph* g);
+/* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
+ * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);
+ * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders). */
+int td_graph_set_option(td_graph* g, const char* key, long value);
 
 /* ---- Project front-end: State (state.rs:27-578) -------------------------------------------- */
 /* State{..} as constructed at main.rs:75-98 (render_sr 48000, bd 16, output "outp.wav"). */

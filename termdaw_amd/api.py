@@ -81,6 +81,7 @@ SIGNATURES = {
     "td_graph_set_profiling": (None, [_vp, _i32]),
     "td_graph_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
     "td_graph_device_bytes": (_sz, [_vp]),
+    "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
     "td_state_new": (_vp, [_cp, _sz, _sz]),
     "td_state_open": (_vp, [_cp]),
     "td_state_free": (None, [_vp]),
@@ -328,6 +329,9 @@ class Graph:
 
     def device_bytes(self):
         return lib().td_graph_device_bytes(self.h)
+
+    def set_option(self, key, value):
+        _check(lib().td_graph_set_option(self.h, key.encode(), int(value)))
 
 
 class State:

@@ -710,6 +710,13 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     for (size_t vi : g->order)
         for (size_t u : g->edges[vi]) last_use[u] = std::max(last_use[u], g->level[vi]);
 
+    // source inlining: a sample_loop vertex that is not the output is gathered directly by its consumers
+    // (all of them sum their inputs through the same term loop), so its edge buffer is never materialised
+    std::vector<char> inlined(nv, 0);
+    if (g->fuse_sources)
+        for (size_t vi : g->order)
+            inlined[vi] = g->vertices[vi].kind == K_SAMPLE_LOOP && (long)vi != g->output_vertex;
+
     struct Launch { int fam; size_t off; int n; };
     std::vector<Launch> launches;
     std::vector<std::vector<size_t>> by_level(g->n_levels);
@@ -735,6 +742,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
         std::vector<size_t> fam_v[F_COUNT];
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
+            if (inlined[vi]) continue;
             g->vbuf[vi] = take_buffer(g);
             if (!g->vbuf[vi]) return fail("termdaw_amd: out of device memory for edge buffers");
             switch (v.kind) {
@@ -752,12 +760,32 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 default: break;
             }
         }
-        // input pointer tables
+        // input term tables: an edge buffer, or an inlined sample_loop source gathered by the consumer
         std::map<size_t, size_t> ins_off;
+        std::map<size_t, uint32_t> term_mode;
         for (size_t vi : by_level[lv]) {
             if (!g->vertices[vi].has_input()) continue;
-            std::vector<const float2*> ins;
-            for (size_t u : g->edges[vi]) ins.push_back(g->vbuf[u]);
+            std::vector<InTerm> ins;
+            for (size_t u : g->edges[vi]) {
+                InTerm t{};
+                if (inlined[u]) {
+                    const Vertex& src = g->vertices[u];
+                    const SampleEntry& s = sb->samples[src.sample_index];
+                    t.p = s.d;
+                    t.len = s.len;
+                    t.t0 = vt[u].t0;
+                    t.pg = make_pg(src.gain, src.angle);
+                    const bool fits32 = s.len <= 0xFFFFFFFFull && t.t0 + M + kTileFrames <= 0xFFFFFFFFull;
+                    t.kind = fits32 ? 1u : 2u;
+                    t.magic = fits32 ? (s.len >= 2 ? (uint32_t)(0x100000000ull / s.len) : 0xFFFFFFFFu) : 0u;
+                } else {
+                    t.p = g->vbuf[u];
+                }
+                ins.push_back(t);
+            }
+            bool all_edge = true, all_loop = !ins.empty();
+            for (auto& t : ins) { all_edge = all_edge && t.kind == 0; all_loop = all_loop && t.kind == 1; }
+            term_mode[vi] = all_edge ? TERMS_ALL_EDGE : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED);
             ins_off[vi] = st.put(ins);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, rscale)
@@ -854,6 +882,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         x.out = g->vbuf[vi];
                         x.k = (uint32_t)g->edges[vi].size();
                         x.mode = v.kind == K_NORMALIZE ? 1u : 0u;
+                        x.term_mode = term_mode[vi];
                         x.pg = make_pg(v.gain, v.angle);
                         d.push_back(x);
                     }
@@ -903,6 +932,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         x.bl = (uint32_t)bl;
                         x.use_off = v.use_off;
                         x.use_max = v.use_max;
+                        x.term_mode = term_mode[vi];
                         x.wet = v.wet;
                         x.conf = v.conf;
                         x.pg = make_pg(v.gain, v.angle);
@@ -926,6 +956,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         x.out = g->vbuf[vi];
                         x.state = &g->dstate[v.state_slot].band;
                         x.k = (uint32_t)g->edges[vi].size();
+                        x.term_mode = term_mode[vi];
                         x.pass = v.pass;
                         x.lgamma = v.lgamma;
                         x.hgamma = v.hgamma;
@@ -1523,5 +1554,16 @@ size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float*
     return std::min(n, cap);
 }
 size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes; }
+
+int td_graph_set_option(td_graph* g, const char* key, long value) {
+    const std::string k = key ? key : "";
+    if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
+    if (k == "max_chunk_frames") {
+        if (value < 1) return fail("max_chunk_frames must be >= 1");
+        g->max_chunk_frames = (size_t)value;
+        return 1;
+    }
+    return fail("unknown option \"" + k + "\"");
+}
 
 }  // extern "C"

@@ -137,6 +137,7 @@ struct td_graph {
     int last_bits = 16;
     float* d_scalar = nullptr;
     size_t device_bytes = 0;
+    bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)
     // profiling
     bool profiling = false;

@@ -22,14 +22,34 @@ struct PanGain {
     uint32_t flags;  // bit0: apply pan, bit1: apply gain
 };
 
+// One input term of a summing vertex, in connect() order.
+//   kind 0: an edge buffer in HBM.
+//   kind 1: an inlined sample_loop source (extensions.rs:331-341 + its own pan/gain epilogue): the consumer
+//           gathers sample[(t0 + m) % len] itself, so the source's edge buffer never exists (DESIGN.md
+//           "source inlining").  32-bit form: t0 + m < 2^32, modulo by Barrett reduction with
+//           magic = floor(2^32 / len).
+//   kind 2: the same with 64-bit cursor / length (generic modulo).
+struct InTerm {
+    const float2* p;   // edge buffer (kind 0) or sample frames (kind 1, 2)
+    uint64_t len;      // sample length
+    uint64_t t0;       // loop cursor at the chunk's first frame
+    PanGain pg;        // the source vertex' epilogue
+    uint32_t kind;
+    uint32_t magic;
+    uint32_t pad[2];
+};
+enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2 };
+
 // sum_inputs (extensions.rs:310-319), optionally + per-reference-block absolute peak
 // (normalize_gen's scan_max, extensions.rs:322 / sample.rs:116-118).
 struct SumDesc {
-    const float2* const* ins;  // k input edge buffers, in connect() order
+    const InTerm* ins;         // k input terms, in connect() order
     float2* out;
     float* peaks;              // [n_blocks] (mode 1)
     uint32_t k;
     uint32_t mode;             // 0: Sum vertex (epilogue applied), 1: Normalize pass A (raw sum + peaks)
+    uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
+    uint32_t pad;
     PanGain pg;
 };
 
@@ -132,11 +152,11 @@ struct SynthDesc {
 // (the `continue` at extensions.rs:632-635).
 struct AdsrVDesc {
     IntervalTab tab;
-    const float2* const* ins;
+    const InTerm* ins;
     float2* out;
     uint32_t k;
     uint32_t sr, bl;
-    uint32_t use_off, use_max, bypass;  // bypass: wet < 1e-4 -> summed input passes through
+    uint32_t use_off, use_max, term_mode;
     float wet;
     AdsrConfD conf;
     PanGain pg;
@@ -145,11 +165,11 @@ struct AdsrVDesc {
 // band_pass_gen (extensions.rs:654-689), exact sequential form.
 struct BandState { float lprevl, lprevr, hprevl, hprevr; uint32_t first; uint32_t pad[3]; };
 struct BandDesc {
-    const float2* const* ins;
+    const InTerm* ins;
     float2* out;
     BandState* state;   // carried across chunks
     uint32_t k;
-    uint32_t bypass;    // wet < 1e-4 or both gammas 0
+    uint32_t term_mode;
     uint32_t pass;
     float lgamma, hgamma;
     PanGain pg;

@@ -79,28 +79,92 @@ TD_DEV void store_quant_pair(void* pcm, uint32_t qmode, uint32_t m, uint32_t M, 
 
 TD_DEV float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
-// sum_inputs (extensions.rs:310-319): zero, then += each input in edge order.  Four inputs per trip
-// keep 8 x 16 B loads in flight per lane.
-TD_DEV void sum_inputs_pairs(const float2* const* ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_t M,
+template <typename IDX>
+TD_DEV float4 loop_pair(const float2* s, IDX len, IDX idx) {
+    float2 a = s[idx];
+    IDX i1 = idx + 1;
+    if (i1 == len) i1 = 0;
+    float2 b = s[i1];
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+// x mod len for x < 2^32 with magic = floor(2^32 / len): q underestimates x / len by at most 1
+TD_DEV uint32_t barrett_mod(uint32_t x, uint32_t len, uint32_t magic) {
+    const uint32_t r = x - __umulhi(x, magic) * len;
+    return r >= len ? r - len : r;
+}
+// sample_loop_gen for one frame pair (extensions.rs:337-338), 32-bit cursor.  The pair is one aligned
+// 16-byte load when the loop position is even and does not wrap inside the pair (the parity is the same
+// for a whole tile of a given source), else two 8-byte loads.
+TD_DEV float4 loop_pair32(const float2* s, uint32_t len, uint32_t magic, uint32_t x) {
+    const uint32_t idx = barrett_mod(x, len, magic);
+    if (((idx & 1u) == 0u) && idx + 1u < len) return *reinterpret_cast<const float4*>(s + idx);
+    return loop_pair<uint32_t>(s, len, idx);
+}
+// stand-alone sample_loop vertex (k_sample_loop): wave-uniform choice of the 32-bit form
+TD_DEV float4 gather_loop_pair(const float2* s, uint64_t len64, uint64_t t0, uint32_t m, uint32_t M) {
+    if (len64 <= 0xFFFFFFFFull && t0 + M + kTileFrames <= 0xFFFFFFFFull) {
+        const uint32_t len = (uint32_t)len64;
+        return loop_pair<uint32_t>(s, len, ((uint32_t)t0 + m) % len);
+    }
+    return loop_pair<uint64_t>(s, len64, (t0 + m) % len64);
+}
+
+TD_DEV float4 zero_tail(float4 v, uint32_t m, uint32_t M) {   // frames at or beyond M contribute nothing
+    if (m + 1 >= M) { v.z = 0.f; v.w = 0.f; }
+    if (m >= M) { v.x = 0.f; v.y = 0.f; }
+    return v;
+}
+
+// value of one input term for the frame pair starting at m (generic form)
+TD_DEV float4 term_pair(const InTerm& t, uint32_t m, uint32_t M) {
+    if (t.kind == 0) return load_pair(t.p, m, M);
+    float4 v = t.kind == 1 ? loop_pair32(t.p, (uint32_t)t.len, t.magic, (uint32_t)t.t0 + m)
+                           : loop_pair<uint64_t>(t.p, t.len, (t.t0 + m) % t.len);
+    return zero_tail(epilogue4(v, t.pg), m, M);
+}
+TD_DEV float4 loop_term_pair(const InTerm& t, uint32_t m, uint32_t M) {
+    return zero_tail(epilogue4(loop_pair32(t.p, (uint32_t)t.len, t.magic, (uint32_t)t.t0 + m), t.pg), m, M);
+}
+
+// sum_inputs (extensions.rs:310-319): zero, then += each input in edge order.  Terms are fetched four
+// (edge buffers: eight) at a time so that 8-16 x 16 B loads are in flight per lane before the first add;
+// the adds themselves stay strictly sequential per element.
+template <int MODE>
+TD_DEV void sum_terms(const InTerm* __restrict__ ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_t M,
+                      float4& a0, float4& a1) {
+    uint32_t j = 0;
+    if (MODE == TERMS_ALL_EDGE) {
+        for (; j + 8 <= k; j += 8) {
+            float4 x0[8], x1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const float2* p = ins[j + u].p; x0[u] = load_pair(p, m0, M); x1[u] = load_pair(p, m1, M); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a0 = add4(a0, x0[u]); a1 = add4(a1, x1[u]); }
+        }
+    }
+    for (; j + 4 <= k; j += 4) {
+        float4 x0[4], x1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (MODE == TERMS_ALL_EDGE) { const float2* p = ins[j + u].p; x0[u] = load_pair(p, m0, M); x1[u] = load_pair(p, m1, M); }
+            else if (MODE == TERMS_ALL_LOOP32) { x0[u] = loop_term_pair(ins[j + u], m0, M); x1[u] = loop_term_pair(ins[j + u], m1, M); }
+            else { x0[u] = term_pair(ins[j + u], m0, M); x1[u] = term_pair(ins[j + u], m1, M); }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a0 = add4(a0, x0[u]); a1 = add4(a1, x1[u]); }
+    }
+    for (; j < k; ++j) {
+        a0 = add4(a0, term_pair(ins[j], m0, M));
+        a1 = add4(a1, term_pair(ins[j], m1, M));
+    }
+}
+TD_DEV void sum_inputs_pairs(const InTerm* ins, uint32_t k, uint32_t term_mode, uint32_t m0, uint32_t m1, uint32_t M,
                              float4& a0, float4& a1) {
     a0 = make_float4(0.f, 0.f, 0.f, 0.f);
     a1 = a0;
-    uint32_t j = 0;
-    for (; j + 4 <= k; j += 4) {
-        const float2* p0 = ins[j]; const float2* p1 = ins[j + 1];
-        const float2* p2 = ins[j + 2]; const float2* p3 = ins[j + 3];
-        float4 x00 = load_pair(p0, m0, M), x01 = load_pair(p0, m1, M);
-        float4 x10 = load_pair(p1, m0, M), x11 = load_pair(p1, m1, M);
-        float4 x20 = load_pair(p2, m0, M), x21 = load_pair(p2, m1, M);
-        float4 x30 = load_pair(p3, m0, M), x31 = load_pair(p3, m1, M);
-        a0 = add4(add4(add4(add4(a0, x00), x10), x20), x30);
-        a1 = add4(add4(add4(add4(a1, x01), x11), x21), x31);
-    }
-    for (; j < k; ++j) {
-        const float2* p = ins[j];
-        a0 = add4(a0, load_pair(p, m0, M));
-        a1 = add4(a1, load_pair(p, m1, M));
-    }
+    if (term_mode == TERMS_ALL_EDGE) sum_terms<TERMS_ALL_EDGE>(ins, k, m0, m1, M, a0, a1);
+    else if (term_mode == TERMS_ALL_LOOP32) sum_terms<TERMS_ALL_LOOP32>(ins, k, m0, m1, M, a0, a1);
+    else sum_terms<TERMS_MIXED>(ins, k, m0, m1, M, a0, a1);
 }
 
 TD_DEV float absmax4(float m, float4 v) {
@@ -120,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
     const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
     float4 a0, a1;
-    sum_inputs_pairs(d.ins, d.k, m0, m1, M, a0, a1);
+    sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
     if (d.mode == 0) {
         store_pair(d.out, m0, M, epilogue4(a0, d.pg));
         store_pair(d.out, m1, M, epilogue4(a1, d.pg));
@@ -241,27 +305,12 @@ __global__ __launch_bounds__(kThreads) void k_quantise(const QuantDesc* __restri
 // ------------------------------------------------------------------------------------------------
 // k_sample_loop: out[m] = sample[(t0 + m) % len]   (extensions.rs:331-341)
 // ------------------------------------------------------------------------------------------------
-template <typename IDX>
-TD_DEV float4 loop_pair(const float2* s, IDX len, IDX idx) {
-    float2 a = s[idx];
-    IDX i1 = idx + 1;
-    if (i1 == len) i1 = 0;
-    float2 b = s[i1];
-    return make_float4(a.x, a.y, b.x, b.y);
-}
 __global__ __launch_bounds__(kThreads) void k_sample_loop(const LoopDesc* __restrict__ descs, uint32_t M) {
     const LoopDesc& d = descs[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
-    float4 v0, v1;
-    if (d.len <= 0xFFFFFFFFull && d.t0 + M + kTileFrames <= 0xFFFFFFFFull) {   // wave-uniform: 32-bit modulo
-        const uint32_t len = (uint32_t)d.len, t0 = (uint32_t)d.t0;
-        v0 = loop_pair<uint32_t>(d.sample, len, (t0 + m0) % len);
-        v1 = loop_pair<uint32_t>(d.sample, len, (t0 + m1) % len);
-    } else {
-        v0 = loop_pair<uint64_t>(d.sample, d.len, (d.t0 + m0) % d.len);
-        v1 = loop_pair<uint64_t>(d.sample, d.len, (d.t0 + m1) % d.len);
-    }
+    const float4 v0 = gather_loop_pair(d.sample, d.len, d.t0, m0, M);
+    const float4 v1 = gather_loop_pair(d.sample, d.len, d.t0, m1, M);
     store_pair(d.out, m0, M, epilogue4(v0, d.pg));
     store_pair(d.out, m1, M, epilogue4(v1, d.pg));
 }
@@ -463,7 +512,7 @@ __global__ __launch_bounds__(kThreads) void k_adsr(const AdsrVDesc* __restrict__
     const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
     float4 a0, a1;
-    sum_inputs_pairs(d.ins, d.k, m0, m1, M, a0, a1);
+    sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
     if (m0 < M) {
         float2 a = adsr_frame(d, m0, make_float2(a0.x, a0.y));
         float2 b = (m0 + 1 < M) ? adsr_frame(d, m0 + 1, make_float2(a0.z, a0.w)) : make_float2(0.f, 0.f);
@@ -504,7 +553,7 @@ __global__ __launch_bounds__(kThreads) void k_band_pass(const BandDesc* __restri
         {
             float4 a0, a1;
             const uint32_t m0 = base + 2 * lane, m1 = m0 + kTileFrames / 2;
-            sum_inputs_pairs(d.ins, d.k, m0, m1, M, a0, a1);
+            sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
             reinterpret_cast<float4*>(xs)[lane] = a0;
             reinterpret_cast<float4*>(xs)[lane + kTileFrames / 4] = a1;
         }

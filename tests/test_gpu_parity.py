@@ -162,3 +162,39 @@ def test_other_bit_depths(gpu_api, oracle, bits):
     gp, _ = p.render(gpu_api)
     op, _ = p.render(oracle)
     assert gp.dtype == op.dtype and np.array_equal(gp, op)
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+@pytest.mark.parametrize("project", ["config2", "drum"])
+def test_source_inlining_is_value_identical(gpu_api, oracle, fuse, project):
+    """fuse_sources only changes WHERE a sample_loop source is evaluated, never a value or the sum order."""
+    p = W.config2(seconds=1.0, n_src=9) if project == "config2" else W.drum_project(seconds=1.0)
+    if project == "config2":
+        p.add_sum("side", 0.5, 10.0)          # vs03 feeds two consumers; one source stays un-inlined as the output elsewhere
+        p.connect("vs03", "side")
+        p.connect("side", "sum")
+    built = p.build(gpu_api)
+    built[2].set_option("fuse_sources", fuse)
+    assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle))
+
+
+def test_sampleloop_as_output_vertex(gpu_api, oracle):
+    p = W.config2(seconds=0.2, n_src=2)
+    p.set_output("vs01")                       # a source may be the output (never inlined)
+    assert_bit_exact(p.render(gpu_api), p.render(oracle))
+
+
+@pytest.mark.parametrize("chunk_frames", [1024, 5000, 40000])
+@pytest.mark.parametrize("project", ["drum", "synth"])
+def test_multi_chunk_render_matches_single_chunk(gpu_api, oracle, chunk_frames, project):
+    """Timelines longer than the edge-buffer chunk cap render chunk after chunk with carried state
+    (running normalize peak, band-pass state, voice lists, envelope clocks)."""
+    p = W.drum_project(seconds=1.5) if project == "drum" else W.synth_project(seconds=1.5)
+    built = p.build(gpu_api)
+    built[2].set_option("max_chunk_frames", chunk_frames)
+    got = p.render(gpu_api, built=built)
+    (assert_bit_exact if project == "drum" else assert_close)(got, p.render(oracle))
+    built = p.build(gpu_api)
+    built[2].set_option("max_chunk_frames", chunk_frames)
+    got = p.render(gpu_api, built=built, scan=True)
+    (assert_bit_exact if project == "drum" else assert_close)(got, p.render(oracle, scan=True))
