@@ -82,6 +82,9 @@ struct Vertex {
     Voice3 ap{0, 0, 0}, ag{0, 0, 0};
     // carried device state slot (Normalize / BandPass), index into Graph::dstate
     int state_slot = -1;
+    // reset_normalization (extensions.rs:295-299) is kept on the host until the next render consumes it
+    bool has_init_override = false;
+    float init_override = 0.0f;
     bool has_input() const {
         return kind == K_SUM || kind == K_NORMALIZE || kind == K_ADSR || kind == K_BAND_PASS;
     }
@@ -127,6 +130,7 @@ struct td_graph {
     size_t arena_cap = 0;
     hipEvent_t arena_copied = nullptr;
     bool arena_inflight = false;
+    size_t arena_valid = 0;                   // bytes of harena that darena currently mirrors
     // outputs of the last render
     void* d_pcm = nullptr;
     size_t pcm_cap = 0, pcm_bytes = 0;

@@ -40,12 +40,21 @@ struct InTerm {
 };
 enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2 };
 
+// Running-peak bookkeeping of normalize_gen (extensions.rs:321-329), carried across chunks / passes.
+struct NormState { float max, scan_max; };
+
 // sum_inputs (extensions.rs:310-319), optionally + per-reference-block absolute peak
 // (normalize_gen's scan_max, extensions.rs:322 / sample.rs:116-118).
 struct SumDesc {
     const InTerm* ins;         // k input terms, in connect() order
     float2* out;
     float* peaks;              // [n_blocks] (mode 1)
+    // mode 1: workgroup 0 snapshots the carried normalize state into scratch {max, scan_max} so that pass
+    // B can update the state in place without racing its own readers
+    const NormState* state;
+    float* init_copy;
+    float init_max;            // used instead of state->max when use_init (reset_normalization, extensions.rs:295-299)
+    uint32_t use_init;
     uint32_t k;
     uint32_t mode;             // 0: Sum vertex (epilogue applied), 1: Normalize pass A (raw sum + peaks)
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
@@ -53,21 +62,18 @@ struct SumDesc {
     PanGain pg;
 };
 
-// Running-peak bookkeeping of normalize_gen (extensions.rs:321-329) over the chunk's blocks.
-struct NormState { float max, scan_max; };
-struct PrefixMaxDesc {
-    const float* peaks;   // [n_blocks]
-    float* rscale;        // [n_blocks]  1.0f / max used for block b
-    NormState* state;     // carried across chunks / passes
-};
-
-// Normalize pass B: buf.scale(len, 1.0 / max) (extensions.rs:328) + epilogue, optional fused quantise.
+// Normalize pass B: running max over the block peaks (`*max = buf_max.max(*max)`), buf.scale(len, 1.0 / max)
+// (extensions.rs:323-328), epilogue, optional fused quantise.  Every workgroup derives the running max of
+// its own blocks from the peak table (a few KB from L2); the workgroup of the last tile stores the carried
+// state.  Scan passes scale by the STALE max and accumulate scan_max instead (quirk Q3).
 struct ScaleDesc {
-    float2* buf;          // in place
-    const float* rscale;
-    void* pcm;            // optional int16/int32 interleaved output
+    float2* buf;            // in place
+    const float* peaks;     // [n_blocks]
+    const float* init_copy; // {max, scan_max} at chunk start
+    NormState* state;       // updated by the last tile's workgroup
+    void* pcm;              // optional int16/int32 interleaved output
     float amplitude;
-    uint32_t qmode;       // 0 none, 1 int16, 2 int32
+    uint32_t qmode;         // 0 none, 1 int16, 2 int32
     PanGain pg;
 };
 
@@ -176,8 +182,7 @@ struct BandDesc {
 };
 
 void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
-void launch_prefix_max(const PrefixMaxDesc* d, int n_desc, uint32_t n_blocks, int is_scan, hipStream_t s);
-void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
+void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_multi(const MultiDesc* d, int n_desc, uint32_t frames, hipStream_t s);

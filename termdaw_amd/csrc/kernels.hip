@@ -192,6 +192,10 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
     }
     store_pair(d.out, m0, M, a0);
     store_pair(d.out, m1, M, a1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.init_copy[0] = d.use_init ? d.init_max : d.state->max;
+        d.init_copy[1] = d.state->scan_max;
+    }
     if (tiles_per_block) {
         float pk = 0.0f;
         if (m0 < M) pk = absmax4(pk, a0);
@@ -221,76 +225,55 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_prefix_max: running peak over the chunk's blocks -> per-block scale 1/max (extensions.rs:321-329)
+// k_scale: Normalize pass B (running peak -> scale by 1/max, epilogue, optional fused quantise)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_prefix_max(const PrefixMaxDesc* __restrict__ descs, uint32_t nb,
-                                                         int is_scan) {
-    const PrefixMaxDesc& d = descs[blockIdx.x];
-    __shared__ float seg[kThreads];
-    const uint32_t per = (nb + kThreads - 1) / kThreads;
-    const uint32_t b0 = threadIdx.x * per;
-    const uint32_t b1 = min(b0 + per, nb);
-    float lm = 0.0f;
-    for (uint32_t b = b0; b < b1; ++b) lm = fmaxf(d.peaks[b], lm);
-    seg[threadIdx.x] = lm;
-    __syncthreads();
-    // inclusive max-scan over the 256 segment maxima (Hillis-Steele; max is exact and order-free)
-    for (int off = 1; off < kThreads; off <<= 1) {
-        float o = threadIdx.x >= (uint32_t)off ? seg[threadIdx.x - off] : 0.0f;
-        __syncthreads();
-        seg[threadIdx.x] = fmaxf(seg[threadIdx.x], o);
-        __syncthreads();
-    }
-    const float old_max = d.state->max;
-    const float old_scan = d.state->scan_max;
-    if (is_scan) {
-        // scan pass: scan_max accumulates, the buffer is scaled by the STALE max (quirk Q3)
-        const float r = 1.0f / old_max;
-        for (uint32_t b = b0; b < b1; ++b) d.rscale[b] = r;
-        __syncthreads();
-        if (threadIdx.x == 0) d.state->scan_max = fmaxf(seg[kThreads - 1], old_scan);
-    } else {
-        float run = threadIdx.x ? fmaxf(seg[threadIdx.x - 1], old_max) : old_max;
-        for (uint32_t b = b0; b < b1; ++b) {
-            run = fmaxf(d.peaks[b], run);   // *max = buf_max.max(*max)
-            d.rscale[b] = 1.0f / run;       // buf.scale(len, 1.0 / *max)
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) d.state->max = fmaxf(seg[kThreads - 1], old_max);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_scale: Normalize pass B (scale by the block's 1/max, epilogue, optional fused quantise)
-// ------------------------------------------------------------------------------------------------
-TD_DEV float4 scale_pair(float4 v, uint32_t m, uint32_t bl, const float* rscale) {
-    uint32_t b0 = m / bl, b1 = (m + 1) / bl;
-    float r0 = rscale[b0];
-    float r1 = b1 == b0 ? r0 : rscale[b1];
-    return make_float4(v.x * r0, v.y * r0, v.z * r1, v.w * r1);
-}
 __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict__ descs, uint32_t M, uint32_t bl,
-                                                    uint32_t n_blocks) {
+                                                    uint32_t nb, int is_scan) {
     const ScaleDesc& d = descs[blockIdx.y];
-    const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
+    const uint32_t tile0 = blockIdx.x * kTileFrames;
+    const uint32_t m0 = tile0 + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
-    (void)n_blocks;
-    if (m0 < M) {
-        float4 v = load_pair(d.buf, m0, M);
-        // the pad frame of an odd chunk maps to block n_blocks: guard the table read
-        v = (m0 + 1 < M) ? scale_pair(v, m0, bl, d.rscale)
-                         : make_float4(v.x * d.rscale[m0 / bl], v.y * d.rscale[m0 / bl], 0.f, 0.f);
-        v = epilogue4(v, d.pg);
-        store_pair(d.buf, m0, M, v);
-        if (d.qmode) store_quant_pair(d.pcm, d.qmode, m0, M, v, d.amplitude);
+    const uint32_t b_lo = tile0 / bl;
+    const float init = d.init_copy[0];
+    // max of the peaks of all blocks before this tile's first block (identity 0: peaks are >= 0, never NaN)
+    __shared__ float wmax[kThreads / 64];
+    float p = 0.0f;
+    for (uint32_t b = threadIdx.x; b < b_lo; b += kThreads) p = fmaxf(d.peaks[b], p);
+    p = wave_max(p);
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = p;
+    __syncthreads();
+    const float before = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    const float r_stale = 1.0f / init;
+    // 1.0 / max for the block holding frame m:  max_b = peak_b.max(max_{b-1}),  max_{-1} = init
+    auto rscale_of = [&](uint32_t m) -> float {
+        if (is_scan) return r_stale;
+        float run = b_lo ? fmaxf(before, init) : init;
+        const uint32_t b = m / bl;
+        for (uint32_t bb = b_lo; bb <= b; ++bb) run = fmaxf(d.peaks[bb], run);
+        return 1.0f / run;
+    };
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t m = h ? m1 : m0;
+        if (m < M) {
+            float4 v = load_pair(d.buf, m, M);
+            const float r0 = rscale_of(m);
+            const float r1 = (m + 1 < M) ? rscale_of(m + 1) : r0;
+            v = epilogue4(make_float4(v.x * r0, v.y * r0, v.z * r1, v.w * r1), d.pg);
+            store_pair(d.buf, m, M, v);
+            if (d.qmode) store_quant_pair(d.pcm, d.qmode, m, M, v, d.amplitude);
+        }
     }
-    if (m1 < M) {
-        float4 v = load_pair(d.buf, m1, M);
-        v = (m1 + 1 < M) ? scale_pair(v, m1, bl, d.rscale)
-                         : make_float4(v.x * d.rscale[m1 / bl], v.y * d.rscale[m1 / bl], 0.f, 0.f);
-        v = epilogue4(v, d.pg);
-        store_pair(d.buf, m1, M, v);
-        if (d.qmode) store_quant_pair(d.pcm, d.qmode, m1, M, v, d.amplitude);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        float all = before;   // max over every block peak of the chunk
+        for (uint32_t bb = b_lo; bb < nb; ++bb) all = fmaxf(d.peaks[bb], all);
+        if (is_scan) {
+            d.state->max = init;
+            d.state->scan_max = fmaxf(all, d.init_copy[1]);   // *scan_max = buf_max.max(*scan_max)
+        } else {
+            d.state->max = fmaxf(all, init);
+            d.state->scan_max = d.init_copy[1];
+        }
     }
 }
 
@@ -621,13 +604,9 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, hipStream
     uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
     hipLaunchKernelGGL(k_sum, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames, bl, tpb);
 }
-void launch_prefix_max(const PrefixMaxDesc* d, int n, uint32_t n_blocks, int is_scan, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_prefix_max, dim3(n), dim3(kThreads), 0, s, d, n_blocks, is_scan);
-}
-void launch_scale(const ScaleDesc* d, int n, uint32_t frames, uint32_t bl, hipStream_t s) {
+void launch_scale(const ScaleDesc* d, int n, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_scale, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames, bl, frames / bl);
+    hipLaunchKernelGGL(k_scale, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames, bl, frames / bl, is_scan);
 }
 void launch_quantise(const QuantDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
