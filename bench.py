@@ -40,8 +40,7 @@ def algorithmic_bytes_per_frame(k):
     """8-byte stereo f32 per edge read and per vertex write."""
     return {
         "k_sample_loop": 16.0 * k,        # per source: 8 B sample read + 8 B edge write, k sources per launch
-        "k_sum": 8.0 * k + 8.0,           # Normalize pass A: k edge reads + raw sum write (+ 4 B / 1024 frames peak)
-        "k_prefix_max": 8.0 / 1024.0,     # per block: peak read + scale write
+        "k_sum": 8.0 * k + 8.0,           # Normalize pass A: k edge (or inlined sample) reads + raw sum write
         "k_scale": 8.0 + 8.0 + 4.0,       # Normalize pass B with fused int16 quantise
     }
 
@@ -157,7 +156,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if dom and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom["kernel"])
+                traffic = json.load(open(tpath)).get("nofuse" if args.no_fuse else "fused", {}).get(dom["kernel"])
             except Exception:
                 traffic = None
         out = {

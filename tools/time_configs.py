@@ -1,0 +1,29 @@
+"""Per-kernel HIP-event times of the non-headline configs (run on the GPU box)."""
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np
+from termdaw_amd import api, workloads as W
+
+def run(name, p, reps=3):
+    sb, fb, g = p.build(api)
+    g.render_all(sb, fb, p.cs, 16, want_f32=False, want_pcm=False)
+    g.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
+        g.render_all_async(sb, fb, p.cs, 16)
+    g.sync()
+    dt = (time.perf_counter() - t0) / reps
+    kt = g.kernel_times()
+    g.set_profiling(False)
+    frames = p.cs * p.bl
+    print("%-10s %8.3f ms/render  %9.1f Msamples/s   " % (name, dt * 1e3, frames / dt / 1e6) +
+          "  ".join("%s %.3f ms x%d" % (k, ms / n, n // reps) for k, (ms, n) in sorted(kt.items(), key=lambda kv: -kv[1][0])))
+
+if __name__ == "__main__":
+    sel = sys.argv[1:] or ["c1", "c2", "c3", "drum", "synth"]
+    if "c1" in sel: run("config1", W.config1())
+    if "c2" in sel: run("config2", W.config2())
+    if "c3" in sel: run("config3", W.config3())
+    if "drum" in sel: run("drum60", W.drum_project(seconds=60.0))
+    if "synth" in sel: run("synth60", W.synth_project(seconds=60.0))
