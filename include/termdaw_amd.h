@@ -140,8 +140,13 @@ size_t td_graph_last_kernel_times(const td_graph* g, const char** names, float* 
 size_t td_graph_device_bytes(const td_graph* g);
 /* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
  * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);
- * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders). */
+ * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders);
+ * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact). */
 int td_graph_set_option(td_graph* g, const char* key, long value);
+/* Counters of the exact parallel band-pass for the last rendered chunk, summed over its band-pass
+ * vertices: out[0] segments whose speculative entry state failed the bit-wise check, out[1] segments
+ * recomputed sequentially, out[2] of those cut short by a fixed point under constant input. */
+int td_graph_band_stats(const td_graph* g, uint32_t out[3]);
 
 /* ---- Project front-end: State (state.rs:27-578) -------------------------------------------- */
 /* State{..} as constructed at main.rs:75-98 (render_sr 48000, bd 16, output "outp.wav"). */

@@ -82,6 +82,7 @@ SIGNATURES = {
     "td_graph_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
     "td_graph_device_bytes": (_sz, [_vp]),
     "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
+    "td_graph_band_stats": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "td_state_new": (_vp, [_cp, _sz, _sz]),
     "td_state_open": (_vp, [_cp]),
     "td_state_free": (None, [_vp]),
@@ -329,6 +330,11 @@ class Graph:
 
     def device_bytes(self):
         return lib().td_graph_device_bytes(self.h)
+
+    def band_stats(self):
+        out = (C.c_uint32 * 3)()
+        _check(lib().td_graph_band_stats(self.h, out))
+        return {"mismatched": out[0], "recomputed": out[1], "parked": out[2]}
 
     def set_option(self, key, value):
         _check(lib().td_graph_set_option(self.h, key.encode(), int(value)))

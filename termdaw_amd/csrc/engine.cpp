@@ -625,10 +625,10 @@ static int ensure_arena(td_graph* g, size_t bytes) {
     return 1;
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SUM, F_SCALE, F_ADSR, F_BAND, F_QUANT, F_COUNT };
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SUM, F_SCALE, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
                                            "k_synth",       "k_sum",          "k_scale",
-                                           "k_adsr",        "k_band_pass",    "k_quantise"};
+                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_quantise"};
 
 static hipEvent_t get_event(td_graph* g) {
     if (!g->ev_free.empty()) {
@@ -660,6 +660,33 @@ struct Prof {
     }
 };
 
+// Band-pass execution plan (DESIGN.md "exact parallel band-pass"): segment length S, warm-up W.  The
+// warm-up must outlast the contraction (1 - gamma)^W of the slower chain.  The choice affects speed only --
+// k_band_fix verifies every segment bit for bit and repairs what failed.
+struct BandPlan {
+    bool parallel = false;
+    uint32_t S = 0, W = 0, nseg = 0;
+    float2* tmp = nullptr;
+};
+static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
+    BandPlan p;
+    if (!g->band_parallel) return p;
+    float gmin = 1.0f;
+    if (v.lgamma != 0.0f) gmin = fminf(gmin, fabsf(v.lgamma));
+    if (v.hgamma != 0.0f) gmin = fminf(gmin, fabsf(v.hgamma));
+    // 150 / gamma: ~103 / gamma frames take a full-scale tail down to the denormal floor (so a warm-up that
+    // starts in the sound before a silence reproduces the decay into it), the rest is coalescence margin
+    const double w = 150.0 / (double)gmin + 64.0;
+    if (!(w <= 262144.0)) return p;   // cut-offs below ~5 Hz: the serial kernel is the better plan
+    p.W = ((uint32_t)w + 7u) & ~7u;
+    p.S = 256;
+    while ((M + p.S - 1) / p.S > kBandMaxSegs && p.S < kBandMaxS) p.S *= 2;
+    p.nseg = (uint32_t)((M + p.S - 1) / p.S);
+    if (p.nseg > kBandMaxSegs) return p;
+    p.parallel = p.nseg >= 8;        // tiny chunks (block pulls) stay on the serial kernel
+    return p;
+}
+
 // ------------------------------------------------------------------------------------------------
 // one chunk: compile tables, upload, launch level by level
 // ------------------------------------------------------------------------------------------------
@@ -673,6 +700,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     if (M > 0xFFFFFFF0ull) return fail("termdaw_amd: chunk too long");
     const size_t nv = g->vertices.size();
 
+    g->band_stats_off.clear();
     // ---- 1. host compile: sequential bookkeeping -> tables
     Staging st;
     std::vector<VTables> vt(nv);
@@ -718,7 +746,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
         for (size_t vi : g->order)
             inlined[vi] = g->vertices[vi].kind == K_SAMPLE_LOOP && (long)vi != g->output_vertex;
 
-    struct Launch { int fam; size_t off; int n; };
+    struct Launch { int fam; size_t off; int n; uint32_t aux; };
     std::vector<Launch> launches;
     std::vector<std::vector<size_t>> by_level(g->n_levels);
     for (size_t vi : g->order) by_level[g->level[vi]].push_back(vi);
@@ -741,6 +769,8 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
 
     for (int lv = 0; lv < g->n_levels; ++lv) {
         std::vector<size_t> fam_v[F_COUNT];
+        std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
+        std::map<size_t, BandPlan> band_plan;
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
             if (inlined[vi]) continue;
@@ -756,7 +786,20 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case K_NORMALIZE: fam_v[F_SUM].push_back(vi); fam_v[F_SCALE].push_back(vi); break;
                 case K_ADSR: fam_v[(v.wet < 0.0001f) ? F_SUM : F_ADSR].push_back(vi); break;
                 case K_BAND_PASS:
-                    fam_v[(v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) ? F_SUM : F_BAND].push_back(vi);
+                    if (v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) {
+                        fam_v[F_SUM].push_back(vi);   // extensions.rs:657-658: the summed input passes through
+                    } else {
+                        BandPlan bp = plan_band(g, v, M);
+                        if (bp.parallel) {
+                            bp.tmp = take_buffer(g);
+                            if (!bp.tmp) return fail("termdaw_amd: out of device memory for edge buffers");
+                            level_tmp.push_back(bp.tmp);
+                            band_plan[vi] = bp;
+                            fam_v[F_BAND_SPEC].push_back(vi);
+                        } else {
+                            fam_v[F_BAND].push_back(vi);
+                        }
+                    }
                     break;
                 default: break;
             }
@@ -789,10 +832,13 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
             term_mode[vi] = all_edge ? TERMS_ALL_EDGE : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED);
             ins_off[vi] = st.put(ins);
         }
-        std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, rscale)
+        std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
+        size_t band_desc_off = 0;
+        uint32_t max_nseg = 0;
         for (int fam = 0; fam < F_COUNT; ++fam) {
             auto& vs = fam_v[fam];
-            if (vs.empty()) continue;
+            if (fam == F_BAND_FIX || fam == F_BAND_FILL) vs = fam_v[F_BAND_SPEC];   // same vertices, follow-up launches
+            if (vs.empty() && !(fam == F_SUM && !fam_v[F_BAND_SPEC].empty())) continue;
             size_t off = 0;
             switch (fam) {
                 case F_LOOP: {
@@ -877,14 +923,17 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 } break;
                 case F_SUM: {
                     std::vector<SumDesc> d;
+                    // parallel band-pass vertices first get their summed input materialised (no epilogue)
+                    for (size_t vi : fam_v[F_BAND_SPEC]) vs.push_back(vi);
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
                         SumDesc x{};
-                        x.out = g->vbuf[vi];
+                        const bool presum = band_plan.count(vi) != 0;
+                        x.out = presum ? band_plan[vi].tmp : g->vbuf[vi];
                         x.k = (uint32_t)g->edges[vi].size();
                         x.mode = v.kind == K_NORMALIZE ? 1u : 0u;
                         x.term_mode = term_mode[vi];
-                        x.pg = make_pg(v.gain, v.angle);
+                        x.pg = presum ? PanGain{1.0f, 1.0f, 1.0f, 0u} : make_pg(v.gain, v.angle);
                         if (v.kind == K_NORMALIZE) {
                             x.state = &g->dstate[v.state_slot].norm;
                             x.use_init = v.has_init_override ? 1u : 0u;   // reset_normalization consumed here
@@ -973,10 +1022,47 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     for (size_t i = 0; i < vs.size(); ++i)
                         ptr_field(off + i * sizeof(BandDesc), offsetof(BandDesc, ins), ins_off[vs[i]]);
                 } break;
+                case F_BAND_SPEC: {
+                    std::vector<BandSpecDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        const BandPlan& bp = band_plan[vi];
+                        BandSpecDesc x{};
+                        x.x = bp.tmp;
+                        x.out = g->vbuf[vi];
+                        x.state = &g->dstate[v.state_slot].band;
+                        x.nseg = bp.nseg;
+                        x.S = bp.S;
+                        x.W = bp.W;
+                        x.pass = v.pass;
+                        x.lgamma = v.lgamma;
+                        x.hgamma = v.hgamma;
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                        max_nseg = std::max(max_nseg, bp.nseg);
+                    }
+                    off = st.put(d);
+                    band_desc_off = off;
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(BandSpecDesc);
+                        const uint32_t ns = band_plan[vs[i]].nseg;
+                        scratch_field(o, offsetof(BandSpecDesc, seg_start), scratch((size_t)ns * 16));
+                        scratch_field(o, offsetof(BandSpecDesc, seg_final), scratch((size_t)ns * 16));
+                        scratch_field(o, offsetof(BandSpecDesc, seg_flags), scratch((size_t)ns * 4));
+                        scratch_field(o, offsetof(BandSpecDesc, seg_x0), scratch((size_t)ns * 8));
+                        scratch_field(o, offsetof(BandSpecDesc, jobs), scratch((size_t)ns * sizeof(BandJob)));
+                        const size_t so = scratch(16);
+                        scratch_field(o, offsetof(BandSpecDesc, stats), so);
+                        g->band_stats_off.push_back(so);
+                    }
+                } break;
+                case F_BAND_FIX:
+                case F_BAND_FILL: off = band_desc_off; break;   // reuse the k_band_spec descriptors
                 default: continue;
             }
-            launches.push_back({fam, off, (int)vs.size()});
+            launches.push_back({fam, off, (int)vs.size(), max_nseg});
         }
+        for (float2* t : level_tmp) g->free_bufs.push_back(t);
         // release buffers whose last consumer sits at this level
         for (size_t vi : g->order)
             if (g->vbuf[vi] && last_use[vi] == lv && (long)vi != g->output_vertex) {
@@ -989,9 +1075,10 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     const Vertex& outv = g->vertices[(size_t)g->output_vertex];
     if (pcm_dst && qmode && outv.kind != K_NORMALIZE) {
         std::vector<QuantDesc> d{{g->vbuf[(size_t)g->output_vertex], pcm_dst, amplitude, (uint32_t)qmode}};
-        launches.push_back({F_QUANT, st.put(d), 1});
+        launches.push_back({F_QUANT, st.put(d), 1, 0u});
     }
 
+    g->band_stats_base = 0;
     // ---- 3. upload
     const size_t upload = (st.b.size() + 255) & ~(size_t)255;
     if (!ensure_arena(g, upload + scratch_bytes + 256)) return 0;
@@ -999,6 +1086,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
         uint64_t p = (uint64_t)(uintptr_t)(g->darena + f.staging_off);
         memcpy(&st.b[f.at], &p, 8);
     }
+    g->band_stats_base = upload;
     for (auto& f : fixes) {
         uint64_t p = (uint64_t)(uintptr_t)(g->darena + upload + f.scratch_off);
         memcpy(&st.b[f.at], &p, 8);
@@ -1030,6 +1118,9 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
             case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, g->stream); break;
             case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, g->stream); break;
             case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, g->stream); break;
+            case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, g->stream); break;
+            case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, (uint32_t)M, g->stream); break;
             case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, (uint32_t)M, g->stream); break;
         }
     }
@@ -1566,9 +1657,24 @@ size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float*
 }
 size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes; }
 
+int td_graph_band_stats(const td_graph* gc, uint32_t out[3]) {
+    td_graph* g = const_cast<td_graph*>(gc);
+    out[0] = out[1] = out[2] = 0;
+    if (g->band_stats_off.empty() || !g->darena) return 1;
+    if (!ensure_device(g->device)) return 0;
+    TD_HIP(hipStreamSynchronize(g->stream));
+    for (size_t so : g->band_stats_off) {
+        uint32_t s[4];
+        TD_HIP(hipMemcpy(s, g->darena + g->band_stats_base + so, 16, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 3; ++i) out[i] += s[i];
+    }
+    return 1;
+}
+
 int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
+    if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
     if (k == "max_chunk_frames") {
         if (value < 1) return fail("max_chunk_frames must be >= 1");
         g->max_chunk_frames = (size_t)value;

@@ -142,6 +142,9 @@ struct td_graph {
     float* d_scalar = nullptr;
     size_t device_bytes = 0;
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
+    bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
+    std::vector<size_t> band_stats_off;        // scratch offsets of the last chunk's k_band_fix counters
+    size_t band_stats_base = 0;
     size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)
     // profiling
     bool profiling = false;

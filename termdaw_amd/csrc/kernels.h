@@ -12,7 +12,9 @@
 namespace tdk {
 
 constexpr int kThreads = 256;       // 4 wave64 per workgroup
-constexpr int kTileFrames = 1024;   // frames per workgroup tile: 2 x float4 (2 frames each) per thread
+constexpr int kTileFrames = 1024;
+constexpr uint32_t kBandMaxSegs = 131072;   // k_band_fix keeps its mismatch bitmap in LDS
+constexpr uint32_t kBandMaxS = 1024;        // ... and stages one segment of input / output there   // frames per workgroup tile: 2 x float4 (2 frames each) per thread
 
 // Vertex epilogue: Sample::apply_angle then Sample::apply_gain (sample.rs:97-114, order fixed at
 // extensions.rs:262-263).  Amplitudes are computed on the host with libm; flags carry the skip
@@ -181,6 +183,37 @@ struct BandDesc {
     PanGain pg;
 };
 
+// band_pass_gen, exact AND parallel: speculative segments.
+//   The recurrence y += gamma * (x - y) is a contraction: two trajectories fed the same input collapse onto
+//   each other and, once bit-identical, stay identical.  The chunk is cut into segments of S frames; a
+//   quad of lanes (low L, low R, high L, high R) runs each segment after a warm-up of W frames started from
+//   a guess, records the state it entered the segment with and the state it left with, and writes the
+//   segment's output.  k_band_fix then checks, bit for bit, that every segment entered with exactly the
+//   state its predecessor left with -- by induction from the exactly-known first segment this proves the
+//   whole output exact -- and recomputes (only) segments where the check fails.  The usual failures are
+//   constant or silent input stretches, where f32 trajectories park on different sticky points: there the
+//   true state is a fixed point, so k_band_fix skips the whole stretch in one step and leaves its output
+//   (state fixed, input known) to the parallel k_band_fill.
+struct BandJob { uint32_t begin, end; float y[4]; uint32_t pad[2]; };   // frames [begin, end) with parked state y
+struct BandSpecDesc {
+    const float2* x;        // summed input of the vertex, materialised (sum_inputs, no epilogue)
+    float2* out;
+    BandState* state;       // carried across chunks
+    float* seg_start;       // [nseg][4] state on entry (after warm-up)
+    float* seg_final;       // [nseg][4] state on exit
+    uint32_t* seg_flags;    // [nseg] bit0: input bit-identical over the whole segment, bit1: input all (+-)0
+    float2* seg_x0;         // [nseg] first input frame of the segment
+    BandJob* jobs;          // [nseg] parked stretches found by k_band_fix, executed by k_band_fill
+    uint32_t* stats;        // [4]: mismatches found, segments recomputed, segments parked, jobs
+    uint32_t nseg, S, W;
+    uint32_t pass;
+    float lgamma, hgamma;
+    PanGain pg;
+};
+
+void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
+void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);

@@ -583,6 +583,301 @@ __global__ __launch_bounds__(kThreads) void k_band_pass(const BandDesc* __restri
     if (lane == 0) d.state->first = first ? 1u : 0u;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_band_spec / k_band_fix: the same filter, exact and parallel (see BandSpecDesc in kernels.h)
+// ------------------------------------------------------------------------------------------------
+template <int J>
+TD_DEV float quad_bcast(float v) {   // value of lane J of this lane's quad (DPP quad_perm, no LDS)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J * 0x55, 0xF, 0xF, true));
+}
+struct BandCoef { float lmul, hmul, pass_mul, cut_mul; };
+TD_DEV BandCoef band_coef(float lgamma, float hgamma, uint32_t pass) {
+    BandCoef k;
+    k.lmul = lgamma == 0.0f ? 0.0f : 1.0f;
+    k.hmul = hgamma == 0.0f ? 0.0f : 1.0f;
+    k.pass_mul = pass ? 1.0f : 0.0f;
+    k.cut_mul = 1.0f - k.pass_mul;
+    return k;
+}
+// one output frame from the quad's four states and the input frame (extensions.rs:682-687, quirk Q7)
+TD_DEV float2 band_out(const BandCoef& k, float l, float r, float ll, float lr, float hl, float hr) {
+    const float cutl = (k.lmul * ll + k.hmul * (l - hl)) * 0.5f;
+    const float cutr = (k.lmul * lr + k.hmul * (r - hr)) * 0.5f;
+    const float passl = l - cutl;
+    const float passr = r - cutl;
+    return make_float2(cutl * k.cut_mul + passl * k.pass_mul, cutr * k.cut_mul + passr * k.pass_mul);
+}
+
+__global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __restrict__ descs, uint32_t M) {
+    const BandSpecDesc& d = descs[blockIdx.y];
+    const uint32_t c = threadIdx.x & 3u;                       // chain: 0 low L, 1 low R, 2 high L, 3 high R
+    const uint32_t seg = blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2);
+    if (seg >= d.nseg) return;                                 // whole quads leave together
+    const uint32_t ch = c & 1u;
+    const float gam = (c & 2u) ? d.hgamma : d.lgamma;
+    const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
+    const float* __restrict__ xf = reinterpret_cast<const float*>(d.x);
+    const uint32_t start = seg * d.S;
+    const uint32_t end = min(start + d.S, M);
+    uint32_t n = start > d.W ? start - d.W : 0u;
+    // exact state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
+    const float y_true0 = d.state->first ? xf[ch] : reinterpret_cast<const float*>(d.state)[c];
+    float y;
+    if (n == 0u || gam == 0.0f) y = y_true0;                   // gamma 0: the chain never moves
+    else y = xf[2u * n + ch];                                  // guess; the warm-up forgets it
+    // Input fetch: the four lanes of a quad load four consecutive 16-byte words (8 frames, 64 B) with ONE
+    // instruction and hand them round with DPP quad broadcasts -- one vector-memory instruction per 8
+    // steps instead of 8, which is what the address path of 16 independent streams per wave can sustain.
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(d.x);
+    const uint32_t M2 = (M + 1u) >> 1;                       // 16-byte words in the (even-padded) buffer
+    auto fetch8 = [&](uint32_t frame) -> float4 {            // frame is a multiple of 8
+        const uint32_t w = (frame >> 1) + c;
+        return w < M2 ? x4[w] : make_float4(0.f, 0.f, 0.f, 0.f);
+    };
+    // (the broadcasts are cross-lane operations: they must execute unconditionally, the per-lane channel
+    // select comes after)
+#define TD_BAND_UNPACK(J)                                                                          \
+    const float bx_##J = quad_bcast<J>(a.x), by_##J = quad_bcast<J>(a.y);                          \
+    const float bz_##J = quad_bcast<J>(a.z), bw_##J = quad_bcast<J>(a.w);                          \
+    const float e0_##J = ch ? by_##J : bx_##J;                                                     \
+    const float e1_##J = ch ? bw_##J : bz_##J;
+    // warm-up: recurrence only (n and start are multiples of 8: S and W are)
+    if (n + 8u <= start && (n & 7u) == 0u) {
+        float4 a = fetch8(n);
+        for (; n + 8u <= start; n += 8u) {
+            const float4 nx = fetch8(n + 8u);                // next batch in flight under this one's VALU chain
+            TD_BAND_UNPACK(0) TD_BAND_UNPACK(1) TD_BAND_UNPACK(2) TD_BAND_UNPACK(3)
+            y = y + gam * (e0_0 - y); y = y + gam * (e1_0 - y);
+            y = y + gam * (e0_1 - y); y = y + gam * (e1_1 - y);
+            y = y + gam * (e0_2 - y); y = y + gam * (e1_2 - y);
+            y = y + gam * (e0_3 - y); y = y + gam * (e1_3 - y);
+            a = nx;
+        }
+    }
+    for (; n < start; ++n) y = y + gam * (xf[2u * n + ch] - y);
+    d.seg_start[seg * 4u + c] = y;
+    // the segment itself: recurrence + output
+    const float x_first = xf[2u * start + ch];
+    bool same = true, zero = true;
+    auto step = [&](uint32_t m, float l, float r) {
+        if (m >= end) return;
+        const float x = ch ? r : l;
+        same = same && (__float_as_uint(x) == __float_as_uint(x_first));
+        zero = zero && (x == 0.0f);
+        y = y + gam * (x - y);
+        const float2 o = band_out(kf, l, r, quad_bcast<0>(y), quad_bcast<1>(y), quad_bcast<2>(y), quad_bcast<3>(y));
+        if (c == 0u) d.out[m] = epilogue(o, d.pg);
+    };
+    if ((start & 7u) == 0u) {
+        float4 a = fetch8(start);
+        for (n = start; n < end; n += 8u) {
+            const float4 nx = fetch8(n + 8u);
+            const float l0 = quad_bcast<0>(a.x), r0 = quad_bcast<0>(a.y), l1 = quad_bcast<0>(a.z), r1 = quad_bcast<0>(a.w);
+            const float l2 = quad_bcast<1>(a.x), r2 = quad_bcast<1>(a.y), l3 = quad_bcast<1>(a.z), r3 = quad_bcast<1>(a.w);
+            const float l4 = quad_bcast<2>(a.x), r4 = quad_bcast<2>(a.y), l5 = quad_bcast<2>(a.z), r5 = quad_bcast<2>(a.w);
+            const float l6 = quad_bcast<3>(a.x), r6 = quad_bcast<3>(a.y), l7 = quad_bcast<3>(a.z), r7 = quad_bcast<3>(a.w);
+            step(n, l0, r0); step(n + 1u, l1, r1); step(n + 2u, l2, r2); step(n + 3u, l3, r3);
+            step(n + 4u, l4, r4); step(n + 5u, l5, r5); step(n + 6u, l6, r6); step(n + 7u, l7, r7);
+            a = nx;
+        }
+    } else {
+        for (n = start; n < end; ++n) { const float2 x = d.x[n]; step(n, x.x, x.y); }
+    }
+#undef TD_BAND_UNPACK
+    d.seg_final[seg * 4u + c] = y;
+    const float s0 = quad_bcast<0>(same ? 1.0f : 0.0f), s1 = quad_bcast<1>(same ? 1.0f : 0.0f);
+    const float z0 = quad_bcast<0>(zero ? 1.0f : 0.0f), z1 = quad_bcast<1>(zero ? 1.0f : 0.0f);
+    const float xr_first = quad_bcast<1>(x_first);
+    if (c == 0u) {
+        d.seg_flags[seg] = ((s0 != 0.0f && s1 != 0.0f) ? 1u : 0u) | ((z0 != 0.0f && z1 != 0.0f) ? 2u : 0u);
+        d.seg_x0[seg] = make_float2(x_first, xr_first);
+    }
+}
+
+// One workgroup per vertex.  Phase A (1024 lanes): bitmap (LDS) of segments whose entry state differs from
+// the predecessor's exit state.  Phase B (wave 0; lanes 0..3 = the four chains, the other lanes mirror
+// them): repair cascades, in segment order.
+constexpr int kFixThreads = 1024;
+constexpr uint32_t kFixMaxSegs = 131072;   // LDS bitmap capacity (host picks S accordingly)
+__global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __restrict__ descs, uint32_t M) {
+    const BandSpecDesc& d = descs[blockIdx.x];
+    __shared__ uint32_t bitmap[kFixMaxSegs / 32];
+    __shared__ uint32_t found_s;
+    __shared__ float2 xs[kBandMaxS];
+    __shared__ __attribute__((aligned(16))) float ys[kBandMaxS * 4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t nwords = (d.nseg + 31u) / 32u;
+    const uint4* S4 = reinterpret_cast<const uint4*>(d.seg_start);
+    uint4* F4 = reinterpret_cast<uint4*>(d.seg_final);
+    if (tid == 0) found_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < d.nseg; base += kFixThreads) {
+        const uint32_t s = base + tid;
+        bool mis = false;
+        if (s > 0u && s < d.nseg) {
+            const uint4 a = S4[s], p = F4[s - 1u];
+            mis = a.x != p.x || a.y != p.y || a.z != p.z || a.w != p.w;
+        }
+        const unsigned long long m = __ballot(mis ? 1 : 0);
+        if (lane == 0u && (s >> 5) < nwords) {
+            bitmap[s >> 5] = (uint32_t)m;
+            if ((s >> 5) + 1u < kFixMaxSegs / 32) bitmap[(s >> 5) + 1u] = (uint32_t)(m >> 32);
+            if (m) atomicAdd(&found_s, (uint32_t)__popcll(m));
+        }
+    }
+    __syncthreads();
+    const uint32_t found = found_s;
+    uint32_t recomputed = 0, parked_segs = 0, njobs = 0;
+    if (tid < 64u) {
+        if (found) {
+            const uint32_t c = lane & 3u, ch = c & 1u;
+            const float gam = (c & 2u) ? d.hgamma : d.lgamma;
+            const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
+                        const uint32_t* Su = reinterpret_cast<const uint32_t*>(d.seg_start);
+            uint32_t* Fu = reinterpret_cast<uint32_t*>(d.seg_final);
+            const uint2* X0 = reinterpret_cast<const uint2*>(d.seg_x0);
+            uint32_t seg = 1;
+            while (seg < d.nseg) {
+                // next flagged segment at or after seg (wave-uniform scan of the bitmap)
+                uint32_t w = seg >> 5, bits = bitmap[w] & (0xFFFFFFFFu << (seg & 31u));
+                while (bits == 0u && ++w < nwords) bits = bitmap[w];
+                if (w >= nwords) break;
+                seg = w * 32u + (uint32_t)__ffs((int)bits) - 1u;
+                // exit state of the predecessor: lanes 0..3 own every store to seg_final made in this kernel
+                float y = __shfl(__uint_as_float(Fu[(seg - 1u) * 4u + c]), (int)c, 64);
+                // cascade: recompute from y until a recomputed exit state reproduces the stored one, or the
+                // next segment is found to have entered with exactly the new exit state
+                for (;;) {
+                    const uint32_t start = seg * d.S, end = min(start + d.S, M), len = end - start;
+                    const uint32_t flags = d.seg_flags[seg];
+                    uint32_t last = seg;   // last segment covered by this round
+                    // stage the segment's input in LDS (one coalesced sweep), step through it, flush the output
+                    for (uint32_t q = lane; q < len; q += 64u) xs[q] = d.x[start + q];
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    const float* xsf = reinterpret_cast<const float*>(xs);
+                    // Quad 0 (lanes 0..3) follows the TRUE trajectory from y; quad 1 (lanes 4..7) re-runs the
+                    // speculative one from the entry state pass 1 used.  As soon as the two are bit-identical
+                    // the rest of the segment -- output and exit state -- is already right (checked every 8
+                    // steps).  The other lanes idle along as copies of quad 0.
+                    float yy = (lane >= 4u && lane < 8u) ? __uint_as_float(Su[seg * 4u + c]) : y;
+                    uint32_t n = 0;
+                    bool parked = false, coalesced = false;
+                    while (n < len && !parked && !coalesced) {
+                        const uint32_t nb = min(8u, len - n);
+                        float xv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) xv[u] = (uint32_t)u < nb ? xsf[2u * (n + u) + ch] : 0.0f;
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            if ((uint32_t)u >= nb || parked) continue;
+                            const float yn = yy + gam * (xv[u] - yy);
+                            const bool still = __float_as_uint(yn) == __float_as_uint(yy);
+                            yy = yn;
+                            if (lane < 4u) ys[(n + u) * 4u + c] = yy;
+                            if (!flags || !__all((lane >= 4u || still) ? 1 : 0)) continue;
+                            // All four chains sit on a fixed point of this frame's input.  It stays one while
+                            // the input is (A) bit-identical, or (B) any-signed zero with every moving chain
+                            // non-zero (x - y is then the same for +0 and -0).  The state is parked for the rest
+                            // of this segment and for every following segment of the same class.
+                            const bool zero_ok = (flags & 2u) && __all((lane >= 4u || gam == 0.0f || yy != 0.0f) ? 1 : 0);
+                            const bool const_ok = (flags & 1u) != 0u;
+                            if (!zero_ok && !const_ok) continue;
+                            const uint2 x0 = X0[seg];
+                            uint32_t e = seg + 1u;
+                            for (;;) {   // extend over following segments, 64 at a time
+                                const uint32_t s2 = e + lane;
+                                bool ok = false;
+                                if (s2 < d.nseg) {
+                                    const uint32_t f2 = d.seg_flags[s2];
+                                    if (zero_ok) ok = (f2 & 2u) != 0u;
+                                    else { const uint2 x2 = X0[s2]; ok = (f2 & 1u) && x2.x == x0.x && x2.y == x0.y; }
+                                }
+                                const unsigned long long m = __ballot(ok ? 1 : 0);
+                                const uint32_t run = m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1u;
+                                e += run;
+                                if (run < 64u) break;
+                            }
+                            const float y0 = quad_bcast<0>(yy), y1 = quad_bcast<1>(yy), y2 = quad_bcast<2>(yy), y3 = quad_bcast<3>(yy);
+                            if (lane == 0u) {
+                                BandJob j;
+                                j.begin = start + n + (uint32_t)u + 1u;
+                                j.end = min(e * d.S, M);
+                                j.y[0] = y0; j.y[1] = y1; j.y[2] = y2; j.y[3] = y3;
+                                j.pad[0] = j.pad[1] = 0u;
+                                d.jobs[njobs] = j;
+                            }
+                            ++njobs;
+                            parked_segs += e - seg;
+                            last = e - 1u;
+                            parked = true;
+                            n += (uint32_t)u + 1u;
+                        }
+                        if (!parked) {
+                            n += nb;
+                            const float twin = __shfl_xor(yy, 4, 64);
+                            coalesced = __all((lane >= 8u || __float_as_uint(twin) == __float_as_uint(yy)) ? 1 : 0) != 0;
+                        }
+                    }
+                    y = __shfl(yy, (int)c, 64);   // true state, every lane
+                    // outputs of the n frames stepped above, 64 at a time
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    for (uint32_t q = lane; q < n; q += 64u) {
+                        const float2 x = xs[q];
+                        const float4 s = reinterpret_cast<const float4*>(ys)[q];
+                        d.out[start + q] = epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), d.pg);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (coalesced && !parked) {   // pass 1's exit state of this segment stands: cascade over
+                        ++recomputed;
+                        ++seg;
+                        break;
+                    }
+                    recomputed += last - seg + 1u;
+                    const bool changed = __any((lane < 4u && Fu[last * 4u + c] != __float_as_uint(y)) ? 1 : 0) != 0;
+                    if (lane < 4u) Fu[last * 4u + c] = __float_as_uint(y);
+                    seg = last + 1u;
+                    if (!changed || seg >= d.nseg) break;
+                    const bool next_ok = __any((lane < 4u && Su[seg * 4u + c] != __float_as_uint(y)) ? 1 : 0) == 0;
+                    if (next_ok) { ++seg; break; }   // seg entered with exactly this state: its pass-1 result stands
+                }
+            }
+        }
+        if (lane < 4u) reinterpret_cast<uint32_t*>(d.state)[lane] = reinterpret_cast<const uint32_t*>(d.seg_final)[(d.nseg - 1u) * 4u + lane];
+        if (lane == 0u) {
+            d.state->first = 0u;
+            d.stats[0] = found;
+            d.stats[1] = recomputed;
+            d.stats[2] = parked_segs;
+            d.stats[3] = njobs;
+        }
+    }
+}
+
+// Output of the parked stretches recorded by k_band_fix: the four states are constants, every frame's
+// output follows from its own input frame -- fully parallel.
+__global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __restrict__ descs, uint32_t M) {
+    const BandSpecDesc& d = descs[blockIdx.y];
+    const uint32_t njobs = d.stats[3];
+    if (njobs == 0u) return;
+    const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
+    const uint32_t tile0 = blockIdx.x * kTileFrames;
+    // jobs are sorted and disjoint: first job ending after the tile start
+    uint32_t lo = 0, hi = njobs;
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (d.jobs[mid].end > tile0) hi = mid; else lo = mid + 1u; }
+    if (lo >= njobs || d.jobs[lo].begin >= min(tile0 + (uint32_t)kTileFrames, M)) return;
+    for (uint32_t f = threadIdx.x; f < (uint32_t)kTileFrames; f += kThreads) {
+        const uint32_t m = tile0 + f;
+        if (m >= M) break;
+        uint32_t j = lo;
+        while (j < njobs && d.jobs[j].end <= m) ++j;
+        if (j >= njobs) break;
+        const BandJob jb = d.jobs[j];
+        if (m < jb.begin) continue;
+        const float2 x = d.x[m];
+        d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
+    }
+}
+
 // single-float absolute max of a small table (per-project peak)
 __global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ v, uint32_t n, float* out) {
     float m = 0.0f;
@@ -640,6 +935,18 @@ void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t s) {
 void launch_band_pass(const BandDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
     hipLaunchKernelGGL(k_band_pass, dim3(n), dim3(kThreads), 0, s, d, frames);
+}
+void launch_band_spec(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max_nseg, hipStream_t s) {
+    if (!n || !frames) return;
+    hipLaunchKernelGGL(k_band_spec, dim3((max_nseg + kThreads / 4 - 1) / (kThreads / 4), n), dim3(kThreads), 0, s, d, frames);
+}
+void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    hipLaunchKernelGGL(k_band_fix, dim3(n), dim3(kFixThreads), 0, s, d, frames);
+}
+void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    hipLaunchKernelGGL(k_band_fill, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
 }
 void launch_absmax(const float* peaks, uint32_t n, float* out, hipStream_t s) {
     hipLaunchKernelGGL(k_absmax, dim3(1), dim3(kThreads), 0, s, peaks, n, out);

@@ -198,3 +198,54 @@ def test_multi_chunk_render_matches_single_chunk(gpu_api, oracle, chunk_frames, 
     built[2].set_option("max_chunk_frames", chunk_frames)
     got = p.render(gpu_api, built=built, scan=True)
     (assert_bit_exact if project == "drum" else assert_close)(got, p.render(oracle, scan=True))
+
+
+def _gappy_project(lo, hi, pass_, seconds=2.0):
+    """sample_multi with sparse hits (exact-zero gaps) and a sample_lerp holding its last frame (constant
+    non-zero stretches) into one band-pass: the inputs on which speculative segments must be repaired."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(seconds)
+    p.assets["pluck"] = W.Asset(W.tone_int16(21, 2500))
+    p.assets["kick"] = W.Asset(W.kick_int16(22, 6000) + np.int16(3))     # last frame != 0 -> held DC offset
+    p.load_sample("pluck", "pluck", "")
+    p.load_sample("kick", "kick", "")
+    p.event_files["a"] = np.array([(0.3 * i + 0.01, 60.0, 0.8) for i in range(int(seconds / 0.3))], np.float32)
+    p.event_files["b"] = np.array([(0.7 * i + 0.2, 36.0, 1.0) for i in range(int(seconds / 0.7) + 1)], np.float32)
+    p.load_midi_floww("a", "a")
+    p.load_midi_floww("b", "b")
+    p.add_sample_multi("m", 1.0, 0.0, "pluck", "a", -1)
+    p.add_sample_lerp("l", 0.5, 30.0, "kick", "b", -1, 64)
+    p.add_bandpass("bp", 1.2, -20.0, 1.0, lo, hi, pass_)
+    p.add_bandpass("bp2", 1.0, 0.0, 1.0, hi, lo, not pass_)
+    p.add_normalize("out", 1.0, 0.0)
+    p.connect("m", "bp")
+    p.connect("l", "bp")
+    p.connect("bp", "bp2")
+    p.connect("bp2", "out")
+    p.set_output("out")
+    return p
+
+
+@pytest.mark.parametrize("lo,hi,pass_", [(200.0, 4000.0, True), (20.0, 18000.0, False), (0.0, 50.0, True),
+                                         (1000.0, 0.0, True), (5.0, 9000.0, True)])
+@pytest.mark.parametrize("parallel", [1, 0])
+def test_band_pass_parallel_is_exact(gpu_api, oracle, lo, hi, pass_, parallel):
+    """The speculative-segment band-pass must reproduce the serial recurrence bit for bit, on inputs with
+    silent and constant stretches, for cut-offs from 5 Hz (serial fallback) to 18 kHz."""
+    p = _gappy_project(lo, hi, pass_)
+    built = p.build(gpu_api)
+    built[2].set_option("band_parallel", parallel)
+    got = p.render(gpu_api, built=built)
+    assert_bit_exact(got, p.render(oracle))
+    st = built[2].band_stats()
+    if parallel and lo == 200.0:
+        assert st["recomputed"] >= st["parked"] >= 0
+    if not parallel:
+        assert st == {"mismatched": 0, "recomputed": 0, "parked": 0}
+
+
+def test_band_pass_parallel_chunked_state_carry(gpu_api, oracle):
+    p = _gappy_project(300.0, 3000.0, True, seconds=3.0)
+    built = p.build(gpu_api)
+    built[2].set_option("max_chunk_frames", 30000)
+    assert_bit_exact(p.render(gpu_api, built=built, scan=True), p.render(oracle, scan=True))
