@@ -179,7 +179,12 @@ def main():
                        "parallelism": "projects sharded 1 per GPU; RCCL all-reduce(max) of the peak table only"},
             "roofline": None if not dom else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac_of_8TBs"], "frac_of_measured_copy_6.29TBs": dom["frac_of_measured_copy"], "traffic": traffic},
+                "frac": dom["frac_of_8TBs"], "frac_of_measured_copy_6.29TBs": dom["frac_of_measured_copy"], "traffic": traffic,
+                "note": ("algorithmic bytes = (8k+8) B/frame x frames (SURVEY 8d); with source inlining the k=64 reads are "
+                         "gathers from the 40 MB sample set, served by L2 / Infinity Cache rather than HBM -- `traffic` is "
+                         "the PMC L2-miss-side byte count per launch (profiles/traffic.json); run with --no-fuse for the "
+                         "edge-buffer model where every algorithmic byte is an HBM byte") if not args.no_fuse else
+                        "edge-buffer model: every algorithmic byte is an HBM byte (PMC traffic == algorithmic bytes)"},
             "kernels": kernels,
             "peak_table": [round(float(x), 6) for x in peaks],
             "device_bytes": g.device_bytes(),

@@ -9,6 +9,7 @@
 #include "engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -678,8 +679,9 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     // starts in the sound before a silence reproduces the decay into it), the rest is coalescence margin
     const double w = 150.0 / (double)gmin + 64.0;
     if (!(w <= 262144.0)) return p;   // cut-offs below ~5 Hz: the serial kernel is the better plan
-    p.W = ((uint32_t)w + 7u) & ~7u;
+    p.W = ((uint32_t)w + 31u) & ~31u;
     p.S = 256;
+    if (const char* sv = getenv("TD_BAND_S")) p.S = (uint32_t)atoi(sv);   // experiment knob
     while ((M + p.S - 1) / p.S > kBandMaxSegs && p.S < kBandMaxS) p.S *= 2;
     p.nseg = (uint32_t)((M + p.S - 1) / p.S);
     if (p.nseg > kBandMaxSegs) return p;

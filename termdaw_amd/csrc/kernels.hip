@@ -641,19 +641,29 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     const float bz_##J = quad_bcast<J>(a.z), bw_##J = quad_bcast<J>(a.w);                          \
     const float e0_##J = ch ? by_##J : bx_##J;                                                     \
     const float e1_##J = ch ? bw_##J : bz_##J;
-    // warm-up: recurrence only (n and start are multiples of 8: S and W are)
-    if (n + 8u <= start && (n & 7u) == 0u) {
-        float4 a = fetch8(n);
-        for (; n + 8u <= start; n += 8u) {
-            const float4 nx = fetch8(n + 8u);                // next batch in flight under this one's VALU chain
-            TD_BAND_UNPACK(0) TD_BAND_UNPACK(1) TD_BAND_UNPACK(2) TD_BAND_UNPACK(3)
-            y = y + gam * (e0_0 - y); y = y + gam * (e1_0 - y);
-            y = y + gam * (e0_1 - y); y = y + gam * (e1_1 - y);
-            y = y + gam * (e0_2 - y); y = y + gam * (e1_2 - y);
-            y = y + gam * (e0_3 - y); y = y + gam * (e1_3 - y);
-            a = nx;
+    // warm-up: recurrence only.  n and start are multiples of 32 (S and W are), so the loop runs in batches
+    // of 32 frames: four quad-wide fetches (256 B per quad) issued one whole batch ahead -- ~32 steps of
+    // dependent VALU (3 ops per step) cover an Infinity Cache / L2 round trip.
+#define TD_BAND_STEP8(A)                                                                           \
+    {                                                                                              \
+        const float4 a = A;                                                                        \
+        TD_BAND_UNPACK(0) TD_BAND_UNPACK(1) TD_BAND_UNPACK(2) TD_BAND_UNPACK(3)                    \
+        y = y + gam * (e0_0 - y); y = y + gam * (e1_0 - y);                                        \
+        y = y + gam * (e0_1 - y); y = y + gam * (e1_1 - y);                                        \
+        y = y + gam * (e0_2 - y); y = y + gam * (e1_2 - y);                                        \
+        y = y + gam * (e0_3 - y); y = y + gam * (e1_3 - y);                                        \
+    }
+    if (n + 32u <= start && (n & 31u) == 0u) {
+        float4 p0 = fetch8(n), p1 = fetch8(n + 8u), p2 = fetch8(n + 16u), p3 = fetch8(n + 24u);
+        for (; n + 32u <= start; n += 32u) {
+            const float4 q0 = fetch8(n + 32u), q1 = fetch8(n + 40u), q2 = fetch8(n + 48u), q3 = fetch8(n + 56u);
+            TD_BAND_STEP8(p0) TD_BAND_STEP8(p1) TD_BAND_STEP8(p2) TD_BAND_STEP8(p3)
+            p0 = q0; p1 = q1; p2 = q2; p3 = q3;
         }
     }
+    if ((n & 7u) == 0u)
+        for (; n + 8u <= start; n += 8u) TD_BAND_STEP8(fetch8(n))
+#undef TD_BAND_STEP8
     for (; n < start; ++n) y = y + gam * (xf[2u * n + ch] - y);
     d.seg_start[seg * 4u + c] = y;
     // the segment itself: recurrence + output

@@ -444,3 +444,49 @@ def synth_project(seconds=3.0, bl=1024, voices=5):
     p.connect("cut", "sum")
     p.set_output("sum")
     return p
+
+
+def config4(seconds=60.0, depth=252):
+    """Deep chain (BASELINE config 4 shape): synth + sample_lerp -> sum -> `depth` single-input vertices
+    alternating sum(gain 1.41, angle +-1) / bandpass(20 Hz, 18 kHz) / adsr -> normalize = depth + 4 vertices.
+    The reference config names a sampsyn wavetable voice and a 44.1 kHz asset; both sit on un-vendored
+    crates (sampsyn, rubato), so this build substitutes the in-tree synth voice and a 48 kHz asset."""
+    p = ProjectScript(48000, 1024)
+    p.set_length(seconds)
+    p.assets["kick"] = Asset(kick_int16(7, 20000))
+    p.load_sample("kick", "kick", "")
+    hits = [(0.25 * i, 36.0, 0.9) for i in range(int(seconds / 0.25))]
+    p.event_files["hits"] = np.array(hits, dtype=np.float32)
+    notes = []
+    t = 0.0
+    while t < seconds:
+        for j in range(4):
+            notes.append((t + 0.01 * j, 50.0 + 4 * j, 0.4))
+        for j in range(4):
+            notes.append((t + 0.8 + 0.01 * j, 50.0 + 4 * j, 0.0))
+        t += 1.0
+    notes.sort(key=lambda e: e[0])
+    p.event_files["notes"] = np.array(notes, dtype=np.float32)
+    p.load_midi_floww("hits", "hits")
+    p.load_midi_floww("notes", "notes")
+    p.add_synth("syn", 0.5, 0.0, "notes", 0.4, 0.3, HIT_ADSR, 1.0, 0.8, NOTE_ADSR, 0.5, NOTE_ADSR)
+    p.add_sample_lerp("lerp", 1.0, 0.0, "kick", "hits", -1, 40)
+    p.add_sum("mix", 1.0, 0.0)
+    p.connect("syn", "mix")
+    p.connect("lerp", "mix")
+    prev = "mix"
+    for i in range(depth):
+        name = "c%03d" % i
+        if i % 3 == 0:
+            # a 1 degree pan already costs x0.713 / x0.701 (constant-power law, quirk Q1): gain 1.41 keeps the chain near unity
+            p.add_sum(name, 1.41, 1.0 if (i // 3) % 2 == 0 else -1.0)
+        elif i % 3 == 1:
+            p.add_bandpass(name, 1.0, 0.0, 1.0, 20.0, 18000.0, True)
+        else:
+            p.add_adsr(name, 1.0, 0.0, 0.5, "hits", False, True, -1, [0.01, 0.1, 0.8, 0.1, 0.2, 0.01])
+        p.connect(prev, name)
+        prev = name
+    p.add_normalize("sum", 1.0, 0.0)
+    p.connect(prev, "sum")
+    p.set_output("sum")
+    return p

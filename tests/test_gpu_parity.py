@@ -249,3 +249,10 @@ def test_band_pass_parallel_chunked_state_carry(gpu_api, oracle):
     built = p.build(gpu_api)
     built[2].set_option("max_chunk_frames", 30000)
     assert_bit_exact(p.render(gpu_api, built=built, scan=True), p.render(oracle, scan=True))
+
+
+def test_config4_deep_chain_short(gpu_api, oracle):
+    """256-vertex chain (sum / band-pass 20 Hz..18 kHz / adsr alternating): synth at the head -> tolerance class."""
+    p = W.config4(seconds=1.5)
+    assert sum(len(p.calls[k]) for k in p.calls if k.startswith("add_")) == 256
+    assert_close(p.render(gpu_api), p.render(oracle), rms_tol=2e-6)

@@ -27,3 +27,5 @@ if __name__ == "__main__":
     if "c3" in sel: run("config3", W.config3())
     if "drum" in sel: run("drum60", W.drum_project(seconds=60.0))
     if "synth" in sel: run("synth60", W.synth_project(seconds=60.0))
+    if "c4" in sel: run("config4", W.config4())
+    if "c4s" in sel: run("config4_6s", W.config4(seconds=6.0))
