@@ -141,7 +141,9 @@ size_t td_graph_device_bytes(const td_graph* g);
 /* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
  * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);
  * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders);
- * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact). */
+ * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
+ * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
+ * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */
 int td_graph_set_option(td_graph* g, const char* key, long value);
 /* Counters of the exact parallel band-pass for the last rendered chunk, summed over its band-pass
  * vertices: out[0] segments whose speculative entry state failed the bit-wise check, out[1] segments

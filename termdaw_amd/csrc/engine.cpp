@@ -541,6 +541,11 @@ static int ensure_graph_device(td_graph* g) {
     if (!g->stream) {
         TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         TD_HIP(hipEventCreateWithFlags(&g->arena_copied, hipEventDisableTiming));
+        TD_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        for (int a = 0; a < td_graph::kAuxStreams; ++a) {
+            TD_HIP(hipStreamCreateWithFlags(&g->aux[a], hipStreamNonBlocking));
+            TD_HIP(hipEventCreateWithFlags(&g->ev_join[a], hipEventDisableTiming));
+        }
         TD_HIP(hipMalloc(&g->d_scalar, 256));
     }
     return 1;
@@ -645,21 +650,39 @@ static hipEvent_t get_event(td_graph* g) {
 struct Prof {
     td_graph* g;
     int fam;
+    hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
-    Prof(td_graph* g_, int fam_) : g(g_), fam(fam_) {
+    Prof(td_graph* g_, int fam_, hipStream_t s_) : g(g_), fam(fam_), s(s_) {
         if (g->profiling) {
             a = get_event(g);
             b = get_event(g);
-            (void)hipEventRecord(a, g->stream);
+            (void)hipEventRecord(a, s);
         }
     }
     ~Prof() {
         if (g->profiling) {
-            (void)hipEventRecord(b, g->stream);
+            (void)hipEventRecord(b, s);
             g->ev_pending.push_back({a, b, fam});
         }
     }
 };
+
+// Branch streams: vertices of one topological level are mutually independent.  Same-kind vertices already
+// share one batched launch; launches of DIFFERENT kinds in a level go to separate HIP streams (fork after the
+// previous level, join before the next) so independent branches of the graph overlap on the device.  The
+// sum -> scale -> band-pass chain of a level stays on the main stream.
+static int aux_stream_of(int fam) {
+    switch (fam) {
+        case F_LOOP: return 0;
+        case F_MULTI: return 1;
+        case F_LERP: return 2;
+        case F_SINE: return 3;
+        case F_SYNTH: return 4;
+        case F_ADSR: return 5;
+        case F_BAND: return 6;
+        default: return -1;
+    }
+}
 
 // Band-pass execution plan (DESIGN.md "exact parallel band-pass"): segment length S, warm-up W.  The
 // warm-up must outlast the contraction (1 - gamma)^W of the slower chain.  The choice affects speed only --
@@ -748,7 +771,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
         for (size_t vi : g->order)
             inlined[vi] = g->vertices[vi].kind == K_SAMPLE_LOOP && (long)vi != g->output_vertex;
 
-    struct Launch { int fam; size_t off; int n; uint32_t aux; };
+    struct Launch { int fam; size_t off; int n; uint32_t aux; int level; };
     std::vector<Launch> launches;
     std::vector<std::vector<size_t>> by_level(g->n_levels);
     for (size_t vi : g->order) by_level[g->level[vi]].push_back(vi);
@@ -1062,7 +1085,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_BAND_FILL: off = band_desc_off; break;   // reuse the k_band_spec descriptors
                 default: continue;
             }
-            launches.push_back({fam, off, (int)vs.size(), max_nseg});
+            launches.push_back({fam, off, (int)vs.size(), max_nseg, lv});
         }
         for (float2* t : level_tmp) g->free_bufs.push_back(t);
         // release buffers whose last consumer sits at this level
@@ -1077,7 +1100,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     const Vertex& outv = g->vertices[(size_t)g->output_vertex];
     if (pcm_dst && qmode && outv.kind != K_NORMALIZE) {
         std::vector<QuantDesc> d{{g->vbuf[(size_t)g->output_vertex], pcm_dst, amplitude, (uint32_t)qmode}};
-        launches.push_back({F_QUANT, st.put(d), 1, 0u});
+        launches.push_back({F_QUANT, st.put(d), 1, 0u, g->n_levels});
     }
 
     g->band_stats_base = 0;
@@ -1106,25 +1129,52 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     }
     for (size_t pk : peaks_to_zero) TD_HIP(hipMemsetAsync(g->darena + upload + pk, 0, nb * sizeof(float), g->stream));
 
-    // ---- 4. launch
-    for (auto& L : launches) {
-        const void* d = g->darena + L.off;
-        Prof prof(g, L.fam);
-        switch (L.fam) {
-            case F_LOOP: launch_sample_loop((const LoopDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_MULTI: launch_sample_multi((const MultiDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_LERP: launch_sample_lerp((const LerpDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, g->stream); break;
-            case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, g->stream); break;
-            case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, g->stream); break;
-            case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, g->stream); break;
-            case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, (uint32_t)M, g->stream); break;
-            case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, (uint32_t)M, g->stream); break;
+    // ---- 4. launch, level by level
+    size_t li = 0;
+    while (li < launches.size()) {
+        size_t lj = li;
+        uint32_t groups = 0;   // bit 0: main chain, bit 1 + i: aux stream i
+        while (lj < launches.size() && launches[lj].level == launches[li].level) {
+            const int a = aux_stream_of(launches[lj].fam);
+            groups |= a < 0 ? 1u : (2u << a);
+            ++lj;
         }
+        const bool fork = g->branch_streams && __builtin_popcount(groups) > 1;
+        if (fork) {
+            TD_HIP(hipEventRecord(g->ev_fork, g->stream));
+            for (int a = 0; a < td_graph::kAuxStreams; ++a)
+                if (groups & (2u << a)) TD_HIP(hipStreamWaitEvent(g->aux[a], g->ev_fork, 0));
+        }
+        for (size_t q = li; q < lj; ++q) {
+            const Launch& L = launches[q];
+            const void* d = g->darena + L.off;
+            const int a = aux_stream_of(L.fam);
+            hipStream_t s = (fork && a >= 0) ? g->aux[a] : g->stream;
+            Prof prof(g, L.fam, s);
+            switch (L.fam) {
+                case F_LOOP: launch_sample_loop((const LoopDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_MULTI: launch_sample_multi((const MultiDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_LERP: launch_sample_lerp((const LerpDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
+                case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
+                case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, s); break;
+                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
+                case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, (uint32_t)M, s); break;
+            }
+        }
+        if (fork) {
+            for (int a = 0; a < td_graph::kAuxStreams; ++a)
+                if (groups & (2u << a)) {
+                    TD_HIP(hipEventRecord(g->ev_join[a], g->aux[a]));
+                    TD_HIP(hipStreamWaitEvent(g->stream, g->ev_join[a], 0));
+                }
+        }
+        li = lj;
     }
     TD_HIP(hipGetLastError());
     g->state_dev_dirty = true;
@@ -1347,6 +1397,11 @@ void td_graph_free(td_graph* g) {
         for (auto& e : g->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto e : g->ev_free) (void)hipEventDestroy(e);
         (void)hipEventDestroy(g->arena_copied);
+        (void)hipEventDestroy(g->ev_fork);
+        for (int a = 0; a < td_graph::kAuxStreams; ++a) {
+            (void)hipEventDestroy(g->ev_join[a]);
+            (void)hipStreamDestroy(g->aux[a]);
+        }
         (void)hipStreamDestroy(g->stream);
     }
     delete g;
@@ -1677,6 +1732,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
+    if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }
     if (k == "max_chunk_frames") {
         if (value < 1) return fail("max_chunk_frames must be >= 1");
         g->max_chunk_frames = (size_t)value;

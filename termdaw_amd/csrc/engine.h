@@ -111,6 +111,10 @@ struct td_graph {
     // ---- device side ----
     int device = 0;
     hipStream_t stream = nullptr;
+    static constexpr int kAuxStreams = 7;      // one per independent launch family of a level (branch streams)
+    hipStream_t aux[kAuxStreams] = {};
+    hipEvent_t ev_fork = nullptr, ev_join[kAuxStreams] = {};
+    bool branch_streams = false;               // measured: cross-stream fork/join costs more than it overlaps
     bool plan_dirty = true;
     std::vector<size_t> order;                // reachable vertices, topological (inputs first)
     std::vector<int> level;                   // per vertex, -1 = unreachable
