@@ -55,23 +55,8 @@ static int ensure_device(int dev) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// sample load pipeline (sample.rs:38-77, 125-147, 252-313) -- load-time, host side
+// sample load pipeline (sample.rs:38-77, 125-147, 252-313) -- decisions on the host, data on the device
 // ------------------------------------------------------------------------------------------------
-static float absmax_of(const std::vector<float>& s) {   // sample.rs:8-14
-    float m = 0.0f;
-    for (float v : s) {
-        float a = fabsf(v);
-        if (a > m) m = a;
-    }
-    return m;
-}
-static float mean_energy(const std::vector<float>& s) {   // sample.rs:16-22
-    if (s.empty()) return 0.0f;
-    float sum = 0.0f;
-    for (float v : s) sum += fabsf(v);
-    return sum / (float)s.size();
-}
-
 enum LoadMethod { LM_STEREO, LM_LEFT, LM_RIGHT, LM_LOUDEST, LM_NORM, LM_MIX };
 static LoadMethod method_from(const char* s) {   // sample.rs:199-210
     std::string m = s ? s : "";
@@ -83,77 +68,124 @@ static LoadMethod method_from(const char* s) {   // sample.rs:199-210
     return LM_STEREO;
 }
 
-static int bank_add_decoded(td_samplebank* sb, const std::string& name, const std::vector<float>& linear,
-                            int channels, size_t sr, size_t bd, LoadMethod method) {
+// SampleBank::add after the WAV header is known (sample.rs:240-313).  The host only takes the decisions
+// that depend on counts (channel / length checks, Sample::from's Err arms); decode, de-interleave, load
+// mode, peak scan and normalisation run on the device.  Exactly one of `linear` (already decoded f32 stream)
+// and `raw` (little-endian PCM words) is given.
+static int bank_add_stream(td_samplebank* sb, const std::string& name, const float* linear, const uint8_t* raw,
+                           uint32_t raw_format, size_t n_values, int channels, size_t sr, size_t bd, LoadMethod method) {
     if (sb->names.count(name))
         return fail("TermDaw: SampleBank: there is already a sample with name \"" + name + "\" present.");
     if (method == LM_STEREO && channels != 2)
         return fail("TermDaw: SampleBank: only 2 channel samples are supported for stereo samples.");
     if (method != LM_STEREO && channels > 2)
         return fail("TermDaw: SampleBank: only 1,2 channel samples are supported for left or right samples.");
+    if (channels < 1) return fail("TermDaw: SampleBank: sample has no channels.");
+    if (n_values > 0xFFFFFFF0ull) return fail("termdaw_amd: sample too long");
     sb->max_sr = std::max(sb->max_sr, sr);
     sb->max_bd = std::max(sb->max_bd, bd);
-    std::vector<float> l, r;
+    // lengths of the de-interleaved l / r (sample.rs:275-292)
+    size_t nl, nr;
     if (channels == 1) {
-        (method == LM_LEFT ? l : r) = linear;
+        nl = method == LM_LEFT ? n_values : 0;
+        nr = method == LM_LEFT ? 0 : n_values;
     } else {
-        size_t half = linear.size() / 2;
-        l.resize(half);
-        r.resize(half);
-        for (size_t i = 0; i < half; ++i) {
-            l[i] = linear[2 * i];
-            r[i] = linear[2 * i + 1];
-        }
-        if (linear.size() > half * 2) l.push_back(linear.back());
+        nl = n_values / 2 + (n_values & 1);   // a dangling last value goes to l
+        nr = n_values / 2;
     }
-    // Sample::from
+    // Sample::from (sample.rs:38-77): which decoded channel feeds l and r; src 0/1 = channel index
+    uint32_t src_l = 0, src_r = channels == 2 ? 1u : 0u;
+    bool pick_loudest = false;
     switch (method) {
         case LM_LEFT:
-            if (l.empty()) return fail("TermDaw: Sample::from: l has length 0.");
-            r = l;
+            if (nl == 0) return fail("TermDaw: Sample::from: l has length 0.");
+            nr = nl;
+            src_r = src_l = 0;
             break;
         case LM_RIGHT:
-            if (r.empty()) return fail("TermDaw: Sample::from: r has length 0.");
-            l = r;
+            if (nr == 0) return fail("TermDaw: Sample::from: r has length 0.");
+            nl = nr;
+            src_l = src_r = channels == 2 ? 1u : 0u;
             break;
-        case LM_LOUDEST:
-            if (mean_energy(l) > mean_energy(r)) r = l; else l = r;
-            break;
+        case LM_LOUDEST: pick_loudest = true; break;
         default:
-            if (l.size() != r.size()) return fail("TermDaw: Sample::from: l and r do not have the same length.");
-            if (l.empty()) return fail("TermDaw: Sample::from: l and r have length 0.");
-    }
-    if (method == LM_NORM) {   // normalize_seperate
-        float sl = 1.0f / absmax_of(l), sr_ = 1.0f / absmax_of(r);
-        for (auto& v : l) v *= sl;
-        for (auto& v : r) v *= sr_;
-    } else if (method == LM_MIX) {   // mix_down
-        size_t n = std::min(l.size(), r.size());
-        std::vector<float> mix(n);
-        for (size_t i = 0; i < n; ++i) mix[i] = l[i] + r[i];
-        float sc = 1.0f / absmax_of(mix);
-        for (auto& v : mix) v *= sc;
-        l = mix;
-        r = mix;
-    } else {   // normalize(usize::MAX)
-        float sc = 1.0f / fmaxf(absmax_of(l), absmax_of(r));
-        for (auto& v : l) v *= sc;
-        for (auto& v : r) v *= sc;
+            if (nl != nr) return fail("TermDaw: Sample::from: l and r do not have the same length.");
+            if (nl == 0) return fail("TermDaw: Sample::from: l and r have length 0.");
     }
     if (sr != sb->sample_rate)
         return fail("termdaw_amd: sample \"" + name + "\" has sample rate " + std::to_string(sr) +
                     " != project rate; the reference resamples with the un-vendored rubato crate "
                     "(sample.rs:305-310) -- not supported (parity unpinned), author assets at the project rate");
-    if (l.size() != r.size()) return fail("termdaw_amd: channel lengths differ after load");
     if (!ensure_device(sb->device)) return 0;
-    size_t n = l.size();
-    std::vector<float2> inter(n + (n & 1));
-    for (size_t i = 0; i < n; ++i) inter[i] = make_float2(l[i], r[i]);
-    if (n & 1) inter[n] = make_float2(0.f, 0.f);
+    hipStream_t st = nullptr;   // load time: the default stream is fine
+    const size_t nmax = std::max(nl, nr);
+    float *d_lin = nullptr, *d_l = nullptr, *d_r = nullptr, *d_s = nullptr;
+    uint8_t* d_raw = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_lin); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_s); (void)hipFree(d_raw);
+    };
+    TD_HIP(hipMalloc(&d_lin, std::max<size_t>(n_values, 1) * sizeof(float)));
+    TD_HIP(hipMalloc(&d_l, std::max<size_t>(nmax, 1) * sizeof(float)));
+    TD_HIP(hipMalloc(&d_r, std::max<size_t>(nmax, 1) * sizeof(float)));
+    TD_HIP(hipMalloc(&d_s, 64));
+    if (linear) {
+        TD_HIP(hipMemcpyAsync(d_lin, linear, n_values * sizeof(float), hipMemcpyHostToDevice, st));
+    } else {
+        const size_t bps = raw_format == PCM_U8 ? 1 : raw_format == PCM_S16 ? 2 : raw_format == PCM_S24 ? 3 : 4;
+        TD_HIP(hipMalloc(&d_raw, std::max<size_t>(n_values * bps, 1)));
+        TD_HIP(hipMemcpyAsync(d_raw, raw, n_values * bps, hipMemcpyHostToDevice, st));
+        launch_pcm_decode(d_raw, d_lin, (uint32_t)n_values, raw_format, st);
+    }
+    if (pick_loudest) {
+        // Loudest (sample.rs:54-62): mean |l| > mean |r| ? l : r, with the means summed left to right in f32
+        if (channels == 1) {   // one of the two is empty: mean_energy(empty) = 0
+            launch_sample_split(d_lin, 1, 0, 0, d_l, d_r, (uint32_t)nl, (uint32_t)nr, st);
+        } else {
+            launch_sample_split(d_lin, 2, 0, 1, d_l, d_r, (uint32_t)nl, (uint32_t)nr, st);
+        }
+        launch_abs_sum_serial(d_l, (uint32_t)nl, d_s + 4, st);
+        launch_abs_sum_serial(d_r, (uint32_t)nr, d_s + 5, st);
+        float sums[2];
+        TD_HIP(hipMemcpyAsync(sums, d_s + 4, 8, hipMemcpyDeviceToHost, st));
+        TD_HIP(hipStreamSynchronize(st));
+        const float lm = nl ? sums[0] / (float)nl : 0.0f, rm = nr ? sums[1] / (float)nr : 0.0f;
+        const bool take_l = lm > rm;
+        const size_t n_take = take_l ? nl : nr;
+        if (n_take == 0) { cleanup(); return fail("termdaw_amd: loudest channel is empty"); }
+        // both outputs become the chosen channel
+        TD_HIP(hipMemcpyAsync(take_l ? d_r : d_l, take_l ? d_l : d_r, n_take * sizeof(float), hipMemcpyDeviceToDevice, st));
+        nl = nr = n_take;
+    } else {
+        launch_sample_split(d_lin, (uint32_t)channels, src_l, src_r, d_l, d_r, (uint32_t)nl, (uint32_t)nr, st);
+    }
+    size_t n = nl;
+    const float *p_max_l = d_s, *p_max_r = d_s + 1;
+    if (method == LM_NORM) {   // normalize_seperate (sample.rs:132-137)
+        launch_absmax(d_l, (uint32_t)nl, d_s, st);
+        launch_absmax(d_r, (uint32_t)nr, d_s + 1, st);
+    } else if (method == LM_MIX) {   // mix_down (sample.rs:139-147): zip stops at the shorter channel
+        n = std::min(nl, nr);
+        launch_add_planar(d_l, d_r, d_l, (uint32_t)n, st);
+        launch_absmax(d_l, (uint32_t)n, d_s, st);
+        TD_HIP(hipMemcpyAsync(d_r, d_l, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+        p_max_r = d_s;
+    } else {   // normalize(usize::MAX) (sample.rs:125-130): one common peak
+        launch_absmax(d_l, (uint32_t)nl, d_s, st);
+        launch_absmax(d_r, (uint32_t)nr, d_s + 1, st);
+        // max(absmax(l), absmax(r)): both are >= 0, so the uint pattern orders like the float
+        launch_absmax(d_s, 2, d_s + 2, st);
+        p_max_l = p_max_r = d_s + 2;
+    }
+    if (nl != nr && method != LM_MIX) { cleanup(); return fail("termdaw_amd: channel lengths differ after load"); }
+    if (n == 0) { cleanup(); return fail("TermDaw: Sample::from: l and r have length 0."); }
     SampleEntry e;
     e.len = n;
-    TD_HIP(hipMalloc(&e.d, inter.size() * sizeof(float2)));
-    TD_HIP(hipMemcpy(e.d, inter.data(), inter.size() * sizeof(float2), hipMemcpyHostToDevice));
+    TD_HIP(hipMalloc(&e.d, (n + (n & 1)) * sizeof(float2)));
+    TD_HIP(hipMemsetAsync(e.d + (n - 1 + (n & 1)), 0, sizeof(float2), st));   // pad frame of an odd length
+    launch_sample_pack(d_l, d_r, p_max_l, p_max_r, e.d, (uint32_t)n, st);
+    TD_HIP(hipStreamSynchronize(st));
+    TD_HIP(hipGetLastError());
+    cleanup();
     sb->samples.push_back(e);
     sb->names[name] = sb->samples.size() - 1;
     return 1;
@@ -1306,16 +1338,16 @@ void td_samplebank_free(td_samplebank* sb) {
 }
 int td_samplebank_add_decoded(td_samplebank* sb, const char* name, const float* linear, size_t n, int channels,
                               size_t sample_rate, size_t bits, const char* method) {
-    std::vector<float> v(linear, linear + n);
-    return bank_add_decoded(sb, name, v, channels, sample_rate, bits, method_from(method));
+    return bank_add_stream(sb, name, linear, nullptr, PCM_F32, n, channels, sample_rate, bits, method_from(method));
 }
 int td_samplebank_add_file(td_samplebank* sb, const char* name, const char* path, const char* method) {
     if (sb->names.count(name))
         return fail(std::string("TermDaw: SampleBank: there is already a sample with name \"") + name + "\" present.");
-    tdw::WavData w;
+    tdw::WavRaw w;
     std::string err;
-    if (!tdw::read_wav(path, &w, &err)) return fail(err);
-    return bank_add_decoded(sb, name, w.linear, w.channels, w.sample_rate, w.bits, method_from(method));
+    if (!tdw::read_wav_raw(path, &w, &err)) return fail(err);
+    const uint32_t fmt = w.is_float ? PCM_F32 : (w.bits == 8 ? PCM_U8 : w.bits == 16 ? PCM_S16 : w.bits == 24 ? PCM_S24 : PCM_S32);
+    return bank_add_stream(sb, name, nullptr, w.bytes.data(), fmt, w.n_values, w.channels, w.sample_rate, w.bits, method_from(method));
 }
 long td_samplebank_get_index(const td_samplebank* sb, const char* name) {
     auto it = sb->names.find(name);

@@ -211,6 +211,21 @@ struct BandSpecDesc {
     PanGain pg;
 };
 
+// ---- sample load pipeline (SampleBank::add, sample.rs:262-303) on the device ----
+// raw PCM words -> f32 exactly like hound + `as f32` (sample.rs:264-273): ints are NOT scaled.
+enum PcmFormat : uint32_t { PCM_F32 = 0, PCM_U8 = 1, PCM_S16 = 2, PCM_S24 = 3, PCM_S32 = 4 };
+void launch_pcm_decode(const uint8_t* raw, float* linear, uint32_t n_values, uint32_t format, hipStream_t s);
+// de-interleave by load mode into planar l / r (lengths nl, nr): src_l / src_r pick the source channel of
+// the interleaved stream (channel index, stride = channels), per Sample::from (sample.rs:38-77)
+void launch_sample_split(const float* linear, uint32_t channels, uint32_t src_l, uint32_t src_r, float* l, float* r,
+                         uint32_t nl, uint32_t nr, hipStream_t s);
+void launch_absmax(const float* v, uint32_t n, float* out, hipStream_t s);             // absmax (sample.rs:8-14)
+void launch_abs_sum_serial(const float* v, uint32_t n, float* out, hipStream_t s);     // mean_energy's f32 sum, in order
+void launch_add_planar(const float* a, const float* b, float* out, uint32_t n, hipStream_t s);   // mix_down sum
+// frames[i] = {l[i] * scale_l, r[i] * scale_r} with scale = 1.0f / *max (normalize / normalize_seperate / mix_down)
+void launch_sample_pack(const float* l, const float* r, const float* max_l, const float* max_r, float2* frames,
+                        uint32_t n, hipStream_t s);
+
 void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
@@ -224,6 +239,5 @@ void launch_debug_sine(const SineDesc* d, int n_desc, uint32_t frames, uint32_t 
 void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
-void launch_absmax(const float* peaks, uint32_t n, float* out, hipStream_t s);
 
 }  // namespace tdk

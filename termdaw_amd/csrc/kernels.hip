@@ -888,15 +888,72 @@ __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __re
     }
 }
 
-// single-float absolute max of a small table (per-project peak)
-__global__ __launch_bounds__(kThreads) void k_absmax(const float* __restrict__ v, uint32_t n, float* out) {
+// ------------------------------------------------------------------------------------------------
+// sample load pipeline (SampleBank::add, sample.rs:262-303)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_pcm_decode(const uint8_t* __restrict__ raw, float* __restrict__ out, uint32_t n,
+                                                         uint32_t format) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        float v;
+        switch (format) {
+            case PCM_U8: v = (float)((int)raw[i] - 128); break;
+            case PCM_S16: v = (float)(int16_t)((uint32_t)raw[2 * i] | ((uint32_t)raw[2 * i + 1] << 8)); break;
+            case PCM_S24: {
+                int32_t w = (int32_t)((uint32_t)raw[3 * i] | ((uint32_t)raw[3 * i + 1] << 8) | ((uint32_t)raw[3 * i + 2] << 16));
+                if (w & 0x800000) w |= ~0xFFFFFF;
+                v = (float)w;
+            } break;
+            case PCM_S32: v = (float)(int32_t)((uint32_t)raw[4 * i] | ((uint32_t)raw[4 * i + 1] << 8) | ((uint32_t)raw[4 * i + 2] << 16) |
+                                                ((uint32_t)raw[4 * i + 3] << 24)); break;
+            default: v = __uint_as_float((uint32_t)raw[4 * i] | ((uint32_t)raw[4 * i + 1] << 8) | ((uint32_t)raw[4 * i + 2] << 16) |
+                                         ((uint32_t)raw[4 * i + 3] << 24));
+        }
+        out[i] = v;
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_sample_split(const float* __restrict__ lin, uint32_t channels, uint32_t src_l,
+                                                           uint32_t src_r, float* __restrict__ l, float* __restrict__ r,
+                                                           uint32_t nl, uint32_t nr) {
+    const uint32_t n = max(nl, nr);
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        if (i < nl) l[i] = lin[(size_t)i * channels + src_l];
+        if (i < nr) r[i] = lin[(size_t)i * channels + src_r];
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_absmax_atomic(const float* __restrict__ v, uint32_t n, float* out) {
     float m = 0.0f;
-    for (uint32_t i = threadIdx.x; i < n; i += kThreads) m = fmaxf(m, fabsf(v[i]));
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+        const float a = fabsf(v[i]);
+        if (a > m) m = a;   // absmaxlen's fold: NaN never wins
+    }
     m = wave_max(m);
-    __shared__ float w[kThreads / 64];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) *out = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
+    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(m));
+}
+// mean_energy (sample.rs:16-22) sums |s| left to right in f32: the order is part of the result.  One
+// workgroup stages 4096 values at a time in LDS, lane 0 adds them in order.
+__global__ __launch_bounds__(kThreads) void k_abs_sum_serial(const float* __restrict__ v, uint32_t n, float* out) {
+    __shared__ float tile[4096];
+    float sum = 0.0f;
+    for (uint32_t base = 0; base < n; base += 4096) {
+        const uint32_t cnt = min(4096u, n - base);
+        for (uint32_t i = threadIdx.x; i < cnt; i += kThreads) tile[i] = fabsf(v[base + i]);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t i = 0; i < cnt; ++i) sum += tile[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sum;
+}
+__global__ __launch_bounds__(kThreads) void k_add_planar(const float* __restrict__ a, const float* __restrict__ b,
+                                                         float* __restrict__ o, uint32_t n) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) o[i] = a[i] + b[i];
+}
+__global__ __launch_bounds__(kThreads) void k_sample_pack(const float* __restrict__ l, const float* __restrict__ r,
+                                                          const float* max_l, const float* max_r, float2* __restrict__ frames,
+                                                          uint32_t n) {
+    const float sl = 1.0f / *max_l, sr = 1.0f / *max_r;   // `1.0 / max`, then multiply (sample.rs:127-129)
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        frames[i] = make_float2(l[i] * sl, r[i] * sr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -958,8 +1015,28 @@ void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t
     if (!n || !frames) return;
     hipLaunchKernelGGL(k_band_fill, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
 }
-void launch_absmax(const float* peaks, uint32_t n, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_absmax, dim3(1), dim3(kThreads), 0, s, peaks, n, out);
+static inline uint32_t grid_for(uint32_t n) { return max(1u, min((n + kThreads - 1) / kThreads, 2048u)); }
+void launch_absmax(const float* v, uint32_t n, float* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, sizeof(float), s);
+    if (n) hipLaunchKernelGGL(k_absmax_atomic, dim3(grid_for(n)), dim3(kThreads), 0, s, v, n, out);
+}
+void launch_pcm_decode(const uint8_t* raw, float* linear, uint32_t n, uint32_t format, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pcm_decode, dim3(grid_for(n)), dim3(kThreads), 0, s, raw, linear, n, format);
+}
+void launch_sample_split(const float* linear, uint32_t channels, uint32_t src_l, uint32_t src_r, float* l, float* r, uint32_t nl,
+                         uint32_t nr, hipStream_t s) {
+    const uint32_t n = nl > nr ? nl : nr;
+    if (n) hipLaunchKernelGGL(k_sample_split, dim3(grid_for(n)), dim3(kThreads), 0, s, linear, channels, src_l, src_r, l, r, nl, nr);
+}
+void launch_abs_sum_serial(const float* v, uint32_t n, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_abs_sum_serial, dim3(1), dim3(kThreads), 0, s, v, n, out);
+}
+void launch_add_planar(const float* a, const float* b, float* out, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_add_planar, dim3(grid_for(n)), dim3(kThreads), 0, s, a, b, out, n);
+}
+void launch_sample_pack(const float* l, const float* r, const float* max_l, const float* max_r, float2* frames, uint32_t n,
+                        hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_sample_pack, dim3(grid_for(n)), dim3(kThreads), 0, s, l, r, max_l, max_r, frames, n);
 }
 
 }  // namespace tdk

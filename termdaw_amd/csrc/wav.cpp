@@ -82,6 +82,61 @@ bool read_wav(const char* path, WavData* out, std::string* err) {
     return false;
 }
 
+bool read_wav_raw(const char* path, WavRaw* out, std::string* err) {
+    FILE* f = fopen(path, "rb");
+    if (!f) {
+        *err = std::string("TermDaw: SampleBank: could not open file \"") + path + "\".";
+        return false;
+    }
+    std::vector<uint8_t> buf;
+    uint8_t tmp[1 << 16];
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
+    fclose(f);
+    if (buf.size() < 12 || memcmp(buf.data(), "RIFF", 4) != 0 || memcmp(buf.data() + 8, "WAVE", 4) != 0) {
+        *err = std::string("TermDaw: SampleBank: \"") + path + "\" is not a RIFF/WAVE file.";
+        return false;
+    }
+    size_t pos = 12;
+    uint32_t fmt = 0, ch = 0, rate = 0, bits = 0;
+    bool have_fmt = false;
+    while (pos + 8 <= buf.size()) {
+        const uint32_t sz = rd32(&buf[pos + 4]);
+        const uint8_t* body = &buf[pos + 8];
+        if (memcmp(&buf[pos], "fmt ", 4) == 0 && pos + 8 + 16 <= buf.size()) {
+            fmt = rd16(body);
+            ch = rd16(body + 2);
+            rate = rd32(body + 4);
+            bits = rd16(body + 14);
+            if (fmt == 0xFFFE && sz >= 26 && pos + 8 + 26 <= buf.size()) fmt = rd16(body + 24);
+            have_fmt = true;
+        } else if (memcmp(&buf[pos], "data", 4) == 0) {
+            if (!have_fmt || ch == 0) {
+                *err = "TermDaw: SampleBank: malformed WAV (no fmt chunk).";
+                return false;
+            }
+            const bool ok = (fmt == 3 && bits == 32) || (fmt == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32));
+            if (!ok) {
+                *err = "TermDaw: SampleBank: unsupported WAV encoding.";
+                return false;
+            }
+            size_t end = pos + 8 + (size_t)sz;
+            if (end > buf.size()) end = buf.size();
+            const size_t bps = bits / 8;
+            out->n_values = (end - (pos + 8)) / bps;
+            out->bytes.assign(buf.begin() + (long)(pos + 8), buf.begin() + (long)(pos + 8 + out->n_values * bps));
+            out->channels = (int)ch;
+            out->sample_rate = rate;
+            out->bits = bits;
+            out->is_float = fmt == 3;
+            return true;
+        }
+        pos += 8 + (size_t)sz + (sz & 1);
+    }
+    *err = "TermDaw: SampleBank: WAV without data chunk.";
+    return false;
+}
+
 static void put16(std::vector<uint8_t>& b, uint32_t v) { b.push_back(v & 0xFF); b.push_back((v >> 8) & 0xFF); }
 static void put32(std::vector<uint8_t>& b, uint32_t v) { put16(b, v & 0xFFFF); put16(b, v >> 16); }
 

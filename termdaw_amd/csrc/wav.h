@@ -20,6 +20,17 @@ struct WavData {
 
 bool read_wav(const char* path, WavData* out, std::string* err);
 
+// Header parse only: the PCM words stay raw (little-endian, as in the file) for the device-side decode.
+struct WavRaw {
+    std::vector<uint8_t> bytes;   // data chunk, truncated to whole samples
+    size_t n_values = 0;          // bytes / bytes-per-sample
+    int channels = 0;
+    size_t sample_rate = 0;
+    size_t bits = 0;
+    bool is_float = false;
+};
+bool read_wav_raw(const char* path, WavRaw* out, std::string* err);
+
 // words: frames*channels integers, int16 (bits <= 16) or int32 (bits > 16) as State::render produces them
 // (write_16s / write_32s).  bits 8 -> unsigned 8-bit samples, 24 -> packed 3-byte samples.
 bool write_wav_int(const char* path, const void* words, size_t frames, int channels, size_t sample_rate, int bits,

@@ -1,0 +1,103 @@
+"""Device-side sample load pipeline (SampleBank::add, sample.rs:224-314) vs the oracle: every load mode, mono
+and stereo, odd lengths, all PCM encodings hound reads -- the bank entries must be bit-identical."""
+import struct
+
+import numpy as np
+import pytest
+
+from termdaw_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+MODES = ["", "left", "right", "loudest", "normalize-seperate", "mix-down"]
+
+
+def _same_bank_entry(a, b):
+    la, ra = a
+    lb, rb = b
+    assert la.shape == lb.shape and ra.shape == rb.shape
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32)) and np.array_equal(ra.view(np.uint32), rb.view(np.uint32))
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("channels,n", [(2, 20000), (2, 20001), (1, 7777), (2, 2), (2, 300001)])
+def test_add_decoded_modes(gpu_api, oracle, mode, channels, n):
+    vals = W.noise_int16(5 + n, (n + 1) // 2 + 1).reshape(-1)[:n].astype(np.float32)
+    if mode == "loudest":
+        vals[1::2] *= 0.5        # make the decision robust (still exercises the ordered f32 sum)
+    out = []
+    for be, exc in ((gpu_api, gpu_api.TermdawError), (oracle, ValueError)):
+        sb = be.SampleBank(48000)
+        try:
+            sb.add_decoded("s", vals, channels, 48000, 16, mode)
+            out.append(sb.get_sample(sb.get_index("s")))
+        except exc as e:
+            out.append(str(e))
+    if isinstance(out[1], str):
+        assert isinstance(out[0], str), "engine accepted what the oracle rejects: %s" % out[1]
+    else:
+        assert not isinstance(out[0], str), out[0]
+        _same_bank_entry(out[0], out[1])
+
+
+def _write_wav(path, data, channels, sr, bits, is_float=False):
+    fmt = 3 if is_float else 1
+    bps = bits // 8
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVE" + b"fmt " + struct.pack(
+        "<IHHIIHH", 16, fmt, channels, sr, sr * channels * bps, channels * bps, bits) + b"data" + struct.pack("<I", len(data))
+    open(path, "wb").write(hdr + data)
+
+
+@pytest.mark.parametrize("bits,is_float", [(8, False), (16, False), (24, False), (32, False), (32, True)])
+def test_add_file_encodings(gpu_api, oracle, tmp_path, bits, is_float):
+    n = 5000
+    rng = W.splitmix64(bits * 7 + is_float, n * 2)
+    if is_float:
+        data = ((rng % np.uint64(20001)).astype(np.float64) / 10000.0 - 1.0).astype("<f4").tobytes()
+    elif bits == 8:
+        data = (rng & np.uint64(0xFF)).astype(np.uint8).tobytes()
+    elif bits == 16:
+        data = ((rng & np.uint64(0xFFFF)).astype(np.int64) - 32768).astype("<i2").tobytes()
+    elif bits == 24:
+        v = (rng & np.uint64(0xFFFFFF)).astype(np.uint32)
+        data = b"".join(int(x).to_bytes(3, "little") for x in v)
+    else:
+        data = ((rng & np.uint64(0xFFFFFFFF)).astype(np.int64) - (1 << 31)).astype("<i4").tobytes()
+    path = str(tmp_path / ("a%d%s.wav" % (bits, "f" if is_float else "")))
+    _write_wav(path, data, 2, 48000, bits, is_float)
+    entries = []
+    for be in (gpu_api, oracle):
+        sb = be.SampleBank(48000)
+        sb.add("s", path, "")
+        entries.append(sb.get_sample(sb.get_index("s")))
+    _same_bank_entry(*entries)
+    peak = max(np.abs(entries[0][0]).max(), np.abs(entries[0][1]).max())
+    assert 0.9999 < peak <= 1.0     # x * (1.0 / max) need not round to exactly 1.0
+
+
+def test_silent_file_gives_nan_like_reference(gpu_api, oracle):
+    z = np.zeros(64, np.float32)
+    for be in (gpu_api, oracle):
+        sb = be.SampleBank(48000)
+        sb.add_decoded("z", z, 2, 48000, 16, "")
+        l, r = sb.get_sample(0)
+        assert np.isnan(l).all() and np.isnan(r).all()     # 0 * (1/0) (quirk noted at SURVEY a22)
+
+
+def test_state_renders_project_from_files(gpu_api, oracle, tmp_path):
+    """project.toml + project.lua + WAV / event files on disk -> td_state_* -> WAV on disk; the data chunk
+    must equal the oracle's render of the same project."""
+    p = W.drum_project(seconds=1.0)
+    lua = p.to_lua(str(tmp_path / "assets"))
+    (tmp_path / "project.toml").write_text('[project]\nname = "t"\n[settings]\nmain = "project.lua"\nbuffer_length = 1024\nproject_samplerate = 48000\n')
+    (tmp_path / "project.lua").write_text(lua + 'set_output_file("%s")\n' % str(tmp_path / "out.wav"))
+    s = gpu_api.State(open_dir=str(tmp_path))
+    assert s.refresh(), gpu_api.last_error()
+    s.scan_exact()
+    s.render()
+    raw = open(str(tmp_path / "out.wav"), "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and raw[36:40] == b"data"
+    ch, sr, bits = struct.unpack("<H", raw[22:24])[0], struct.unpack("<I", raw[24:28])[0], struct.unpack("<H", raw[34:36])[0]
+    assert (ch, sr, bits) == (2, 48000, 16)
+    got = np.frombuffer(raw[44:], "<i2").reshape(-1, 2)
+    want, _ = p.render(oracle, scan=True)
+    assert np.array_equal(got, want)
