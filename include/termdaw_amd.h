@@ -47,7 +47,9 @@ int td_set_device(int device);
 td_samplebank* td_samplebank_new(size_t sample_rate);                    /* SampleBank::new   sample.rs:213 */
 void td_samplebank_free(td_samplebank* sb);
 /* SampleBank::add sample.rs:224-314 (WAV decode -> load mode -> peak normalise -> upload to HBM).
- * method: "" (stereo) | "left" | "right" | "loudest" | "normalize-seperate" | "mix-down". */
+ * method: "" (stereo) | "left" | "right" | "loudest" | "normalize-seperate" | "mix-down".
+ * A file whose rate differs from the bank's is resampled (Sample::resample sample.rs:150-175) with this
+ * engine's own sinc resampler (rubato is un-vendored: parity unpinned, DESIGN.md "Resampler"). */
 int td_samplebank_add_file(td_samplebank* sb, const char* name, const char* path, const char* method);
 /* Same pipeline from an already decoded stream (what hound hands to sample.rs:262-274): `linear`
  * holds n interleaved values, integer PCM cast to f32 without scaling, or float PCM as is. */
@@ -119,6 +121,12 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
  * result stays in HBM.  bits in {8,16,24,32}: <= 16 -> int16 words, otherwise int32 words, exactly the
  * integers the reference hands to hound.  Returns the number of frames rendered (0 on failure). */
 size_t td_graph_render_all(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits);
+/* The `psr > render_sr` arm of State::render (state.rs:533-561): the same render followed by a down-sample
+ * of the whole timeline from psr to render_sr and the quantise.  The reference streams the un-vendored
+ * rubato resampler block by block; this engine uses its own documented sinc resampler with rubato's
+ * parameter set (DESIGN.md "Resampler") -- parity with the reference is unpinned.  Returns output frames. */
+size_t td_graph_render_all_resampled(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits,
+                                     size_t psr, size_t render_sr);
 /* Device-resident results of the last td_graph_render_all (valid until the next render on g). */
 const void* td_graph_output_pcm_device(const td_graph* g);    /* int16|int32 interleaved, frames*2 words */
 const float* td_graph_output_f32_device(const td_graph* g);   /* float2 per frame, un-quantised output vertex */

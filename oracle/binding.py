@@ -96,6 +96,7 @@ def lib():
     sig("orc_graph_render", i32, vp, vp, vp, fp, fp)
     sig("orc_graph_true_normalize_scan", None, vp, vp, vp, sz)
     sig("orc_state_render", sz, vp, vp, vp, sz, sz, vp, fp)
+    sig("orc_state_render_resampled", sz, vp, vp, vp, sz, sz, sz, sz, vp, fp)
     _lib = L
     return L
 
@@ -263,6 +264,15 @@ class Graph:
 
     def true_normalize_scan(self, sb, fb, chunks):
         lib().orc_graph_true_normalize_scan(self.h, sb.h, fb.h, chunks)
+
+    def render_all_resampled(self, sb, fb, cs, bd, psr, render_sr):
+        """State::render, psr > render_sr arm, with the build-defined resampler. Returns (pcm, f32)."""
+        n = lib().orc_state_render_resampled(self.h, sb.h, fb.h, cs, bd, psr, render_sr, None, None)
+        pcm = np.zeros((n, 2), np.int32 if bd > 16 else np.int16)
+        f = np.zeros((n, 2), np.float32)
+        lib().orc_state_render_resampled(self.h, sb.h, fb.h, cs, bd, psr, render_sr, pcm.ctypes.data_as(C.c_void_p),
+                                         f.ctypes.data_as(C.POINTER(C.c_float)))
+        return pcm, f
 
     def render_all(self, sb, fb, cs, bd=16, want_f32=True, want_pcm=True):
         """State::render loop (state.rs:562-575). Returns (pcm[frames,2] int16|int32, f32[frames,2])."""

@@ -18,10 +18,11 @@
 //     from source text and cross-checked only by hand-derived known answers
 //     and by an independent numpy twin (tests/np_twin.py).  Treat them as "parity unpinned vs a
 //     reference executable".
-//   * Not restated (arithmetic lives in un-vendored crates): rubato 0.15.0 resampling
-//     (sample.rs:150-175, state.rs:533-561), sampsyn 0.1.4 wavetable voice (extensions.rs:532-578),
-//     floww 0.1.10 MIDI reader (floww.rs:40-48), LV2 hosting (extensions.rs:580-590).
-//     Those entry points fail loudly here.
+//   * Arithmetic that lives in un-vendored crates cannot be restated: rubato 0.15.0 resampling
+//     (sample.rs:150-175, state.rs:533-561) is REPLACED by a build-defined sinc resampler with rubato's
+//     visible parameter set (see "Build-defined sinc resampler" below; parity unpinned by construction);
+//     the sampsyn 0.1.4 wavetable voice (extensions.rs:532-578), the floww 0.1.10 MIDI reader
+//     (floww.rs:40-48) and LV2 hosting (extensions.rs:580-590) fail loudly here.
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared (see oracle/Makefile).
 // Rust `as` casts are emulated (saturating, truncating, NaN->0); f32::max/min -> fmaxf/fminf;
@@ -288,6 +289,65 @@ bool sample_from(std::vector<float> l, std::vector<float> r, LoadMethod m, Sampl
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Build-defined sinc resampler -- stands in for rubato 0.15.0 (un-vendored), PARITY UNPINNED.
+// ---------------------------------------------------------------------------------------------
+// The reference resamples with rubato::SincFixedIn<f32> (sample.rs:150-175, state.rs:533-561); its
+// parameter set is visible (sinc_len 256, f_cutoff 0.95, Linear interpolation, oversampling 256,
+// BlackmanHarris2) but its arithmetic, delay and output length are not.  This engine defines its own
+// resampler with those parameters (specification: DESIGN.md "Resampler"); oracle and HIP kernel implement
+// the same specification and must agree bit for bit -- neither is claimed to match rubato.
+//   out[j] = sum_{k=0..255} in[i0 - 127 + k] * c_k,   x = j * from / to = i0 + frac   (zero outside the input)
+//   c_k    = T[p][k] * (1 - a) + T[p+1][k] * a,        p = floor(frac * 256), a = frac * 256 - p  (f32)
+//   T[p][k] = (f32)( fc * sinc(fc * d) * bh(u)^2 ),    d = k - 127 - p/256,  u = (d + 128) / 256,
+//             fc = 0.95 * min(1, to/from),  bh = 4-term Blackman-Harris;  table in f64, rounded once
+//   len_out = ceil(len * to / from); zero delay.
+const int kSincLen = 256, kSincOver = 256;
+void build_sinc_table(size_t from, size_t to, std::vector<float>* T) {
+    const double ratio = (double)to / (double)from;
+    const double fc = 0.95 * (ratio < 1.0 ? ratio : 1.0);
+    const double pi = 3.14159265358979323846;
+    T->resize((size_t)(kSincOver + 1) * kSincLen);
+    for (int p = 0; p <= kSincOver; ++p)
+        for (int k = 0; k < kSincLen; ++k) {
+            const double d = (double)k - 127.0 - (double)p / (double)kSincOver;
+            const double z = fc * d;
+            const double sinc = z == 0.0 ? 1.0 : sin(pi * z) / (pi * z);
+            const double u = (d + 128.0) / 256.0;
+            const double bh = 0.35875 - 0.48829 * cos(2.0 * pi * u) + 0.14128 * cos(4.0 * pi * u) - 0.01168 * cos(6.0 * pi * u);
+            (*T)[(size_t)p * kSincLen + k] = (float)(fc * sinc * bh * bh);
+        }
+}
+void resample_planar(const std::vector<float>& l, const std::vector<float>& r, size_t from, size_t to,
+                     std::vector<float>* ol, std::vector<float>* orr) {
+    std::vector<float> T;
+    build_sinc_table(from, to, &T);
+    const size_t len = l.size();
+    const size_t nout = (size_t)(((unsigned __int128)len * to + from - 1) / from);
+    ol->assign(nout, 0.0f);
+    orr->assign(nout, 0.0f);
+    for (size_t j = 0; j < nout; ++j) {
+        const unsigned __int128 num = (unsigned __int128)j * from;
+        const int64_t i0 = (int64_t)(num / to);
+        const uint64_t rem = (uint64_t)(num % to);
+        const uint64_t ph = rem * (uint64_t)kSincOver;
+        const size_t p = (size_t)(ph / to);
+        const float a = (float)(ph % to) / (float)to;
+        const float* t0 = &T[p * kSincLen];
+        const float* t1 = &T[(p + 1) * kSincLen];
+        float al = 0.0f, ar = 0.0f;
+        for (int k = 0; k < kSincLen; ++k) {
+            const int64_t idx = i0 - 127 + k;
+            if (idx < 0 || idx >= (int64_t)len) continue;
+            const float c = t0[k] * (1.0f - a) + t1[k] * a;
+            al += l[(size_t)idx] * c;
+            ar += r[(size_t)idx] * c;
+        }
+        (*ol)[j] = al;
+        (*orr)[j] = ar;
+    }
+}
+
 struct SampleBank {  // sample.rs:187-194
     size_t sample_rate;
     std::vector<Sample> samples;
@@ -329,10 +389,10 @@ struct SampleBank {  // sample.rs:187-194
         if (method == M_NORM) sample.normalize_seperate();           // sample.rs:297-303
         else if (method == M_MIX) sample.mix_down();
         else sample.normalize(SIZE_MAX);
-        if (sr != sample_rate) {  // sample.rs:305-310 -> rubato (un-vendored): not restated
-            *err = "oracle: sample rate differs from project rate; rubato resample is un-vendored "
-                   "and not restated (parity unpinned).";
-            return false;
+        if (sr != sample_rate) {  // sample.rs:305-310: Sample::resample -> build-defined resampler (parity unpinned)
+            Sample rs;
+            resample_planar(sample.l, sample.r, sr, sample_rate, &rs.l, &rs.r);
+            sample = rs;
         }
         samples.push_back(sample);  // sample.rs:311-312
         names[name] = samples.size() - 1;
@@ -1152,6 +1212,44 @@ size_t orc_state_render(void* g, void* sb, void* fb, size_t cs, size_t bd, void*
     }
     gr->set_time(0);
     return frames;
+}
+
+// State::render's `psr > render_sr` arm (state.rs:533-561) with the build-defined resampler applied to the
+// whole rendered timeline (the reference streams rubato block by block; parity unpinned).  Returns the
+// number of output frames; out_pcm / out_f32 may be NULL to query it.
+size_t orc_state_render_resampled(void* g, void* sb, void* fb, size_t cs, size_t bd, size_t psr, size_t render_sr,
+                                  void* out_pcm, float* out_f32) {
+    Graph* gr = (Graph*)g;
+    const size_t frames = cs * gr->max_buffer_len;
+    const size_t nout = (size_t)(((unsigned __int128)frames * render_sr + psr - 1) / psr);
+    if (!out_pcm && !out_f32) return nout;
+    std::vector<float> l(frames), r(frames);
+    size_t done = 0;
+    for (size_t c = 0; c < cs; ++c) {
+        const Sample* chunk = gr->render(*(SampleBank*)sb, *(FlowwBank*)fb);
+        if (!chunk) continue;
+        memcpy(&l[done], chunk->l.data(), chunk->len() * 4);
+        memcpy(&r[done], chunk->r.data(), chunk->len() * 4);
+        done += chunk->len();
+        ((FlowwBank*)fb)->set_time_to_next_block();
+    }
+    gr->set_time(0);
+    std::vector<float> ol, orr;
+    resample_planar(l, r, psr, render_sr, &ol, &orr);
+    const float amplitude = orc_amplitude(bd);
+    for (size_t i = 0; i < nout; ++i) {
+        if (out_pcm) {
+            if (bd > 16) {
+                ((int32_t*)out_pcm)[2 * i] = f32_as_i32(ol[i] * amplitude);
+                ((int32_t*)out_pcm)[2 * i + 1] = f32_as_i32(orr[i] * amplitude);
+            } else {
+                ((int16_t*)out_pcm)[2 * i] = f32_as_i16(ol[i] * amplitude);
+                ((int16_t*)out_pcm)[2 * i + 1] = f32_as_i16(orr[i] * amplitude);
+            }
+        }
+        if (out_f32) { out_f32[2 * i] = ol[i]; out_f32[2 * i + 1] = orr[i]; }
+    }
+    return nout;
 }
 
 }  // extern "C"

@@ -71,6 +71,7 @@ SIGNATURES = {
     "td_graph_render_block": (_i32, [_vp, _vp, _vp, _fp, _fp]),
     "td_graph_normalize_scan": (_i32, [_vp, _vp, _vp, _sz]),
     "td_graph_render_all": (_sz, [_vp, _vp, _vp, _sz, _i32]),
+    "td_graph_render_all_resampled": (_sz, [_vp, _vp, _vp, _sz, _i32, _sz, _sz]),
     "td_graph_output_pcm_device": (_vp, [_vp]),
     "td_graph_output_f32_device": (_vp, [_vp]),
     "td_graph_read_pcm": (_i32, [_vp, _vp, _sz]),
@@ -102,13 +103,29 @@ SIGNATURES = {
 }
 
 
+def build(force=False):
+    """hipcc build of the in-tree HIP library (termdaw_amd/Makefile); rebuilds when a source is newer."""
+    import glob
+    import subprocess
+    srcs = glob.glob(os.path.join(_HERE, "csrc", "*")) + [os.path.join(_HERE, "..", "include", "termdaw_amd.h"),
+                                                         os.path.join(_HERE, "Makefile")]
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-j8", "-s"])
+    return LIB_PATH
+
+
 def lib():
-    """Loads the HIP library. Raises if it has not been built (python __graft_entry__.py / make -C termdaw_amd)."""
+    """Loads the HIP library, building it first if the in-tree .so is missing or older than its sources.
+    There is no CPU fallback: if hipcc cannot build it, this raises."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise TermdawError("%s is missing: build it with `make -C termdaw_amd` (hipcc, gfx950); "
-                               "there is no CPU fallback" % LIB_PATH)
+        try:
+            build()
+        except Exception as e:   # noqa: BLE001
+            if not os.path.exists(LIB_PATH):
+                raise TermdawError("%s is missing and `make -C termdaw_amd` failed (%s); there is no CPU fallback"
+                                   % (LIB_PATH, e))
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
@@ -302,6 +319,18 @@ class Graph:
             f = np.zeros((frames, 2), np.float32)
             if frames:
                 _check(lib().td_graph_read_f32(self.h, f.ctypes.data_as(_fp), f.size))
+        return pcm, f
+
+    def render_all_resampled(self, sb, fb, cs, bd, psr, render_sr):
+        """State::render, psr > render_sr arm (build-defined resampler). Returns (pcm, f32)."""
+        n = lib().td_graph_render_all_resampled(self.h, sb.h, fb.h, cs, bd, psr, render_sr)
+        if cs and not n:
+            raise TermdawError(last_error())
+        pcm = np.zeros((n, 2), np.int32 if bd > 16 else np.int16)
+        f = np.zeros((n, 2), np.float32)
+        if n:
+            _check(lib().td_graph_read_pcm(self.h, pcm.ctypes.data_as(_vp), pcm.nbytes))
+            _check(lib().td_graph_read_f32(self.h, f.ctypes.data_as(_fp), f.size))
         return pcm, f
 
     # -- bench hooks --

@@ -68,6 +68,47 @@ static LoadMethod method_from(const char* s) {   // sample.rs:199-210
     return LM_STEREO;
 }
 
+// Build-defined sinc resampler (DESIGN.md "Resampler"): the reference calls rubato::SincFixedIn<f32> with
+// sinc_len 256, f_cutoff 0.95, Linear, oversampling 256, BlackmanHarris2 (sample.rs:152-158,
+// state.rs:534-540); rubato's arithmetic is un-vendored, so this is this engine's own specification with
+// that parameter set -- parity with the reference is unpinned, parity with oracle/ is bit-exact.
+static void build_sinc_table(size_t from, size_t to, std::vector<float>* T) {
+    const double ratio = (double)to / (double)from;
+    const double fc = 0.95 * (ratio < 1.0 ? ratio : 1.0);
+    const double pi = 3.14159265358979323846;
+    T->resize((size_t)(kSincOver + 1) * kSincLen);
+    for (int p = 0; p <= kSincOver; ++p)
+        for (int k = 0; k < kSincLen; ++k) {
+            const double d = (double)k - 127.0 - (double)p / (double)kSincOver;
+            const double z = fc * d;
+            const double sinc = z == 0.0 ? 1.0 : sin(pi * z) / (pi * z);
+            const double u = (d + 128.0) / 256.0;
+            const double bh = 0.35875 - 0.48829 * cos(2.0 * pi * u) + 0.14128 * cos(4.0 * pi * u) - 0.01168 * cos(6.0 * pi * u);
+            (*T)[(size_t)p * kSincLen + k] = (float)(fc * sinc * bh * bh);
+        }
+}
+// Resamples `len` frames at `in` (device) from rate `from` to rate `to` into a fresh device buffer.
+int resample_device(const float2* in, size_t len, size_t from, size_t to, float2** out, size_t* nout_p, hipStream_t st) {
+    if (from == 0 || to == 0) return fail("resample: sample rate 0");
+    const size_t nout = (size_t)(((unsigned __int128)len * to + from - 1) / from);
+    std::vector<float> T;
+    build_sinc_table(from, to, &T);
+    float* d_T = nullptr;
+    float2* d_out = nullptr;
+    TD_HIP(hipMalloc(&d_T, T.size() * sizeof(float)));
+    TD_HIP(hipMalloc(&d_out, (nout + (nout & 1) + 1) * sizeof(float2)));
+    TD_HIP(hipMemcpyAsync(d_T, T.data(), T.size() * sizeof(float), hipMemcpyHostToDevice, st));
+    TD_HIP(hipMemsetAsync(d_out + nout - (nout ? 1 : 0), 0, 2 * sizeof(float2), st));
+    ResampleDesc d{in, d_out, d_T, len, nout, from, to};
+    launch_resample(d, st);
+    TD_HIP(hipStreamSynchronize(st));
+    TD_HIP(hipGetLastError());
+    (void)hipFree(d_T);
+    *out = d_out;
+    *nout_p = nout;
+    return 1;
+}
+
 // SampleBank::add after the WAV header is known (sample.rs:240-313).  The host only takes the decisions
 // that depend on counts (channel / length checks, Sample::from's Err arms); decode, de-interleave, load
 // mode, peak scan and normalisation run on the device.  Exactly one of `linear` (already decoded f32 stream)
@@ -112,10 +153,6 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
             if (nl != nr) return fail("TermDaw: Sample::from: l and r do not have the same length.");
             if (nl == 0) return fail("TermDaw: Sample::from: l and r have length 0.");
     }
-    if (sr != sb->sample_rate)
-        return fail("termdaw_amd: sample \"" + name + "\" has sample rate " + std::to_string(sr) +
-                    " != project rate; the reference resamples with the un-vendored rubato crate "
-                    "(sample.rs:305-310) -- not supported (parity unpinned), author assets at the project rate");
     if (!ensure_device(sb->device)) return 0;
     hipStream_t st = nullptr;   // load time: the default stream is fine
     const size_t nmax = std::max(nl, nr);
@@ -186,6 +223,15 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     TD_HIP(hipStreamSynchronize(st));
     TD_HIP(hipGetLastError());
     cleanup();
+    if (sr != sb->sample_rate) {   // sample.rs:305-310: Sample::resample after the normalisation
+        float2* rs = nullptr;
+        size_t nout = 0;
+        if (!resample_device(e.d, e.len, sr, sb->sample_rate, &rs, &nout, st)) { (void)hipFree(e.d); return 0; }
+        (void)hipFree(e.d);
+        if (nout == 0) { (void)hipFree(rs); return fail("termdaw_amd: resampled sample is empty"); }
+        e.d = rs;
+        e.len = nout;
+    }
     sb->samples.push_back(e);
     sb->names[name] = sb->samples.size() - 1;
     return 1;
@@ -1425,6 +1471,7 @@ void td_graph_free(td_graph* g) {
         if (g->darena) (void)hipFree(g->darena);
         if (g->d_pcm) (void)hipFree(g->d_pcm);
         if (g->d_out_f32) (void)hipFree(g->d_out_f32);
+        if (g->d_resampled) (void)hipFree(g->d_resampled);
         if (g->d_scalar) (void)hipFree(g->d_scalar);
         for (auto& e : g->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
         for (auto e : g->ev_free) (void)hipEventDestroy(e);
@@ -1679,6 +1726,44 @@ size_t td_graph_render_all(td_graph* g, const td_samplebank* sb, td_flowwbank* f
     if (!n) return 0;
     if (!td_graph_sync(g)) return 0;
     return n;
+}
+// State::render's `psr > render_sr` arm (state.rs:533-561): render, then resample the whole timeline with
+// the build-defined resampler (the reference streams rubato block by block -- parity unpinned), quantise.
+size_t td_graph_render_all_resampled(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits,
+                                     size_t psr, size_t render_sr) {
+    if (!(bits == 8 || bits == 16 || bits == 24 || bits == 32)) {
+        fail("Bitdepth not supported: choose bitdepth in {8, 16, 24, 32}.");
+        return 0;
+    }
+    if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, false)) return 0;
+    if (!graph_set_time_impl(g, 0)) return 0;
+    const size_t total = n_blocks * g->bl;
+    float2* rs = nullptr;
+    size_t nout = 0;
+    if (!resample_device(g->last_out_f32, total, psr, render_sr, &rs, &nout, g->stream)) return 0;
+    if (g->d_resampled) (void)hipFree(g->d_resampled);
+    g->d_resampled = rs;
+    const int qmode = bits > 16 ? 2 : 1;
+    const size_t word = qmode == 1 ? 2 : 4;
+    const float amplitude = bits < 32 ? (float)((1 << (bits - 1)) - 1) : (float)INT32_MAX;
+    const size_t need = nout * 2 * word + 64;
+    if (need > g->pcm_cap) {
+        if (hipStreamSynchronize(g->stream) != hipSuccess) return 0;
+        if (g->d_pcm) { (void)hipFree(g->d_pcm); g->device_bytes -= g->pcm_cap; }
+        if (hipMalloc(&g->d_pcm, need) != hipSuccess) { fail("out of device memory"); return 0; }
+        g->pcm_cap = need;
+        g->device_bytes += need;
+    }
+    QuantDesc qd{rs, g->d_pcm, amplitude, (uint32_t)qmode};
+    if (hipMemcpyAsync(g->d_scalar + 8, &qd, sizeof qd, hipMemcpyHostToDevice, g->stream) != hipSuccess) return 0;
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return 0;   // qd lives on this stack frame
+    launch_quantise((const QuantDesc*)(g->d_scalar + 8), 1, (uint32_t)nout, g->stream);
+    if (hipStreamSynchronize(g->stream) != hipSuccess) return 0;
+    g->pcm_bytes = nout * 2 * word;
+    g->last_out_f32 = rs;
+    g->last_frames = nout;
+    g->last_bits = bits;
+    return nout;
 }
 const void* td_graph_output_pcm_device(const td_graph* g) { return g->d_pcm; }
 const float* td_graph_output_f32_device(const td_graph* g) { return (const float*)g->last_out_f32; }

@@ -144,6 +144,7 @@ struct td_graph {
     size_t last_frames = 0;
     int last_bits = 16;
     float* d_scalar = nullptr;
+    float2* d_resampled = nullptr;            // output of the last td_graph_render_all_resampled
     size_t device_bytes = 0;
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
@@ -159,6 +160,7 @@ struct td_graph {
 };
 
 namespace tde {
+int resample_device(const float2* in, size_t len, size_t from, size_t to, float2** out, size_t* nout, hipStream_t st);
 int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
                         int bits, bool advance_graph_time, size_t scan_t0, bool want_pcm);
 }

@@ -211,6 +211,16 @@ struct BandSpecDesc {
     PanGain pg;
 };
 
+// ---- build-defined sinc resampler (stands in for the un-vendored rubato crate; DESIGN.md "Resampler") ----
+constexpr int kSincLen = 256, kSincOver = 256;
+struct ResampleDesc {
+    const float2* in;
+    float2* out;
+    const float* table;   // [(kSincOver + 1) * kSincLen], built on the host in f64 and rounded once
+    uint64_t len, nout, from, to;
+};
+void launch_resample(const ResampleDesc& d, hipStream_t s);
+
 // ---- sample load pipeline (SampleBank::add, sample.rs:262-303) on the device ----
 // raw PCM words -> f32 exactly like hound + `as f32` (sample.rs:264-273): ints are NOT scaled.
 enum PcmFormat : uint32_t { PCM_F32 = 0, PCM_U8 = 1, PCM_S16 = 2, PCM_S24 = 3, PCM_S32 = 4 };

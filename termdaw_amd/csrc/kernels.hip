@@ -889,6 +889,33 @@ __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_resample: build-defined windowed-sinc resampler (specification in DESIGN.md "Resampler"; the oracle
+// implements the same arithmetic: taps in order k = 0..255, coefficient T0*(1-a) + T1*a, f32 accumulate)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_resample(ResampleDesc d) {
+    for (uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x; j < d.nout; j += (uint64_t)gridDim.x * kThreads) {
+        const uint64_t num = j * d.from;
+        const int64_t i0 = (int64_t)(num / d.to);
+        const uint64_t ph = (num % d.to) * (uint64_t)kSincOver;
+        const uint64_t p = ph / d.to;
+        const float a = (float)(ph % d.to) / (float)d.to;
+        const float* __restrict__ t0 = d.table + p * kSincLen;
+        const float* __restrict__ t1 = t0 + kSincLen;
+        const float one_minus_a = 1.0f - a;
+        float al = 0.0f, ar = 0.0f;
+        for (int k = 0; k < kSincLen; ++k) {
+            const int64_t idx = i0 - 127 + k;
+            if (idx < 0 || idx >= (int64_t)d.len) continue;
+            const float c = t0[k] * one_minus_a + t1[k] * a;
+            const float2 x = d.in[idx];
+            al += x.x * c;
+            ar += x.y * c;
+        }
+        d.out[j] = make_float2(al, ar);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // sample load pipeline (SampleBank::add, sample.rs:262-303)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_pcm_decode(const uint8_t* __restrict__ raw, float* __restrict__ out, uint32_t n,
@@ -1019,6 +1046,11 @@ static inline uint32_t grid_for(uint32_t n) { return max(1u, min((n + kThreads -
 void launch_absmax(const float* v, uint32_t n, float* out, hipStream_t s) {
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     if (n) hipLaunchKernelGGL(k_absmax_atomic, dim3(grid_for(n)), dim3(kThreads), 0, s, v, n, out);
+}
+void launch_resample(const ResampleDesc& d, hipStream_t s) {
+    if (!d.nout) return;
+    const uint64_t blocks = (d.nout + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k_resample, dim3((uint32_t)(blocks < 65535u * 16u ? blocks : 65535u * 16u)), dim3(kThreads), 0, s, d);
 }
 void launch_pcm_decode(const uint8_t* raw, float* linear, uint32_t n, uint32_t format, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_pcm_decode, dim3(grid_for(n)), dim3(kThreads), 0, s, raw, linear, n, format);

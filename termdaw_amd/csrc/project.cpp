@@ -114,6 +114,7 @@ struct td_state {
     std::vector<Triple> cur_samples;
     std::string dump;
     std::vector<uint8_t> host_pcm;
+    size_t out_frames = 0;
 };
 
 namespace {
@@ -513,17 +514,21 @@ static int state_render_device(td_state* s) {
     if (!s->loaded) return fail("State not loaded!");
     if (!(s->bd == 8 || s->bd == 16 || s->bd == 24 || s->bd == 32))
         return fail("Bitdepth of " + std::to_string(s->bd) + " not supported: choose bitdepth in {8, 16, 24, 32}.");
-    if (s->psr > s->render_sr)
-        return fail("render would down-sample from " + std::to_string(s->psr) + " to " + std::to_string(s->render_sr) +
-                    ": the reference does this with the un-vendored rubato crate (state.rs:533-561) -- not supported "
-                    "(parity unpinned); set_render_samplerate >= project_samplerate writes un-resampled frames like the reference");
     if (s->cs == 0) {
         s->host_pcm.clear();
+        s->out_frames = 0;
         return 1;
     }
-    if (!td_graph_render_all(s->g, s->sb, s->fb, s->cs, (int)s->bd)) return 0;
     const size_t word = s->bd > 16 ? 4 : 2;
-    s->host_pcm.resize(s->cs * s->bl * 2 * word);
+    size_t frames = s->cs * s->bl;
+    if (s->psr > s->render_sr) {   // state.rs:533-561 (build-defined resampler, parity unpinned)
+        frames = td_graph_render_all_resampled(s->g, s->sb, s->fb, s->cs, (int)s->bd, s->psr, s->render_sr);
+        if (!frames) return 0;
+    } else if (!td_graph_render_all(s->g, s->sb, s->fb, s->cs, (int)s->bd)) {
+        return 0;
+    }
+    s->out_frames = frames;
+    s->host_pcm.resize(frames * 2 * word);
     return td_graph_read_pcm(s->g, s->host_pcm.data(), s->host_pcm.size());
 }
 
@@ -531,14 +536,16 @@ int td_state_render(td_state* s, const char* path_override) {
     if (!state_render_device(s)) return 0;
     std::string err;
     const std::string path = path_override ? path_override : s->output_file;
-    if (!tdw::write_wav_int(path.c_str(), s->host_pcm.data(), s->cs * s->bl, 2, s->render_sr, (int)s->bd, &err)) return fail(err);
+    if (!tdw::write_wav_int(path.c_str(), s->host_pcm.data(), s->out_frames, 2, s->render_sr, (int)s->bd, &err)) return fail(err);
     return 1;
 }
 
 size_t td_state_render_to_memory(td_state* s, void* out, size_t bytes) {
     if (!out) {
         const size_t word = s->bd > 16 ? 4 : 2;
-        return s->cs * s->bl * 2 * word;
+        size_t frames = s->cs * s->bl;
+        if (s->psr > s->render_sr && s->psr) frames = (size_t)(((unsigned __int128)frames * s->render_sr + s->psr - 1) / s->psr);
+        return frames * 2 * word;
     }
     if (!state_render_device(s)) return 0;
     if (bytes < s->host_pcm.size()) {

@@ -1,0 +1,73 @@
+"""Build-defined sinc resampler (stands in for the un-vendored rubato crate -- parity with the reference is
+UNPINNED; these tests pin the HIP kernel to the oracle's implementation of the same specification and check
+the specification's own sanity)."""
+import numpy as np
+import pytest
+
+from termdaw_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+@pytest.mark.parametrize("file_sr", [44100, 96000, 22050, 47999])
+@pytest.mark.parametrize("mode", ["", "mix-down"])
+def test_load_time_resample_matches_oracle(gpu_api, oracle, file_sr, mode):
+    pcm = W.tone_int16(3, 3001).astype(np.float32).reshape(-1)
+    got = []
+    for be in (gpu_api, oracle):
+        sb = be.SampleBank(48000)
+        sb.add_decoded("s", pcm, 2, file_sr, 16, mode)
+        got.append(sb.get_sample(0))
+    assert got[0][0].shape == got[1][0].shape == ((3001 * 48000 + file_sr - 1) // file_sr,)
+    assert np.array_equal(_bits(got[0][0]), _bits(got[1][0])) and np.array_equal(_bits(got[0][1]), _bits(got[1][1]))
+
+
+def test_resampler_reproduces_a_sine(gpu_api):
+    n, sr = 44100, 44100
+    t = np.arange(n) / sr
+    x = np.stack([np.sin(2 * np.pi * 1000 * t), 0.5 * np.sin(2 * np.pi * 5000 * t)], axis=1)
+    sb = gpu_api.SampleBank(48000)
+    sb.add_decoded("s", np.round(x * 30000).astype(np.float32).reshape(-1), 2, sr, 16, "")
+    l, r = sb.get_sample(0)
+    assert l.shape == (48000,)
+    t2 = np.arange(48000) / 48000.0
+    core = slice(400, -400)
+    assert np.abs(l[core] - np.sin(2 * np.pi * 1000 * t2)[core]).max() < 2e-4
+    assert np.abs(r[core] - 0.5 * np.sin(2 * np.pi * 5000 * t2)[core]).max() < 2e-4
+
+
+def test_project_with_44k1_asset(gpu_api, oracle):
+    """sample_lerp over a 44.1 kHz asset in a 48 kHz project (BASELINE config 4's resample ingredient)."""
+    p = W.drum_project(seconds=1.0)
+    p.assets["kick"] = W.Asset(W.kick_int16(12, 13781), sr=44100)
+    g, o = p.render(gpu_api), p.render(oracle)
+    assert np.array_equal(g[0], o[0]) and np.array_equal(_bits(g[1]), _bits(o[1]))
+
+
+def test_render_time_downsample(gpu_api, oracle):
+    """psr 48000 > render_sr 44100 (the README example's settings, README.md:96)."""
+    p = W.config1(seconds=0.5)
+    gb, ob = p.build(gpu_api), p.build(oracle)
+    gp, gf = gb[2].render_all_resampled(gb[0], gb[1], p.cs, 16, 48000, 44100)
+    op, of = ob[2].render_all_resampled(ob[0], ob[1], p.cs, 16, 48000, 44100)
+    assert gp.shape == op.shape == ((p.cs * 1024 * 44100 + 47999) // 48000, 2)
+    assert np.array_equal(_bits(gf), _bits(of)) and np.array_equal(gp, op)
+    assert gb[2].get_time() == 0
+
+
+def test_state_render_downsampled_wav(gpu_api, tmp_path):
+    import struct
+    p = W.config1(seconds=0.25)
+    p.set_render_samplerate(44100)
+    lua = p.to_lua(str(tmp_path / "a"))
+    s = gpu_api.State("", 48000, 1024)
+    assert s.refresh(lua), gpu_api.last_error()
+    out = str(tmp_path / "o.wav")
+    s.render(out)
+    raw = open(out, "rb").read()
+    assert struct.unpack("<I", raw[24:28])[0] == 44100
+    assert (len(raw) - 44) // 4 == (p.cs * 1024 * 44100 + 47999) // 48000

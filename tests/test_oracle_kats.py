@@ -224,8 +224,9 @@ def test_sample_load_modes(oracle):   # sample.rs:38-77,125-147, quirk Q17
         sb.add_decoded("st", pcm.reshape(-1), 2, 48000, 16, "")        # duplicate name
     with pytest.raises(ValueError):
         sb.add_decoded("mono", pcm[:, 0], 1, 48000, 16, "")            # stereo mode needs 2 channels
-    with pytest.raises(ValueError):
-        sb.add_decoded("rs", pcm.reshape(-1), 2, 44100, 16, "")        # rubato path: not restated, fails loudly
+    sb.add_decoded("rs", pcm.reshape(-1), 2, 24000, 16, "")            # other rate: build-defined resampler (parity unpinned)
+    l, _ = sb.get_sample(sb.get_index("rs"))
+    assert l.shape == (6,)                                             # ceil(3 * 48000 / 24000)
 
 
 def test_graph_rules(oracle):   # graph.rs:58-174
