@@ -92,6 +92,12 @@ int td_graph_add_synth(td_graph* g, const char* name, float gain, float angle, s
                        float square_vel, float square_z, const float* square_adsr, int square_adsr_len,
                        float topflat_vel, float topflat_z, const float* topflat_adsr, int topflat_adsr_len,
                        float triangle_vel, const float* triangle_adsr, int triangle_adsr_len);
+/* add_sampsyn (state.rs:406-426, extensions.rs:143-150,532-578).  The wavetable oscillator and its file
+ * format live in the un-vendored sampsyn crate; this engine defines its own (DESIGN.md "Wavetable voice":
+ * "TDWT" u32 version=1, u32 n_frames, u32 frame_len, f32 table_seconds, n_frames*frame_len f32 LE) --
+ * parity with the reference is unpinned.  Unparseable / NULL bytes select the default table. */
+int td_graph_add_sampsyn(td_graph* g, const char* name, float gain, float angle, size_t floww_index, const float* adsr,
+                         int adsr_len, const void* table_bytes, size_t table_len);
 int td_graph_add_adsr(td_graph* g, const char* name, float gain, float angle, float wet, size_t floww_index,
                       int use_off, int use_max, int note, const float* adsr, int adsr_len);
 int td_graph_add_bandpass(td_graph* g, const char* name, float gain, float angle, float wet,

@@ -85,6 +85,8 @@ def lib():
     sig("orc_graph_add_debug_sine", None, vp, cp, f32, f32, sz)
     sig("orc_graph_add_synth", i32, vp, cp, f32, f32, sz, f32, f32, fp, i32, f32, f32, fp, i32, f32, fp, i32)
     sig("orc_graph_add_adsr", i32, vp, cp, f32, f32, f32, sz, i32, i32, i32, fp, i32)
+    sig("orc_graph_add_sampsyn", i32, vp, cp, f32, f32, sz, fp, i32, cp, sz)
+    sig("orc_wavetable_act", f32, cp, sz, f32, f32)
     sig("orc_graph_add_bandpass", None, vp, cp, f32, f32, f32, f32, f32, i32)
     sig("orc_graph_connect", i32, vp, cp, cp)
     sig("orc_graph_set_output", i32, vp, cp)
@@ -223,6 +225,13 @@ class Graph:
         a3, p3 = _fa(tr_adsr)
         if not lib().orc_graph_add_synth(self.h, name.encode(), gain, angle, floww_index, sq_vel, sq_z, p1,
                                          a1.size, tf_vel, tf_z, p2, a2.size, tr_vel, p3, a3.size):
+            raise ValueError(_err())
+
+    def add_sampsyn(self, name, gain, angle, floww_index, adsr, table_bytes):
+        a, p = _fa(adsr)
+        tb = bytes(table_bytes) if table_bytes is not None else None
+        if not lib().orc_graph_add_sampsyn(self.h, name.encode(), gain, angle, floww_index, p, a.size, tb,
+                                           len(tb) if tb else 0):
             raise ValueError(_err())
 
     def add_adsr(self, name, gain, angle, wet, floww_index, use_off, use_max, note, adsr):

@@ -21,8 +21,9 @@
 //   * Arithmetic that lives in un-vendored crates cannot be restated: rubato 0.15.0 resampling
 //     (sample.rs:150-175, state.rs:533-561) is REPLACED by a build-defined sinc resampler with rubato's
 //     visible parameter set (see "Build-defined sinc resampler" below; parity unpinned by construction);
-//     the sampsyn 0.1.4 wavetable voice (extensions.rs:532-578), the floww 0.1.10 MIDI reader
-//     (floww.rs:40-48) and LV2 hosting (extensions.rs:580-590) fail loudly here.
+//     the sampsyn 0.1.4 wavetable oscillator + table format (extensions.rs:532-578, state.rs:415-422) are
+//     REPLACED by build-defined ones (see "Build-defined wavetable voice"; parity unpinned by construction);
+//     the floww 0.1.10 MIDI reader (floww.rs:40-48) and LV2 hosting (extensions.rs:580-590) fail loudly.
 //
 // Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared (see oracle/Makefile).
 // Rust `as` casts are emulated (saturating, truncating, NaN->0); f32::max/min -> fmaxf/fminf;
@@ -546,7 +547,61 @@ struct FlowwBank {  // floww.rs:6-16
 // extensions.rs
 // ---------------------------------------------------------------------------------------------
 enum Kind { K_SUM, K_NORMALIZE, K_SAMPLE_LOOP, K_SAMPLE_MULTI, K_SAMPLE_LERP, K_DEBUG_SINE, K_SYNTH,
-            K_ADSR, K_BAND_PASS };
+            K_SAMPSYN, K_ADSR, K_BAND_PASS };
+
+// ---------------------------------------------------------------------------------------------
+// Build-defined wavetable voice -- stands in for the sampsyn 0.1.4 crate (un-vendored), PARITY UNPINNED.
+// ---------------------------------------------------------------------------------------------
+// The reference's SampSyn vertex (extensions.rs:532-578) calls sampsyn::wavetable_act_state(table, &mut
+// state, hz, t, sr) on a table parsed by sampsyn::parse_wavetable_from_buffer (state.rs:415-422).  Neither
+// the file format nor the oscillator are visible.  This engine defines both (DESIGN.md "Wavetable voice");
+// the voice bookkeeping around it (note on/off, envelope clocks, retain rule) follows the reference text.
+//   file:  "TDWT" u32 version=1, u32 n_frames, u32 frame_len, f32 table_seconds, n_frames*frame_len f32 (LE)
+//   voice: ph = frac(t * hz); sample position ph * frame_len, frame position min(t / table_seconds, 1) *
+//          (n_frames - 1); bilinear interpolation (within the frame with wrap-around, then across frames)
+struct WaveTable {
+    uint32_t n_frames = 1, frame_len = 2048;
+    float table_seconds = 1.0f;
+    std::vector<float> data;
+};
+WaveTable default_wavetable() {   // WaveTable::default() stand-in: one frame, one sine cycle
+    WaveTable t;
+    t.data.resize(2048);
+    for (int i = 0; i < 2048; ++i) t.data[i] = (float)sin(2.0 * 3.14159265358979323846 * (double)i / 2048.0);
+    return t;
+}
+bool parse_wavetable(const uint8_t* b, size_t n, WaveTable* out) {
+    if (n < 20 || memcmp(b, "TDWT", 4) != 0) return false;
+    uint32_t ver, nf, fl;
+    float secs;
+    memcpy(&ver, b + 4, 4); memcpy(&nf, b + 8, 4); memcpy(&fl, b + 12, 4); memcpy(&secs, b + 16, 4);
+    if (ver != 1 || nf == 0 || fl < 2 || (uint64_t)nf * fl > (1u << 26) || n < 20 + (size_t)nf * fl * 4) return false;
+    if (!(secs > 0.0f)) return false;
+    out->n_frames = nf; out->frame_len = fl; out->table_seconds = secs;
+    out->data.resize((size_t)nf * fl);
+    memcpy(out->data.data(), b + 20, (size_t)nf * fl * 4);
+    return true;
+}
+inline float wavetable_act(const WaveTable& w, float hz, float t) {
+    float ph = t * hz;
+    ph = ph - floorf(ph);
+    const float pos = ph * (float)w.frame_len;
+    uint32_t i0 = (uint32_t)f32_as_usize(pos);
+    if (i0 >= w.frame_len) i0 = w.frame_len - 1;
+    const float a = pos - (float)i0;
+    const uint32_t i1 = i0 + 1 == w.frame_len ? 0 : i0 + 1;
+    float fp = fminf(t / w.table_seconds, 1.0f) * (float)(w.n_frames - 1);
+    if (!(fp >= 0.0f)) fp = 0.0f;
+    uint32_t f0 = (uint32_t)f32_as_usize(fp);
+    if (f0 >= w.n_frames) f0 = w.n_frames - 1;
+    const float b = fp - (float)f0;
+    const uint32_t f1 = f0 + 1 < w.n_frames ? f0 + 1 : w.n_frames - 1;
+    const float* r0 = &w.data[(size_t)f0 * w.frame_len];
+    const float* r1 = &w.data[(size_t)f1 * w.frame_len];
+    const float s0 = lerp(r0[i0], r0[i1], a);
+    const float s1 = lerp(r1[i0], r1[i1], a);
+    return lerp(s0, s1, b);
+}
 
 struct SynthNote { float note, vel, env_t, rel_t; };
 struct SineNote { float note, vel; };
@@ -566,6 +621,8 @@ struct VertexExt {  // extensions.rs:15-80
     std::vector<SineNote> sine_notes;
     std::vector<SynthNote> notes;
     OscConf square, topflat, triangle;
+    // SampSyn (uses `notes` and `conf`)
+    WaveTable wave_table;
     // Adsr
     bool use_off = false, use_max = false;
     AdsrConf conf;
@@ -776,6 +833,51 @@ void synth_gen(Sample& buf, FlowwBank& fb, size_t len, VertexExt& e, size_t t, s
     e.notes.swap(kept);
 }
 
+void sampsyn_gen(Sample& buf, FlowwBank& fb, size_t len, VertexExt& e, size_t sr) {  // :532-578
+    const AdsrConf& adsr = e.conf;
+    float amp_multiplier = 1.0f / adsr.max_vel();
+    fb.start_block(e.floww_index);
+    for (size_t i = 0; i < len; ++i) {
+        for (auto& ev : fb.get_block_simple(e.floww_index, i)) {
+            if (ev.on) {
+                e.notes.push_back({ev.note, ev.vel, -((float)i / (float)sr), 0.0f});   // (+ initial_state: none here)
+            } else {
+                std::vector<SynthNote> kept;
+                for (auto& x : e.notes)
+                    if (fabsf(x.note - ev.note) > 0.001f || x.rel_t == 0.0f) kept.push_back(x);
+                e.notes.swap(kept);
+                for (auto& x : e.notes) {
+                    if (fabsf(x.note - ev.note) > 0.001f) continue;
+                    if (x.rel_t == 0.0f) {
+                        x.rel_t = x.env_t + ((float)i / (float)sr);
+                        x.env_t = -((float)i / (float)sr);
+                    } else {
+                        fprintf(stderr, "Synth: impossible release stage note\n");  // :552 panic
+                        abort();
+                    }
+                }
+            }
+        }
+        buf.l[i] = 0.0f;
+        buf.r[i] = 0.0f;
+        for (auto& x : e.notes) {
+            float env_time = x.env_t + ((float)i / (float)sr);
+            float hz = 440.0f * powf(2.0f, (x.note - 69.0f) / 12.0f);
+            float env = x.rel_t == 0.0f ? apply_ads(adsr, env_time) : apply_r_rt(adsr, env_time, x.rel_t);
+            float s = 0.0f;
+            float vel = x.vel * env * amp_multiplier;
+            s += wavetable_act(e.wave_table, hz, env_time + x.rel_t) * vel;   // build-defined oscillator
+            buf.l[i] += s;
+            buf.r[i] += s;
+        }
+    }
+    for (auto& x : e.notes) x.env_t += (float)len / (float)sr;
+    std::vector<SynthNote> kept;
+    for (auto& x : e.notes)
+        if (x.rel_t == 0.0f || x.env_t <= adsr.release_sec) kept.push_back(x);
+    e.notes.swap(kept);
+}
+
 void adsr_gen(Sample& buf, size_t len, FlowwBank& fb, float wet, VertexExt& e, size_t sr) {  // :593-651
     if (wet < 0.0001f) return;
     const AdsrConf& conf = e.conf;
@@ -881,6 +983,7 @@ void ext_generate(VertexExt& e, size_t t, size_t sr, size_t len, bool is_scan, c
         case K_SAMPLE_LERP: sample_lerp_gen(buf, sb, fb, len, e); break;
         case K_DEBUG_SINE: debug_sine_gen(buf, fb, len, e, t, sr); break;
         case K_SYNTH: synth_gen(buf, fb, len, e, t, sr); break;
+        case K_SAMPSYN: sampsyn_gen(buf, fb, len, e, sr); break;
         case K_ADSR: adsr_gen(buf, len, fb, wet, e, sr); break;
         case K_BAND_PASS: band_pass_gen(buf, len, wet, e); break;
     }
@@ -1137,6 +1240,20 @@ int orc_graph_add_synth(void* g, const char* name, float gain, float angle, size
     e.triangle.volume = tr_vel; e.triangle.param = 0.0f;                // state.rs:402
     g_add(g, name, gain, angle, 0.0f, e);
     return 1;
+}
+// add_sampsyn (state.rs:406-426): table = parse(resource bytes) or the default table (state.rs:415-422)
+int orc_graph_add_sampsyn(void* g, const char* name, float gain, float angle, size_t floww, const float* arr, int n,
+                          const uint8_t* table_bytes, size_t table_len) {
+    VertexExt e; e.kind = K_SAMPSYN; e.floww_index = floww;
+    if (!build_adsr_conf(arr, n, &e.conf)) { g_err = "ADSR config must have 6 or 9 elements"; return 0; }
+    if (!table_bytes || !parse_wavetable(table_bytes, table_len, &e.wave_table)) e.wave_table = default_wavetable();
+    g_add(g, name, gain, angle, 0.0f, e);
+    return 1;
+}
+float orc_wavetable_act(const uint8_t* table_bytes, size_t table_len, float hz, float t) {
+    WaveTable w;
+    if (!table_bytes || !parse_wavetable(table_bytes, table_len, &w)) w = default_wavetable();
+    return wavetable_act(w, hz, t);
 }
 int orc_graph_add_adsr(void* g, const char* name, float gain, float angle, float wet, size_t floww,
                        int use_off, int use_max, int note, const float* arr, int n) {

@@ -58,6 +58,7 @@ SIGNATURES = {
     "td_graph_add_debug_sine": (_i32, [_vp, _cp, _f32, _f32, _sz]),
     "td_graph_add_synth": (_i32, [_vp, _cp, _f32, _f32, _sz, _f32, _f32, _fp, _i32, _f32, _f32, _fp, _i32, _f32, _fp, _i32]),
     "td_graph_add_adsr": (_i32, [_vp, _cp, _f32, _f32, _f32, _sz, _i32, _i32, _i32, _fp, _i32]),
+    "td_graph_add_sampsyn": (_i32, [_vp, _cp, _f32, _f32, _sz, _fp, _i32, _cp, _sz]),
     "td_graph_add_bandpass": (_i32, [_vp, _cp, _f32, _f32, _f32, _f32, _f32, _i32]),
     "td_graph_connect": (_i32, [_vp, _cp, _cp]),
     "td_graph_set_output": (_i32, [_vp, _cp]),
@@ -257,6 +258,11 @@ class Graph:
         a3, p3 = _fa(tr_adsr)
         _check(lib().td_graph_add_synth(self.h, name.encode(), gain, angle, floww_index, sq_vel, sq_z, p1, a1.size,
                                         tf_vel, tf_z, p2, a2.size, tr_vel, p3, a3.size))
+
+    def add_sampsyn(self, name, gain, angle, floww_index, adsr, table_bytes):
+        a, p = _fa(adsr)
+        tb = bytes(table_bytes) if table_bytes is not None else None
+        _check(lib().td_graph_add_sampsyn(self.h, name.encode(), gain, angle, floww_index, p, a.size, tb, len(tb) if tb else 0))
 
     def add_adsr(self, name, gain, angle, wet, floww_index, use_off, use_max, note, adsr):
         a, p = _fa(adsr)

@@ -482,11 +482,13 @@ static float synth_release_sec(const Vertex& v) {   // extensions.rs:469-478
     if (v.triangle.volume > 0.0f) release_sec = fmaxf(release_sec, v.triangle.adsr.release_sec);
     return release_sec;
 }
+// Shared by Synth (extensions.rs:460-529) and SampSyn (extensions.rs:532-578): identical voice bookkeeping,
+// only the retain threshold differs (max release over enabled oscillators vs the single ADSR's release).
 static int compile_synth(Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl,
                          size_t sr, Staging& st, VTables& vt) {
     IntervalBuilder ib;
     ib.limit = (uint32_t)(cur.size() * bl);
-    const float release_sec = synth_release_sec(v);
+    const float release_sec = v.kind == K_SAMPSYN ? v.conf.release_sec : synth_release_sec(v);
     auto emit = [&](size_t m) {
         if (!ib.begin(m)) return;
         for (auto& n : v.notes) ib.push(note_hz(n.note), n.vel, n.env_t, n.rel_t);
@@ -709,9 +711,9 @@ static int ensure_arena(td_graph* g, size_t bytes) {
     return 1;
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SUM, F_SCALE, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
-                                           "k_synth",       "k_sum",          "k_scale",
+                                           "k_synth",       "k_sampsyn", "k_sum",          "k_scale",
                                            "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_quantise"};
 
 static hipEvent_t get_event(td_graph* g) {
@@ -756,6 +758,7 @@ static int aux_stream_of(int fam) {
         case F_LERP: return 2;
         case F_SINE: return 3;
         case F_SYNTH: return 4;
+        case F_SAMPSYN: return 4;
         case F_ADSR: return 5;
         case F_BAND: return 6;
         default: return -1;
@@ -826,6 +829,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 break;
             case K_DEBUG_SINE: compile_sine(v, fb, cur, bl, st, vt[vi]); break;
             case K_SYNTH:
+            case K_SAMPSYN:
                 if (!compile_synth(v, fb, cur, bl, sr, st, vt[vi])) return 0;
                 break;
             case K_ADSR:
@@ -885,6 +889,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case K_SAMPLE_LERP: fam_v[F_LERP].push_back(vi); break;
                 case K_DEBUG_SINE: fam_v[F_SINE].push_back(vi); break;
                 case K_SYNTH: fam_v[F_SYNTH].push_back(vi); break;
+                case K_SAMPSYN: fam_v[F_SAMPSYN].push_back(vi); break;
                 case K_SUM: fam_v[F_SUM].push_back(vi); break;
                 case K_NORMALIZE: fam_v[F_SUM].push_back(vi); fam_v[F_SCALE].push_back(vi); break;
                 case K_ADSR: fam_v[(v.wet < 0.0001f) ? F_SUM : F_ADSR].push_back(vi); break;
@@ -1019,6 +1024,29 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SynthDesc) + offsetof(SynthDesc, tab);
+                        ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
+                        ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                    }
+                } break;
+                case F_SAMPSYN: {
+                    std::vector<SampsynDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        SampsynDesc x{};
+                        x.tab.n_int = vt[vi].n_int;
+                        x.out = g->vbuf[vi];
+                        x.wt = v.wavetable;
+                        x.sr = (uint32_t)sr;
+                        x.bl = (uint32_t)bl;
+                        x.adsr = v.conf;
+                        x.amp_multiplier = 1.0f / adsr_max_vel(v.conf);   // extensions.rs:537
+                        x.pg = make_pg(v.gain, v.angle);
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(SampsynDesc) + offsetof(SampsynDesc, tab);
                         ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
                         ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
                         ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
@@ -1235,6 +1263,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_LERP: launch_sample_lerp((const LerpDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, s); break;
                 case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, s); break;
@@ -1466,6 +1495,7 @@ void td_graph_free(td_graph* g) {
     if (g->stream && hipSetDevice(g->device) == hipSuccess) {
         (void)hipStreamSynchronize(g->stream);
         for (float2* p : g->pool) (void)hipFree(p);
+        for (float* p : g->wavetables) (void)hipFree(p);
         if (g->dstate) (void)hipFree(g->dstate);
         if (g->harena) (void)hipHostFree(g->harena);
         if (g->darena) (void)hipFree(g->darena);
@@ -1486,6 +1516,11 @@ void td_graph_free(td_graph* g) {
     delete g;
 }
 void td_graph_reset(td_graph* g) {
+    if (!g->wavetables.empty() && g->stream && hipSetDevice(g->device) == hipSuccess) {
+        (void)hipStreamSynchronize(g->stream);
+        for (float* p : g->wavetables) (void)hipFree(p);
+    }
+    g->wavetables.clear();
     g->vertices.clear();
     g->edges.clear();
     g->name_map.clear();
@@ -1579,6 +1614,44 @@ int td_graph_add_synth(td_graph* g, const char* name, float gain, float angle, s
     v.square = {square_vel, fmaxf(square_z, 0.0001f), sq};   // state.rs:400
     v.topflat = {topflat_vel, topflat_z, tf};
     v.triangle = {triangle_vel, 0.0f, tr};
+    return 1;
+}
+// Wavetable resource of add_sampsyn: this engine's own format (the reference parses with the un-vendored
+// sampsyn crate, state.rs:415-422):  "TDWT" u32 version=1, u32 n_frames, u32 frame_len, f32 table_seconds,
+// then n_frames*frame_len f32 little-endian.  Anything else -> the default table (one sine cycle of 2048),
+// like the reference's "using default table!" arm.
+static bool parse_wavetable(const uint8_t* b, size_t n, uint32_t* nf, uint32_t* fl, float* secs, std::vector<float>* data) {
+    if (!b || n < 20 || memcmp(b, "TDWT", 4) != 0) return false;
+    uint32_t ver;
+    memcpy(&ver, b + 4, 4); memcpy(nf, b + 8, 4); memcpy(fl, b + 12, 4); memcpy(secs, b + 16, 4);
+    if (ver != 1 || *nf == 0 || *fl < 2 || (uint64_t)*nf * *fl > (1u << 26) || n < 20 + (size_t)*nf * *fl * 4) return false;
+    if (!(*secs > 0.0f)) return false;
+    data->resize((size_t)*nf * *fl);
+    memcpy(data->data(), b + 20, data->size() * 4);
+    return true;
+}
+int td_graph_add_sampsyn(td_graph* g, const char* name, float gain, float angle, size_t floww_index, const float* adsr,
+                         int adsr_len, const void* table_bytes, size_t table_len) {
+    AdsrConfD c;
+    if (!conf_from(adsr, adsr_len, &c)) return fail("ADSR config must have 6 or 9 elements");   // state.rs:410
+    uint32_t nf = 1, fl = 2048;
+    float secs = 1.0f;
+    std::vector<float> data;
+    if (!parse_wavetable((const uint8_t*)table_bytes, table_len, &nf, &fl, &secs, &data)) {
+        nf = 1; fl = 2048; secs = 1.0f;
+        data.resize(2048);
+        for (int i = 0; i < 2048; ++i) data[i] = (float)sin(2.0 * 3.14159265358979323846 * (double)i / 2048.0);
+    }
+    if (!ensure_device(g->device)) return 0;
+    float* d_t = nullptr;
+    TD_HIP(hipMalloc(&d_t, data.size() * sizeof(float)));
+    TD_HIP(hipMemcpy(d_t, data.data(), data.size() * sizeof(float), hipMemcpyHostToDevice));
+    g->wavetables.push_back(d_t);
+    g->device_bytes += data.size() * sizeof(float);
+    Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SAMPSYN);
+    v.floww_index = floww_index;
+    v.conf = c;
+    v.wavetable = WaveTableD{d_t, nf, fl, secs, 0u};
     return 1;
 }
 int td_graph_add_adsr(td_graph* g, const char* name, float gain, float angle, float wet, size_t floww_index,

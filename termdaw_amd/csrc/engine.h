@@ -52,7 +52,7 @@ struct td_flowwbank {
 namespace tde {
 
 enum Kind { K_SUM, K_NORMALIZE, K_SAMPLE_LOOP, K_SAMPLE_MULTI, K_SAMPLE_LERP, K_DEBUG_SINE, K_SYNTH,
-            K_ADSR, K_BAND_PASS, K_COUNT };
+            K_SAMPSYN, K_ADSR, K_BAND_PASS, K_COUNT };
 
 struct SineNote { float note, vel; };
 struct SynthNote { float note, vel, env_t, rel_t; };
@@ -71,6 +71,7 @@ struct Vertex {
     tdk::AdsrConfD conf{};
     bool use_off = false, use_max = false, pass = true;
     float lgamma = 0, hgamma = 0;
+    tdk::WaveTableD wavetable{};   // K_SAMPSYN: table in HBM (owned by the graph)
     // carried host state (what the reference keeps inside VertexExt, extensions.rs:15-80)
     uint64_t loop_t = 0;
     std::deque<std::pair<int64_t, float>> ts;
@@ -119,6 +120,7 @@ struct td_graph {
     std::vector<size_t> order;                // reachable vertices, topological (inputs first)
     std::vector<int> level;                   // per vertex, -1 = unreachable
     int n_levels = 0;
+    std::vector<float*> wavetables;            // device tables of K_SAMPSYN vertices
     std::vector<float2*> pool;                // every edge buffer ever allocated (cap_frames each)
     std::vector<float2*> free_bufs;
     size_t cap_frames = 0;

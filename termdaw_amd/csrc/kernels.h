@@ -155,6 +155,24 @@ struct SynthDesc {
     PanGain pg;
 };
 
+// sampsyn_gen (extensions.rs:532-578) with this engine's own wavetable oscillator (the sampsyn crate is
+// un-vendored; DESIGN.md "Wavetable voice"): voice = (hz, vel, env_t at block start, rel_t)
+struct WaveTableD {
+    const float* data;      // [n_frames][frame_len]
+    uint32_t n_frames, frame_len;
+    float table_seconds;
+    uint32_t pad;
+};
+struct SampsynDesc {
+    IntervalTab tab;
+    float2* out;
+    WaveTableD wt;
+    uint32_t sr, bl;
+    AdsrConfD adsr;
+    float amp_multiplier;
+    PanGain pg;
+};
+
 // adsr_gen (extensions.rs:593-651): two voice records per interval: primary, ghost = (t_off, vel,
 // release_val, skip) -- skip != 0 on the primary record marks a frame the reference leaves untouched
 // (the `continue` at extensions.rs:632-635).
@@ -247,6 +265,7 @@ void launch_sample_multi(const MultiDesc* d, int n_desc, uint32_t frames, hipStr
 void launch_sample_lerp(const LerpDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_debug_sine(const SineDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
 void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_sampsyn(const SampsynDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 

@@ -469,6 +469,59 @@ __global__ __launch_bounds__(kThreads) void k_synth(const SynthDesc* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sampsyn (extensions.rs:532-578; oscillator and table format are this engine's own, see kernels.h)
+// ------------------------------------------------------------------------------------------------
+TD_DEV float wavetable_act(const WaveTableD& w, float hz, float t) {
+    float ph = t * hz;
+    ph = ph - floorf(ph);
+    const float pos = ph * (float)w.frame_len;
+    uint32_t i0 = pos >= 0.0f ? (uint32_t)pos : 0u;   // NaN / negative -> 0, like Rust's `as usize`
+    if (i0 >= w.frame_len) i0 = w.frame_len - 1u;
+    const float a = pos - (float)i0;
+    const uint32_t i1 = i0 + 1u == w.frame_len ? 0u : i0 + 1u;
+    float fp = fminf(t / w.table_seconds, 1.0f) * (float)(w.n_frames - 1u);
+    if (!(fp >= 0.0f)) fp = 0.0f;
+    uint32_t f0 = (uint32_t)fp;
+    if (f0 >= w.n_frames) f0 = w.n_frames - 1u;
+    const float b = fp - (float)f0;
+    const uint32_t f1 = f0 + 1u < w.n_frames ? f0 + 1u : w.n_frames - 1u;
+    const float* __restrict__ r0 = w.data + (size_t)f0 * w.frame_len;
+    const float* __restrict__ r1 = w.data + (size_t)f1 * w.frame_len;
+    const float s0 = lerpf(r0[i0], r0[i1], a);
+    const float s1 = lerpf(r1[i0], r1[i1], a);
+    return lerpf(s0, s1, b);
+}
+TD_DEV float sampsyn_frame(const SampsynDesc& d, uint32_t m) {
+    const uint32_t it = find_interval(d.tab.istart, d.tab.n_int, m);
+    const uint32_t v0 = d.tab.ivoff[it], v1 = d.tab.ivoff[it + 1];
+    const float off = (float)(m % d.bl) / (float)d.sr;
+    float acc = 0.0f;
+    for (uint32_t v = v0; v < v1; ++v) {
+        const float4 n = d.tab.voices[v];   // (hz, vel, env_t, rel_t)
+        const float env_time = n.z + off;
+        const float env = n.w == 0.0f ? apply_ads(d.adsr, env_time) : apply_r_rt(d.adsr, env_time, n.w);
+        float s = 0.0f;
+        const float vel = n.y * env * d.amp_multiplier;
+        s += wavetable_act(d.wt, n.x, env_time + n.w) * vel;
+        acc += s;
+    }
+    return acc;
+}
+__global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restrict__ descs, uint32_t M) {
+    const SampsynDesc& d = descs[blockIdx.y];
+    const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
+    const uint32_t m1 = m0 + kTileFrames / 2;
+    if (m0 < M) {
+        float a = sampsyn_frame(d, m0), b = (m0 + 1 < M) ? sampsyn_frame(d, m0 + 1) : 0.0f;
+        store_pair(d.out, m0, M, epilogue4(make_float4(a, a, b, b), d.pg));
+    }
+    if (m1 < M) {
+        float a = sampsyn_frame(d, m1), b = (m1 + 1 < M) ? sampsyn_frame(d, m1 + 1) : 0.0f;
+        store_pair(d.out, m1, M, epilogue4(make_float4(a, a, b, b), d.pg));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_adsr: envelope-follower vertex (extensions.rs:593-651)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
@@ -1021,6 +1074,10 @@ void launch_debug_sine(const SineDesc* d, int n, uint32_t frames, uint32_t bl, h
 void launch_synth(const SynthDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
     hipLaunchKernelGGL(k_synth, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+}
+void launch_sampsyn(const SampsynDesc* d, int n, uint32_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    hipLaunchKernelGGL(k_sampsyn, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
 }
 void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;

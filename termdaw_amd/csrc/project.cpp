@@ -410,9 +410,20 @@ int do_refresh(td_state* s, const std::string& contents) {
                                 c.tf.data(), (int)c.tf.size(), c.tr_vel, c.tr.data(), (int)c.tr.size()))
             return 0;
     }
-    if (!sampsyns.empty())
-        return fail("add_sampsyn(\"" + sampsyns[0].name + "\"): the wavetable voice lives in the un-vendored sampsyn crate "
-                    "(extensions.rs:532-578, state.rs:415-422) -- not supported (parity unpinned)");
+    for (auto& c : sampsyns) {   // state.rs:406-426
+        if (!floww_index(c.floww, c.name, &fi)) return 0;
+        const std::string* path = nullptr;
+        for (auto& r : new_resources)
+            if (r.first == c.resource) path = &r.second;
+        if (!path) return fail("Could not find resource named " + c.resource + "!");   // state.rs:413 panics
+        std::ifstream rf(join_path(s->wdir, *path), std::ios::binary);
+        if (!rf) return fail("TermDaw: BufferBank: could not open file \"" + *path + "\".");   // bufferbank.rs:26-52
+        std::stringstream rs;
+        rs << rf.rdbuf();
+        const std::string bytes = rs.str();
+        if (!td_graph_add_sampsyn(s->g, c.name.c_str(), c.gain, c.angle, fi, c.adsr.data(), (int)c.adsr.size(), bytes.data(), bytes.size()))
+            return 0;
+    }
     // lv2fxs: the reference only builds them with the optional `lv2` cargo feature (state.rs:427-436,
     // Cargo.toml:9-11, off by default); without it the vertices do not exist and edges naming them fail.
     (void)lv2fxs;

@@ -77,6 +77,22 @@ def tone_int16(seed, frames, period=97):
     return np.clip(np.stack([l, r], axis=1), -32768, 32767).astype(np.int16)
 
 
+def wavetable_bytes(seed, n_frames=64, frame_len=2048, table_seconds=2.0):
+    """A wavetable resource in this engine's own format (the reference's lives in the un-vendored sampsyn
+    crate): "TDWT", u32 version 1, u32 n_frames, u32 frame_len, f32 table_seconds, then the f32 frames.
+    Frame f is a seeded additive mix whose upper harmonics fade in with f."""
+    rnd = (splitmix64(seed, 16).astype(np.float64) / 2.0 ** 64)
+    i = np.arange(frame_len, dtype=np.float64) / frame_len
+    frames = np.zeros((n_frames, frame_len), np.float64)
+    for f in range(n_frames):
+        w = f / max(n_frames - 1, 1)
+        for h in range(1, 9):
+            amp = (1.0 / h) * (1.0 if h == 1 else w ** (0.5 * h)) * (0.5 + rnd[h])
+            frames[f] += amp * np.sin(2 * np.pi * (h * i + rnd[8 + h - 1]))
+        frames[f] /= np.abs(frames[f]).max()
+    return b"TDWT" + struct.pack("<IIIf", 1, n_frames, frame_len, table_seconds) + frames.astype("<f4").tobytes()
+
+
 def write_wav_int16(path, pcm, sr):
     """Canonical 44-byte-header 16-bit PCM RIFF/WAVE (what hound writes for 16-bit int)."""
     pcm = np.ascontiguousarray(pcm, dtype="<i2")
@@ -117,9 +133,10 @@ class ProjectScript:
         self.assets = {}                    # path -> Asset
         self.event_files = {}               # path -> ndarray [n,3] (t_sec, note, vel)
         self.calls = {k: [] for k in (
-            "load_sample", "load_midi_floww", "add_sum", "add_normalize", "add_sampleloop",
-            "add_sample_multi", "add_sample_lerp", "add_debug_sine", "add_synth", "add_adsr",
+            "load_sample", "load_resource", "load_midi_floww", "add_sum", "add_normalize", "add_sampleloop",
+            "add_sample_multi", "add_sample_lerp", "add_debug_sine", "add_synth", "add_sampsyn", "add_adsr",
             "add_bandpass", "connect")}
+        self.resources = {}                 # path -> bytes (load_resource)
         self.script_order = []              # (fn, args) in call order, for to_lua()
 
     # -- settings --
@@ -154,6 +171,9 @@ class ProjectScript:
     def load_midi_floww(self, name, path):
         self._rec("load_midi_floww", name, path)
 
+    def load_resource(self, name, path):
+        self._rec("load_resource", name, path)
+
     # -- graph --
     def add_sum(self, name, gain, angle):
         self._rec("add_sum", name, gain, angle)
@@ -176,6 +196,9 @@ class ProjectScript:
     def add_synth(self, name, gain, angle, floww, sq_vel, sq_z, sq_adsr, tf_vel, tf_z, tf_adsr, tr_vel, tr_adsr):
         self._rec("add_synth", name, gain, angle, floww, sq_vel, sq_z, list(sq_adsr), tf_vel, tf_z,
                   list(tf_adsr), tr_vel, list(tr_adsr))
+
+    def add_sampsyn(self, name, gain, angle, floww, adsr, resource):
+        self._rec("add_sampsyn", name, gain, angle, floww, list(adsr), resource)
 
     def add_adsr(self, name, gain, angle, wet, floww, use_off, use_max, note, adsr):
         self._rec("add_adsr", name, gain, angle, wet, floww, use_off, use_max, note, list(adsr))
@@ -224,6 +247,11 @@ class ProjectScript:
             g.add_debug_sine(name, gain, angle, fidx(f, name))
         for name, gain, angle, f, sv, sz, sa, tv, tz, ta, rv, ra in self.calls["add_synth"]:
             g.add_synth(name, gain, angle, fidx(f, name), sv, sz, sa, tv, tz, ta, rv, ra)
+        res = dict(self.calls["load_resource"])
+        for name, gain, angle, f, conf, resource in self.calls["add_sampsyn"]:
+            if resource not in res:
+                raise KeyError("Could not find resource named %s!" % resource)
+            g.add_sampsyn(name, gain, angle, fidx(f, name), conf, self.resources[res[resource]])
         for name, gain, angle, wet, f, uo, um, note, conf in self.calls["add_adsr"]:
             g.add_adsr(name, gain, angle, wet, fidx(f, name), uo, um, note, conf)
         for name, gain, angle, wet, lo, hi, p in self.calls["add_bandpass"]:
@@ -259,6 +287,12 @@ class ProjectScript:
                     f.write("%s %s %s\n" % (float(t).hex(), float(n).hex(), float(v).hex()))
             paths[p] = out
 
+        for p, blob in self.resources.items():
+            out = os.path.join(asset_dir, p.replace("/", "_") + ".tdwt")
+            with open(out, "wb") as f:
+                f.write(blob)
+            paths[p] = out
+
         def lit(x):
             if isinstance(x, bool):
                 return "true" if x else "false"
@@ -272,7 +306,7 @@ class ProjectScript:
 
         lines = ["-- generated by termdaw_amd.workloads.ProjectScript.to_lua"]
         for fn, args in self.script_order:
-            if fn in ("load_sample", "load_midi_floww"):
+            if fn in ("load_sample", "load_midi_floww", "load_resource"):
                 args = (args[0], paths[args[1]]) + tuple(args[2:])
             lines.append("%s(%s);" % (fn, ", ".join(lit(a) for a in args)))
         return "\n".join(lines) + "\n"
@@ -447,14 +481,18 @@ def synth_project(seconds=3.0, bl=1024, voices=5):
 
 
 def config4(seconds=60.0, depth=252):
-    """Deep chain (BASELINE config 4 shape): synth + sample_lerp -> sum -> `depth` single-input vertices
-    alternating sum(gain 1.41, angle +-1) / bandpass(20 Hz, 18 kHz) / adsr -> normalize = depth + 4 vertices.
-    The reference config names a sampsyn wavetable voice and a 44.1 kHz asset; both sit on un-vendored
-    crates (sampsyn, rubato), so this build substitutes the in-tree synth voice and a 48 kHz asset."""
+    """Deep chain (BASELINE config 4): wavetable synth (sampsyn, 64 x 2048 table, seed 7) + sample_lerp over a
+    44.1 kHz asset (hits every 0.25 s, lerp_len 40) -> sum -> `depth` single-input vertices alternating
+    sum(gain 1.41, angle +-1) / bandpass(20 Hz, 18 kHz) / adsr -> normalize = depth + 4 vertices.
+    The wavetable oscillator and the 44.1 k -> 48 k resample sit on un-vendored crates (sampsyn, rubato) in
+    the reference; here they are this engine's own documented stand-ins (parity unpinned vs the reference,
+    bit-exact vs the oracle)."""
     p = ProjectScript(48000, 1024)
     p.set_length(seconds)
-    p.assets["kick"] = Asset(kick_int16(7, 20000))
+    p.assets["kick"] = Asset(kick_int16(7, 18375, sr=44100), sr=44100)
     p.load_sample("kick", "kick", "")
+    p.resources["table"] = wavetable_bytes(7)
+    p.load_resource("table", "table")
     hits = [(0.25 * i, 36.0, 0.9) for i in range(int(seconds / 0.25))]
     p.event_files["hits"] = np.array(hits, dtype=np.float32)
     notes = []
@@ -469,7 +507,7 @@ def config4(seconds=60.0, depth=252):
     p.event_files["notes"] = np.array(notes, dtype=np.float32)
     p.load_midi_floww("hits", "hits")
     p.load_midi_floww("notes", "notes")
-    p.add_synth("syn", 0.5, 0.0, "notes", 0.4, 0.3, HIT_ADSR, 1.0, 0.8, NOTE_ADSR, 0.5, NOTE_ADSR)
+    p.add_sampsyn("syn", 0.5, 0.0, "notes", STD_ADSR, "table")
     p.add_sample_lerp("lerp", 1.0, 0.0, "kick", "hits", -1, 40)
     p.add_sum("mix", 1.0, 0.0)
     p.connect("syn", "mix")

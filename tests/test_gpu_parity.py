@@ -252,10 +252,37 @@ def test_band_pass_parallel_chunked_state_carry(gpu_api, oracle):
 
 
 def test_config4_deep_chain_short(gpu_api, oracle):
-    """256-vertex chain (sum / band-pass 20 Hz..18 kHz / adsr alternating): synth at the head -> tolerance class."""
+    """256-vertex chain (sum / band-pass 20 Hz..18 kHz / adsr alternating) behind the wavetable voice and a
+    resampled 44.1 kHz asset: every operation is IEEE-only -> bit-exact vs the oracle."""
     p = W.config4(seconds=1.5)
     assert sum(len(p.calls[k]) for k in p.calls if k.startswith("add_")) == 256
-    assert_close(p.render(gpu_api), p.render(oracle), rms_tol=2e-6)
+    assert_bit_exact(p.render(gpu_api), p.render(oracle))
+
+
+def test_wavetable_voice(gpu_api, oracle):
+    """Build-defined wavetable voice (stand-in for the un-vendored sampsyn crate): voice bookkeeping per
+    extensions.rs:532-578, table lookups bilinear -- bit-exact HIP vs oracle, with and without a parsed table."""
+    for table in (W.wavetable_bytes(3, 5, 64, 0.3), b"garbage -> default table"):
+        p = W.synth_project(seconds=1.5)
+        p.resources["t"] = table
+        p.load_resource("t", "t")
+        p.add_sampsyn("wt", 0.7, 25.0, "notes", W.NOTE_ADSR, "t")
+        p.connect("wt", "mix")
+        for scan in (False, True):
+            assert_close(p.render(gpu_api, scan=scan), p.render(oracle, scan=scan))   # debug_sine/synth share the mix
+        q = W.ProjectScript(48000, 512)
+        q.set_length(1.0)
+        q.event_files["n"] = p.event_files["notes"]
+        q.load_midi_floww("n", "n")
+        q.resources["t"] = table
+        q.load_resource("t", "t")
+        q.add_sampsyn("wt", 0.7, 25.0, "n", W.STD_ADSR, "t")
+        q.add_normalize("out", 1.0, 0.0)
+        q.connect("wt", "out")
+        q.set_output("out")
+        gb, ob = q.build(gpu_api), q.build(oracle)
+        for _ in range(2):   # second render continues the voices: SampSyn notes are not cleared by set_time (Q4)
+            assert_bit_exact(q.render(gpu_api, built=gb), q.render(oracle, built=ob))
 
 
 @pytest.mark.parametrize("streams", [0, 1])

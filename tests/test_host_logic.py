@@ -134,7 +134,7 @@ def test_lua_subset_semantics(api):
     ("add_sum('a', 1, 0) set_output('nope')", "graph check failed"),
     ("add_sampleloop('l', 1, 0, 'missing') set_output('l')", "Could not get sample index"),
     ("add_debug_sine('l', 1, 0, 'missing') set_output('l')", "Could not get floww index"),
-    ("declare_stream('f') add_sampsyn('w', 1, 0, 'f', {}, 'tab') set_output('w')", "sampsyn"),
+    ("declare_stream('f') add_sampsyn('w', 1, 0, 'f', {}, 'tab') set_output('w')", "Could not find resource named tab"),
     ("load_midi_floww('f', '/nonexistent/x.mid')", "Could not read midi file"),
 ])
 def test_refresh_failures_are_reported(api, src, needle):
