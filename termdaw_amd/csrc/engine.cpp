@@ -770,8 +770,9 @@ static int aux_stream_of(int fam) {
 // k_band_fix verifies every segment bit for bit and repairs what failed.
 struct BandPlan {
     bool parallel = false;
-    uint32_t S = 0, W = 0, nseg = 0;
+    uint32_t S = 0, W = 0, Ws = 0, nseg = 0;
     float2* tmp = nullptr;
+    size_t blk_peaks_off = 0;
 };
 static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     BandPlan p;
@@ -784,8 +785,10 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     const double w = 150.0 / (double)gmin + 64.0;
     if (!(w <= 262144.0)) return p;   // cut-offs below ~5 Hz: the serial kernel is the better plan
     p.W = ((uint32_t)w + 31u) & ~31u;
+    p.Ws = std::min(p.W, ((uint32_t)(40.0 / (double)gmin + 64.0) + 31u) & ~31u);   // coalescence only
+    p.Ws = (p.Ws + 255u) & ~255u;                                                   // whole 256-frame liveness blocks
+    p.W = std::max(p.W, p.Ws);
     p.S = 256;
-    if (const char* sv = getenv("TD_BAND_S")) p.S = (uint32_t)atoi(sv);   // experiment knob
     while ((M + p.S - 1) / p.S > kBandMaxSegs && p.S < kBandMaxS) p.S *= 2;
     p.nseg = (uint32_t)((M + p.S - 1) / p.S);
     if (p.nseg > kBandMaxSegs) return p;
@@ -1062,7 +1065,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         const bool presum = band_plan.count(vi) != 0;
                         x.out = presum ? band_plan[vi].tmp : g->vbuf[vi];
                         x.k = (uint32_t)g->edges[vi].size();
-                        x.mode = v.kind == K_NORMALIZE ? 1u : 0u;
+                        x.mode = v.kind == K_NORMALIZE ? 1u : (presum ? 2u : 0u);
                         x.term_mode = term_mode[vi];
                         x.pg = presum ? PanGain{1.0f, 1.0f, 1.0f, 0u} : make_pg(v.gain, v.angle);
                         if (v.kind == K_NORMALIZE) {
@@ -1083,6 +1086,10 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                             scratch_field(o, offsetof(SumDesc, init_copy), ic);
                             if (peaks_need_zero) peaks_to_zero.push_back(pk);
                             g->vertices[vs[i]].has_init_override = false;
+                        } else if (band_plan.count(vs[i])) {
+                            const size_t bpk = scratch(((M + 255) / 256) * sizeof(float));
+                            band_plan[vs[i]].blk_peaks_off = bpk;
+                            scratch_field(o, offsetof(SumDesc, peaks), bpk);
                         }
                     }
                 } break;
@@ -1165,6 +1172,8 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         x.nseg = bp.nseg;
                         x.S = bp.S;
                         x.W = bp.W;
+                        x.Ws = bp.Ws;
+                        x.live_thr = 1e-6f;
                         x.pass = v.pass;
                         x.lgamma = v.lgamma;
                         x.hgamma = v.hgamma;
@@ -1180,6 +1189,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         scratch_field(o, offsetof(BandSpecDesc, seg_start), scratch((size_t)ns * 16));
                         scratch_field(o, offsetof(BandSpecDesc, seg_final), scratch((size_t)ns * 16));
                         scratch_field(o, offsetof(BandSpecDesc, seg_flags), scratch((size_t)ns * 4));
+                        scratch_field(o, offsetof(BandSpecDesc, blk_peaks), band_plan[vs[i]].blk_peaks_off);
                         scratch_field(o, offsetof(BandSpecDesc, seg_x0), scratch((size_t)ns * 8));
                         scratch_field(o, offsetof(BandSpecDesc, jobs), scratch((size_t)ns * sizeof(BandJob)));
                         const size_t so = scratch(16);

@@ -58,7 +58,8 @@ struct SumDesc {
     float init_max;            // used instead of state->max when use_init (reset_normalization, extensions.rs:295-299)
     uint32_t use_init;
     uint32_t k;
-    uint32_t mode;             // 0: Sum vertex (epilogue applied), 1: Normalize pass A (raw sum + peaks)
+    uint32_t mode;             // 0: Sum vertex (epilogue applied), 1: Normalize pass A (raw sum + peaks),
+                               // 2: band-pass input (raw sum + peak of every 256-frame block -> peaks)
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
     uint32_t pad;
     PanGain pg;
@@ -219,11 +220,14 @@ struct BandSpecDesc {
     BandState* state;       // carried across chunks
     float* seg_start;       // [nseg][4] state on entry (after warm-up)
     float* seg_final;       // [nseg][4] state on exit
+    const float* blk_peaks; // [ceil(frames / 256)] per 256-frame block: input peak, or -1 if bit-constant (k_sum mode 2)
     uint32_t* seg_flags;    // [nseg] bit0: input bit-identical over the whole segment, bit1: input all (+-)0
     float2* seg_x0;         // [nseg] first input frame of the segment
     BandJob* jobs;          // [nseg] parked stretches found by k_band_fix, executed by k_band_fill
     uint32_t* stats;        // [4]: mismatches found, segments recomputed, segments parked, jobs
     uint32_t nseg, S, W;
+    uint32_t Ws;            // short warm-up (k_band_spec picks W or Ws per segment from blk_peaks)
+    float live_thr;         // quietest / loudest block peak ratio above which a window counts as live (1e-6)
     uint32_t pass;
     float lgamma, hgamma;
     PanGain pg;

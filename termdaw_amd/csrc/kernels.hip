@@ -192,6 +192,40 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
     }
     store_pair(d.out, m0, M, a0);
     store_pair(d.out, m1, M, a1);
+    if (d.mode == 2) {
+        // Liveness of the tile's four 256-frame blocks (threads 0..127 / 128..255 x first / second frame pair):
+        // the block's absolute peak, or -1 when every frame of the block is bit-identical (a held constant
+        // parks the filter state just like silence does).
+        __shared__ float bp[kThreads / 64][2];
+        __shared__ uint32_t bc[kThreads / 64][2];
+        __shared__ float2 first[4];
+        if ((threadIdx.x & 127) == 0) {
+            first[(threadIdx.x >> 7)] = make_float2(a0.x, a0.y);        // blocks 0, 1
+            first[2 + (threadIdx.x >> 7)] = make_float2(a1.x, a1.y);    // blocks 2, 3
+        }
+        __syncthreads();
+        const float2 f0 = first[threadIdx.x >> 7], f1 = first[2 + (threadIdx.x >> 7)];
+        auto same2 = [](float4 a, float2 f) {
+            return __float_as_uint(a.x) == __float_as_uint(f.x) && __float_as_uint(a.y) == __float_as_uint(f.y) &&
+                   __float_as_uint(a.z) == __float_as_uint(f.x) && __float_as_uint(a.w) == __float_as_uint(f.y);
+        };
+        float p0 = m0 < M ? absmax4(0.0f, a0) : 0.0f, p1 = m1 < M ? absmax4(0.0f, a1) : 0.0f;
+        const bool c0 = __all((m0 + 1 >= M || same2(a0, f0)) ? 1 : 0) != 0, c1 = __all((m1 + 1 >= M || same2(a1, f1)) ? 1 : 0) != 0;
+        p0 = wave_max(p0);
+        p1 = wave_max(p1);
+        if ((threadIdx.x & 63) == 0) {
+            bp[threadIdx.x >> 6][0] = p0; bp[threadIdx.x >> 6][1] = p1;
+            bc[threadIdx.x >> 6][0] = c0; bc[threadIdx.x >> 6][1] = c1;
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) {
+            const uint32_t half = threadIdx.x & 1u, pair = threadIdx.x >> 1;   // block = pair * 2 + half
+            const uint32_t blk = blockIdx.x * 4u + pair * 2u + half;
+            const bool cst = bc[2 * half][pair] && bc[2 * half + 1][pair];
+            if (blk * 256u < M) d.peaks[blk] = cst ? -1.0f : fmaxf(bp[2 * half][pair], bp[2 * half + 1][pair]);
+        }
+        return;
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.init_copy[0] = d.use_init ? d.init_max : d.state->max;
         d.init_copy[1] = d.state->scan_max;
@@ -664,20 +698,20 @@ TD_DEV float2 band_out(const BandCoef& k, float l, float r, float ll, float lr, 
 __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __restrict__ descs, uint32_t M) {
     const BandSpecDesc& d = descs[blockIdx.y];
     const uint32_t c = threadIdx.x & 3u;                       // chain: 0 low L, 1 low R, 2 high L, 3 high R
-    const uint32_t seg = blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2);
-    if (seg >= d.nseg) return;                                 // whole quads leave together
+    const uint32_t seg_raw = blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2);
+    if (blockIdx.x * (kThreads / 4) >= d.nseg) return;         // whole workgroup beyond this vertex' segments
+    // quads past the last segment shadow it (cross-lane reductions below need every lane of the wave) and
+    // store nothing
+    const bool live = seg_raw < d.nseg;
+    const uint32_t seg = live ? seg_raw : d.nseg - 1u;
     const uint32_t ch = c & 1u;
     const float gam = (c & 2u) ? d.hgamma : d.lgamma;
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
     const float* __restrict__ xf = reinterpret_cast<const float*>(d.x);
     const uint32_t start = seg * d.S;
     const uint32_t end = min(start + d.S, M);
-    uint32_t n = start > d.W ? start - d.W : 0u;
     // exact state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
     const float y_true0 = d.state->first ? xf[ch] : reinterpret_cast<const float*>(d.state)[c];
-    float y;
-    if (n == 0u || gam == 0.0f) y = y_true0;                   // gamma 0: the chain never moves
-    else y = xf[2u * n + ch];                                  // guess; the warm-up forgets it
     // Input fetch: the four lanes of a quad load four consecutive 16-byte words (8 frames, 64 B) with ONE
     // instruction and hand them round with DPP quad broadcasts -- one vector-memory instruction per 8
     // steps instead of 8, which is what the address path of 16 independent streams per wave can sustain.
@@ -706,19 +740,50 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         y = y + gam * (e0_2 - y); y = y + gam * (e1_2 - y);                                        \
         y = y + gam * (e0_3 - y); y = y + gam * (e1_3 - y);                                        \
     }
+    // Warm-up length.  The long warm-up W covers a full-scale tail decaying to the denormal floor (needed when
+    // the segment sits in or after a silence or a held constant); when the whole short window Ws is live
+    // signal the state is driven by it and Ws (coalescence only) does.  A wrong pick only costs a repair in
+    // k_band_fix, never exactness.
+    uint32_t my_w = d.W;
+    if (d.Ws < d.W && start > d.Ws) {
+        // The short window is live when none of its 256-frame blocks is a held constant (-1) and their peaks
+        // stay within 120 dB of each other (the guess error scales with the loudest block, the state at the
+        // segment start with the quietest) and clear of the denormal range.  Block values come for free from
+        // the k_sum launch that materialised the input.
+        float lo = 3.0e38f, hi = 0.0f;
+        for (uint32_t b = (start - d.Ws) / 256u + c; b < start / 256u; b += 4u) {
+            const float v = d.blk_peaks[b];
+            lo = fminf(lo, v);
+            hi = fmaxf(hi, v);
+        }
+        lo = fminf(fminf(quad_bcast<0>(lo), quad_bcast<1>(lo)), fminf(quad_bcast<2>(lo), quad_bcast<3>(lo)));
+        hi = fmaxf(fmaxf(quad_bcast<0>(hi), quad_bcast<1>(hi)), fmaxf(quad_bcast<2>(hi), quad_bcast<3>(hi)));
+        if (lo >= 1e-30f && lo >= hi * d.live_thr) my_w = d.Ws;
+    }
+    const uint32_t my_begin = start > my_w ? start - my_w : 0u;
+    uint32_t wave_begin = my_begin;   // the wave walks from its earliest lane; later lanes (re)seed on arrival
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) wave_begin = min(wave_begin, (uint32_t)__shfl_xor((int)wave_begin, off, 64));
+    uint32_t n = wave_begin;
+    float y = y_true0;
+    auto seed = [&]() {   // at this lane's own warm-up start: exact state at frame 0, constant chain, or the guess
+        if (n == my_begin) y = (my_begin == 0u || gam == 0.0f) ? y_true0 : xf[2u * n + ch];
+    };
     if (n + 32u <= start && (n & 31u) == 0u) {
         float4 p0 = fetch8(n), p1 = fetch8(n + 8u), p2 = fetch8(n + 16u), p3 = fetch8(n + 24u);
         for (; n + 32u <= start; n += 32u) {
             const float4 q0 = fetch8(n + 32u), q1 = fetch8(n + 40u), q2 = fetch8(n + 48u), q3 = fetch8(n + 56u);
+            seed();
             TD_BAND_STEP8(p0) TD_BAND_STEP8(p1) TD_BAND_STEP8(p2) TD_BAND_STEP8(p3)
             p0 = q0; p1 = q1; p2 = q2; p3 = q3;
         }
     }
     if ((n & 7u) == 0u)
-        for (; n + 8u <= start; n += 8u) TD_BAND_STEP8(fetch8(n))
+        for (; n + 8u <= start; n += 8u) { seed(); TD_BAND_STEP8(fetch8(n)) }
 #undef TD_BAND_STEP8
-    for (; n < start; ++n) y = y + gam * (xf[2u * n + ch] - y);
-    d.seg_start[seg * 4u + c] = y;
+    for (; n < start; ++n) { seed(); y = y + gam * (xf[2u * n + ch] - y); }
+    seed();   // n == start == my_begin: segment 0 / no warm-up
+    if (live) d.seg_start[seg * 4u + c] = y;
     // the segment itself: recurrence + output
     const float x_first = xf[2u * start + ch];
     bool same = true, zero = true;
@@ -729,7 +794,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         zero = zero && (x == 0.0f);
         y = y + gam * (x - y);
         const float2 o = band_out(kf, l, r, quad_bcast<0>(y), quad_bcast<1>(y), quad_bcast<2>(y), quad_bcast<3>(y));
-        if (c == 0u) d.out[m] = epilogue(o, d.pg);
+        if (c == 0u && live) d.out[m] = epilogue(o, d.pg);
     };
     if ((start & 7u) == 0u) {
         float4 a = fetch8(start);
@@ -747,11 +812,11 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         for (n = start; n < end; ++n) { const float2 x = d.x[n]; step(n, x.x, x.y); }
     }
 #undef TD_BAND_UNPACK
-    d.seg_final[seg * 4u + c] = y;
+    if (live) d.seg_final[seg * 4u + c] = y;
     const float s0 = quad_bcast<0>(same ? 1.0f : 0.0f), s1 = quad_bcast<1>(same ? 1.0f : 0.0f);
     const float z0 = quad_bcast<0>(zero ? 1.0f : 0.0f), z1 = quad_bcast<1>(zero ? 1.0f : 0.0f);
     const float xr_first = quad_bcast<1>(x_first);
-    if (c == 0u) {
+    if (c == 0u && live) {
         d.seg_flags[seg] = ((s0 != 0.0f && s1 != 0.0f) ? 1u : 0u) | ((z0 != 0.0f && z1 != 0.0f) ? 2u : 0u);
         d.seg_x0[seg] = make_float2(x_first, xr_first);
     }
