@@ -12,6 +12,8 @@
 // wave-instruction.
 #include "kernels.h"
 
+#include <algorithm>
+
 namespace tdk {
 
 #define TD_DEV __device__ __forceinline__
@@ -1105,65 +1107,72 @@ __global__ __launch_bounds__(kThreads) void k_sample_pack(const float* __restric
 // launch wrappers
 // ------------------------------------------------------------------------------------------------
 static inline uint32_t tiles(uint32_t frames) { return (frames + kTileFrames - 1) / kTileFrames; }
+constexpr int kMaxGridY = 65535;
+
+// Batched launches put the vertex index in grid.y (limit 65535): larger batches go out in slices.
+#define TD_BATCHED(KERNEL, GRID_X, BLOCK, D, N, ...)                                                        \
+    for (int o_ = 0; o_ < (N); o_ += kMaxGridY)                                                             \
+        hipLaunchKernelGGL(KERNEL, dim3((GRID_X), std::min((N) - o_, kMaxGridY)), dim3(BLOCK), 0, s, (D) + o_, __VA_ARGS__)
 
 void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, hipStream_t s) {
     if (!n || !frames) return;
-    uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
-    hipLaunchKernelGGL(k_sum, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames, bl, tpb);
+    const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
+    TD_BATCHED(k_sum, tiles(frames), kThreads, d, n, frames, bl, tpb);
 }
 void launch_scale(const ScaleDesc* d, int n, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_scale, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames, bl, frames / bl, is_scan);
+    TD_BATCHED(k_scale, tiles(frames), kThreads, d, n, frames, bl, frames / bl, is_scan);
 }
 void launch_quantise(const QuantDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_quantise, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_quantise, tiles(frames), kThreads, d, n, frames);
 }
 void launch_sample_loop(const LoopDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_sample_loop, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_sample_loop, tiles(frames), kThreads, d, n, frames);
 }
 void launch_sample_multi(const MultiDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_sample_multi, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_sample_multi, tiles(frames), kThreads, d, n, frames);
 }
 void launch_sample_lerp(const LerpDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_sample_lerp, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_sample_lerp, tiles(frames), kThreads, d, n, frames);
 }
 void launch_debug_sine(const SineDesc* d, int n, uint32_t frames, uint32_t bl, hipStream_t s) {
     if (!n || !frames) return;
     (void)bl;
-    hipLaunchKernelGGL(k_debug_sine, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_debug_sine, tiles(frames), kThreads, d, n, frames);
 }
 void launch_synth(const SynthDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_synth, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_synth, tiles(frames), kThreads, d, n, frames);
 }
 void launch_sampsyn(const SampsynDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_sampsyn, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_sampsyn, tiles(frames), kThreads, d, n, frames);
 }
 void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_adsr, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_adsr, tiles(frames), kThreads, d, n, frames);
 }
-void launch_band_pass(const BandDesc* d, int n, uint32_t frames, hipStream_t s) {
+void launch_band_pass(const BandDesc* d, int n, uint32_t frames, hipStream_t s) {   // vertex index in grid.x
     if (!n || !frames) return;
     hipLaunchKernelGGL(k_band_pass, dim3(n), dim3(kThreads), 0, s, d, frames);
 }
 void launch_band_spec(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max_nseg, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_band_spec, dim3((max_nseg + kThreads / 4 - 1) / (kThreads / 4), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_band_spec, (max_nseg + kThreads / 4 - 1) / (kThreads / 4), kThreads, d, n, frames);
 }
-void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
+void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {    // vertex index in grid.x
     if (!n || !frames) return;
     hipLaunchKernelGGL(k_band_fix, dim3(n), dim3(kFixThreads), 0, s, d, frames);
 }
 void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    hipLaunchKernelGGL(k_band_fill, dim3(tiles(frames), n), dim3(kThreads), 0, s, d, frames);
+    TD_BATCHED(k_band_fill, tiles(frames), kThreads, d, n, frames);
 }
+#undef TD_BATCHED
 static inline uint32_t grid_for(uint32_t n) { return max(1u, min((n + kThreads - 1) / kThreads, 2048u)); }
 void launch_absmax(const float* v, uint32_t n, float* out, hipStream_t s) {
     (void)hipMemsetAsync(out, 0, sizeof(float), s);

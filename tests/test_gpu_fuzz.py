@@ -1,0 +1,138 @@
+"""Randomised parity: seeded random projects (random DAG over every bit-exact vertex kind, random events with
+same-frame collisions / note-offs / out-of-order-free but dense timing, random block lengths, gains and pans
+around the skip thresholds, duplicate edges, unreachable vertices) rendered by the HIP engine and by the oracle
+must agree bit for bit -- plain render, scanned render, and a second render that continues carried state."""
+import numpy as np
+import pytest
+
+from termdaw_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def random_project(seed, allow_sinf=False):
+    rng = np.random.default_rng(seed)
+    bl = int(rng.choice([64, 100, 256, 1000, 1024, 2048]))
+    p = W.ProjectScript(48000, bl)
+    p.set_length(float(rng.uniform(0.2, 1.2)))
+    n_samples = int(rng.integers(1, 4))
+    for i in range(n_samples):
+        n = int(rng.integers(50, 9000))
+        gen = [W.noise_int16, W.tone_int16, W.kick_int16][int(rng.integers(0, 3))]
+        sr = int(rng.choice([48000, 48000, 44100]))
+        p.assets["a%d" % i] = W.Asset(gen(int(rng.integers(1, 1000)), n), sr=sr)
+        p.load_sample("a%d" % i, "a%d" % i, str(rng.choice(["", "", "mix-down", "normalize-seperate", "left", "loudest"])))
+    n_flowws = int(rng.integers(1, 3))
+    for i in range(n_flowws):
+        ev = []
+        t = float(rng.uniform(0, 0.05))
+        while t < 1.3:
+            note = float(rng.integers(58, 63))
+            ev.append((t, note, float(rng.uniform(0.1, 1.0))))
+            if rng.random() < 0.3:
+                ev.append((t, float(rng.integers(58, 63)), float(rng.uniform(0.1, 1.0))))   # same-frame second hit
+            if rng.random() < 0.5:
+                ev.append((t + float(rng.uniform(0.001, 0.05)), note, 0.0))                  # note-off
+            t += float(rng.uniform(0.002, 0.2))
+        ev.sort(key=lambda e: e[0])
+        p.event_files["f%d" % i] = np.array(ev, np.float32)
+        p.load_midi_floww("f%d" % i, "f%d" % i)
+
+    def gain():
+        return float(rng.choice([1.0, 1.0005, 0.9985, 0.5, 1.7, 0.0, -0.8]))
+
+    def angle():
+        return float(rng.choice([0.0, 0.0009, -0.002, 30.0, -75.0, 90.0, 120.0]))
+
+    names = []
+    sources = ["loop", "multi", "lerp"] + (["sine", "synth"] if allow_sinf else []) + ["sampsyn"]
+    n_src = int(rng.integers(1, 5))
+    for i in range(n_src):
+        kind = str(rng.choice(sources))
+        nm = "s%d" % i
+        smp, fl = "a%d" % rng.integers(0, n_samples), "f%d" % rng.integers(0, n_flowws)
+        note = int(rng.choice([-1, -1, 60, 61]))
+        if kind == "loop":
+            p.add_sampleloop(nm, gain(), angle(), smp)
+        elif kind == "multi":
+            p.add_sample_multi(nm, gain(), angle(), smp, fl, note)
+        elif kind == "lerp":
+            p.add_sample_lerp(nm, gain(), angle(), smp, fl, note, int(rng.choice([0, 1, 40, 3000, -5])))
+        elif kind == "sine":
+            p.add_debug_sine(nm, gain(), angle(), fl)
+        elif kind == "synth":
+            p.add_synth(nm, gain(), angle(), fl, 0.4, 0.3, W.HIT_ADSR, 1.0, 0.8, W.NOTE_ADSR, float(rng.choice([0.0, 0.5])), W.STD_ADSR)
+        else:
+            if "wt" not in p.resources:
+                p.resources["wt"] = W.wavetable_bytes(int(rng.integers(1, 99)), 3, 128, 0.2)
+                p.load_resource("wt", "wt")
+            p.add_sampsyn(nm, gain(), angle(), fl, [W.NOTE_ADSR, W.STD_ADSR, []][int(rng.integers(0, 2))], "wt")
+        names.append(nm)
+    n_fx = int(rng.integers(1, 7))
+    fx = []
+    for i in range(n_fx):
+        kind = str(rng.choice(["sum", "norm", "adsr", "band"]))
+        nm = "x%d" % i
+        fl = "f%d" % rng.integers(0, n_flowws)
+        if kind == "sum":
+            p.add_sum(nm, gain(), angle())
+        elif kind == "norm":
+            p.add_normalize(nm, gain(), angle())
+        elif kind == "adsr":
+            conf = [W.NOTE_ADSR, [1.0, 0.01, 0.3, 0.2, 0.3, 0.0, 0.0, 0.05, 1.0], [0.0, 0.1, 0.5, 0.0, 0.2, 0.1]][int(rng.integers(0, 3))]
+            p.add_adsr(nm, gain(), angle(), float(rng.choice([1.0, 0.5, 0.0])), fl, bool(rng.integers(0, 2)), bool(rng.integers(0, 2)),
+                       int(rng.choice([-1, 60])), conf)
+        else:
+            p.add_bandpass(nm, gain(), angle(), float(rng.choice([1.0, 1.0, 0.0])), float(rng.choice([0.0, 30.0, 300.0, 2500.0])),
+                           float(rng.choice([0.0, 80.0, 5000.0, 19000.0, 30000.0])), bool(rng.integers(0, 2)))
+        # inputs: any earlier vertex (sources or earlier fx) -> acyclic by construction
+        pool = names + fx
+        for src in rng.choice(pool, size=int(rng.integers(1, min(4, len(pool)) + 1)), replace=True):   # duplicates allowed
+            p.connect(str(src), nm)
+        fx.append(nm)
+    p.connect(fx[-1], fx[0])    # a cycle attempt: rejected by both
+    p.connect(names[0], names[0])
+    out = fx[-1] if rng.random() < 0.9 else names[-1]
+    p.set_output(out)
+    return p
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_projects_bit_exact(gpu_api, oracle, seed):
+    p = random_project(seed)
+    try:
+        ob = p.build(oracle)
+    except (RuntimeError, KeyError):
+        with pytest.raises((gpu_api.TermdawError, RuntimeError, KeyError)):
+            p.build(gpu_api)
+        return
+    gb = p.build(gpu_api)
+    for scan in (False, True, False):    # plain, scanned, and a continuation render on the carried state
+        gp, gf = p.render(gpu_api, built=gb, scan=scan)
+        op, of = p.render(oracle, built=ob, scan=scan)
+        assert np.array_equal(np.isnan(gf), np.isnan(of))
+        bad = np.nonzero(_bits(gf) != _bits(of))[0]
+        assert bad.size == 0, "seed %d scan %s: first bad frame %d got %s want %s" % (seed, scan, bad[0], gf[bad[0]], of[bad[0]])
+        assert np.array_equal(gp, op)
+
+
+@pytest.mark.parametrize("seed", range(100, 112))
+def test_random_projects_with_sinf_close(gpu_api, oracle, seed):
+    p = random_project(seed, allow_sinf=True)
+    try:
+        ob = p.build(oracle)
+    except (RuntimeError, KeyError):
+        return
+    gb = p.build(gpu_api)
+    for scan in (False, True):
+        gp, gf = p.render(gpu_api, built=gb, scan=scan)
+        op, of = p.render(oracle, built=ob, scan=scan)
+        ok = np.isfinite(of)
+        assert np.array_equal(np.isfinite(gf), ok)
+        scale = max(1.0, float(np.abs(of[ok]).max()) if ok.any() else 1.0)
+        rms = float(np.sqrt(np.mean(((gf[ok].astype(np.float64) - of[ok].astype(np.float64)) / scale) ** 2))) if ok.any() else 0.0
+        assert rms <= 1e-6, "seed %d rms %g" % (seed, rms)
