@@ -25,7 +25,8 @@
 //     REPLACED by build-defined ones (see "Build-defined wavetable voice"; parity unpinned by construction);
 //     the floww 0.1.10 MIDI reader (floww.rs:40-48) and LV2 hosting (extensions.rs:580-590) fail loudly.
 //
-// Build: g++ -O2 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared (see oracle/Makefile).
+// Build: g++ -O3 -std=c++17 -ffp-contract=off -fno-fast-math -fPIC -shared (see oracle/Makefile) --
+// the optimisation level of a Rust release build, no fast-math, no FMA contraction.
 // Rust `as` casts are emulated (saturating, truncating, NaN->0); f32::max/min -> fmaxf/fminf;
 // f32::sin/cos/powf/floor/ceil -> glibc sinf/cosf/powf/floorf/ceilf (what Rust lowers to on
 // x86_64-unknown-linux-gnu).

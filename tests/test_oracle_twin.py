@@ -53,3 +53,73 @@ def _one_shot_project(kind, bl=1024):
 def test_one_shot_kinds_and_bandpass(oracle, kind):
     p = _one_shot_project(kind)
     _same(p.render(oracle), np_twin.render(p))
+
+
+# ---- event-driven float kinds: the twin's per-sample np.float32 loops vs the oracle, bit for bit ----
+def _events(seconds, dense=False):
+    ev = []
+    t, k = 0.004, 0
+    while t < seconds:
+        for j in range(3):
+            ev.append((t + 0.0007 * j, 57.0 + 4 * j, 0.3 + 0.1 * j))
+        ev.append((t + 0.03, 57.0, 0.6))                 # re-strike while held
+        ev.append((t + 0.03, 57.0, 0.0))                 # on + off on the same frame (quirk Q5 territory)
+        for j in range(3):
+            ev.append((t + 0.06 + 0.0011 * j, 57.0 + 4 * j, 0.0))
+        ev.append((t + 0.07, 99.0, 0.0))                 # off for a silent note
+        t += 0.05 if dense else 0.11
+        k += 1
+    ev.sort(key=lambda e: e[0])
+    return np.array(ev, np.float32)
+
+
+def _mono_out(project, oracle, name):
+    project.set_output(name)
+    _, f = project.render(oracle)
+    assert np.array_equal(f[:, 0].view(np.uint32), f[:, 1].view(np.uint32))
+    return f[:, 0]
+
+
+@pytest.mark.parametrize("bl", [64, 256])
+def test_debug_sine_and_synth_twin(oracle, bl):
+    p = W.ProjectScript(8000, bl)          # low rate keeps the python loops short; semantics are rate-free
+    p.set_length(0.35)
+    p.event_files["n"] = _events(0.35)
+    p.load_midi_floww("n", "n")
+    p.add_debug_sine("sine", 1.0, 0.0, "n")
+    p.add_synth("syn", 1.0, 0.0, "n", 0.4, 0.3, W.HIT_ADSR, 1.0, 0.8, W.NOTE_ADSR, 0.5, W.STD_ADSR)
+    p.add_synth("syn2", 1.0, 0.0, "n", 0.0, 0.00001, [], 0.7, 0.5, [0.0, 0.02, 1.0, 0.05, 0.4, 0.02, 0.4, 0.03, 0.1], 0.0, [])
+    N = p.cs * bl
+    got = _mono_out(p, oracle, "sine")
+    want = np_twin.debug_sine(p.event_files["n"], N, bl, 8000)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    conf = np_twin.adsr_conf
+    got = _mono_out(p, oracle, "syn")
+    want = np_twin.synth(p.event_files["n"], N, bl, 8000, (np.float32(0.4), np.float32(0.3), conf(W.HIT_ADSR)),
+                         (np.float32(1.0), np.float32(0.8), conf(W.NOTE_ADSR)), (np.float32(0.5), np.float32(0.0), conf(W.STD_ADSR)))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    got = _mono_out(p, oracle, "syn2")     # square off, z clamped to 1e-4 (state.rs:400), 9-float conf
+    want = np_twin.synth(p.event_files["n"], N, bl, 8000, (np.float32(0.0), np.float32(0.0001), conf([])),
+                         (np.float32(0.7), np.float32(0.5), conf([0.0, 0.02, 1.0, 0.05, 0.4, 0.02, 0.4, 0.03, 0.1])),
+                         (np.float32(0.0), np.float32(0.0), conf([])))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("use_off,use_max,note,wet", [(False, True, -1, 1.0), (False, False, 57, 0.6), (True, True, -1, 1.0),
+                                                       (True, False, 61, 0.35), (False, True, -1, 0.00005)])
+def test_adsr_vertex_twin(oracle, use_off, use_max, note, wet):
+    bl = 128
+    p = W.ProjectScript(8000, bl)
+    p.set_length(0.4)
+    p.event_files["n"] = _events(0.4, dense=True)
+    p.load_midi_floww("n", "n")
+    p.assets["c"] = W.Asset(np.full((16, 2), 1000, np.int16), sr=8000)     # constant 1.0 after load normalisation
+    p.load_sample("c", "c", "")
+    p.add_sampleloop("one", 1.0, 0.0, "c")
+    conf = [1.0, 0.01, 0.3, 0.02, 0.3, 0.0, 0.0, 0.05, 1.0] if not use_off else W.NOTE_ADSR
+    p.add_adsr("env", 1.0, 0.0, wet, "n", use_off, use_max, note, conf)
+    p.connect("one", "env")
+    got = _mono_out(p, oracle, "env")      # input is exactly 1.0 -> output is the applied multiplier
+    want = np_twin.adsr_vertex(np.ones(p.cs * bl, np.float32), p.event_files["n"], bl, 8000, wet, use_off, use_max, note,
+                               np_twin.adsr_conf(conf))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
