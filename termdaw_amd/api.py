@@ -12,6 +12,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libtermdaw_amd.so")
+_LIB_OVERRIDE = os.environ.get("TD_LIB")   # A/B experiments only (tools/ab_lib.py)
 
 
 class TermdawError(RuntimeError):
@@ -127,7 +128,7 @@ def lib():
             if not os.path.exists(LIB_PATH):
                 raise TermdawError("%s is missing and `make -C termdaw_amd` failed (%s); there is no CPU fallback"
                                    % (LIB_PATH, e))
-        L = C.CDLL(LIB_PATH)
+        L = C.CDLL(_LIB_OVERRIDE or LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype = res
