@@ -101,3 +101,20 @@ def test_state_renders_project_from_files(gpu_api, oracle, tmp_path):
     got = np.frombuffer(raw[44:], "<i2").reshape(-1, 2)
     want, _ = p.render(oracle, scan=True)
     assert np.array_equal(got, want)
+
+
+def test_headless_driver(gpu_api, oracle, tmp_path):
+    """python -m termdaw_amd <dir> --scan -o out.wav == refresh -> scan_exact -> render of the reference's TUI."""
+    import subprocess
+    import sys
+    p = W.config1(seconds=0.5)
+    lua = p.to_lua(str(tmp_path / "assets"))
+    (tmp_path / "project.toml").write_text('[settings]\nmain = "main.lua"\nproject_samplerate = 48000\n')
+    (tmp_path / "main.lua").write_text(lua)
+    out = str(tmp_path / "x.wav")
+    r = subprocess.run([sys.executable, "-m", "termdaw_amd", str(tmp_path), "--scan", "-o", out], capture_output=True, text=True,
+                       cwd=str(__import__("pathlib").Path(__file__).resolve().parents[1]))
+    assert r.returncode == 0, r.stderr + r.stdout
+    got = np.frombuffer(open(out, "rb").read()[44:], "<i2").reshape(-1, 2)
+    want, _ = p.render(oracle, scan=True)
+    assert np.array_equal(got, want)
