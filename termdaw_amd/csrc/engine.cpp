@@ -957,7 +957,9 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
                         const SampleEntry& s = sb->samples[v.sample_index];
-                        d.push_back({s.d, g->vbuf[vi], s.len, vt[vi].t0, make_pg(v.gain, v.angle)});
+                        const bool fits32 = s.len <= 0xFFFFFFFFull && vt[vi].t0 + M + kTileFrames <= 0xFFFFFFFFull;
+                        const uint32_t magic = fits32 ? (s.len >= 2 ? (uint32_t)(0x100000000ull / s.len) : 0xFFFFFFFFu) : 0u;
+                        d.push_back({s.d, g->vbuf[vi], s.len, vt[vi].t0, magic, {0, 0, 0}, make_pg(v.gain, v.angle)});
                     }
                     off = st.put(d);
                 } break;

@@ -93,6 +93,8 @@ struct LoopDesc {
     float2* out;
     uint64_t len;
     uint64_t t0;
+    uint32_t magic;   // floor(2^32 / len) when the 32-bit form applies (len, t0 + frames < 2^32), else 0
+    uint32_t pad[3];
     PanGain pg;
 };
 

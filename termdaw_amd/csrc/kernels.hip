@@ -31,15 +31,32 @@ TD_DEV float4 epilogue4(float4 v, const PanGain& pg) {
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
+// Every buffer pointer reaches a kernel through a descriptor in memory, so the compiler only knows it as a
+// generic ("flat") pointer and would emit flat_load / flat_store -- which count on both vmcnt and lgkmcnt
+// and force `s_waitcnt vmcnt(0) lgkmcnt(0)` before ANY use, i.e. no load can stay in flight across a use.
+// All of them are device-global: these helpers say so (address space 1 -> global_load / global_store with
+// counted vmcnt waits, so prefetched batches really overlap the arithmetic).
+#define TD_GLOBAL __attribute__((address_space(1)))
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+typedef int i2v __attribute__((ext_vector_type(2)));
+TD_DEV float4 gload4(const void* p) { const f4v v = *reinterpret_cast<const f4v TD_GLOBAL*>((const TD_GLOBAL char*)p); return make_float4(v.x, v.y, v.z, v.w); }
+TD_DEV float2 gload2(const void* p) { const f2v v = *reinterpret_cast<const f2v TD_GLOBAL*>((const TD_GLOBAL char*)p); return make_float2(v.x, v.y); }
+TD_DEV float gload1(const float* p) { return *reinterpret_cast<const float TD_GLOBAL*>((const TD_GLOBAL char*)p); }
+TD_DEV void gstore4(void* p, float4 v) { f4v w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; *reinterpret_cast<f4v TD_GLOBAL*>((TD_GLOBAL char*)p) = w; }
+TD_DEV void gstore2(void* p, float2 v) { f2v w; w.x = v.x; w.y = v.y; *reinterpret_cast<f2v TD_GLOBAL*>((TD_GLOBAL char*)p) = w; }
+
 // Two consecutive frames starting at frame m (m even).  Buffers are padded to an even frame count, so a
 // pair whose first frame is valid may always be accessed as one 16-byte word.
 TD_DEV float4 load_pair(const float2* p, uint32_t m, uint32_t M) {
-    if (m + 1 < M) return *reinterpret_cast<const float4*>(p + m);
-    if (m < M) { const float2 a = p[m]; return make_float4(a.x, a.y, 0.f, 0.f); }   // odd tail: pad reads as 0
+    if (m + 1 < M) return gload4(p + m);
+    if (m < M) { const float2 a = gload2(p + m); return make_float4(a.x, a.y, 0.f, 0.f); }   // odd tail: pad reads as 0
     return make_float4(0.f, 0.f, 0.f, 0.f);
 }
 TD_DEV void store_pair(float2* p, uint32_t m, uint32_t M, float4 v) {
-    if (m < M) *reinterpret_cast<float4*>(p + m) = v;
+    if (m < M) gstore4(p + m, v);
 }
 
 TD_DEV float wave_max(float v) {
@@ -69,13 +86,17 @@ TD_DEV void store_quant_pair(void* pcm, uint32_t qmode, uint32_t m, uint32_t M, 
         uint32_t w0 = ((uint32_t)quant16(v.x, amp) & 0xFFFFu) | ((uint32_t)quant16(v.y, amp) << 16);
         uint32_t w1 = ((uint32_t)quant16(v.z, amp) & 0xFFFFu) | ((uint32_t)quant16(v.w, amp) << 16);
         uint32_t* o = reinterpret_cast<uint32_t*>(pcm) + m;  // one 32-bit word per frame
-        if (m + 1 < M) *reinterpret_cast<uint2*>(o) = make_uint2(w0, w1);
-        else o[0] = w0;
+        if (m + 1 < M) { u2v w; w.x = w0; w.y = w1; *reinterpret_cast<u2v TD_GLOBAL*>((TD_GLOBAL char*)o) = w; }
+        else *reinterpret_cast<uint32_t TD_GLOBAL*>((TD_GLOBAL char*)o) = w0;
     } else {
         int32_t* o = reinterpret_cast<int32_t*>(pcm) + 2 * (size_t)m;
-        if (m + 1 < M) *reinterpret_cast<int4*>(o) = make_int4(quant32(v.x, amp), quant32(v.y, amp),
-                                                              quant32(v.z, amp), quant32(v.w, amp));
-        else *reinterpret_cast<int2*>(o) = make_int2(quant32(v.x, amp), quant32(v.y, amp));
+        if (m + 1 < M) {
+            i4v w; w.x = quant32(v.x, amp); w.y = quant32(v.y, amp); w.z = quant32(v.z, amp); w.w = quant32(v.w, amp);
+            *reinterpret_cast<i4v TD_GLOBAL*>((TD_GLOBAL char*)o) = w;
+        } else {
+            i2v w; w.x = quant32(v.x, amp); w.y = quant32(v.y, amp);
+            *reinterpret_cast<i2v TD_GLOBAL*>((TD_GLOBAL char*)o) = w;
+        }
     }
 }
 
@@ -83,10 +104,10 @@ TD_DEV float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y
 
 template <typename IDX>
 TD_DEV float4 loop_pair(const float2* s, IDX len, IDX idx) {
-    float2 a = s[idx];
+    float2 a = gload2(s + idx);
     IDX i1 = idx + 1;
     if (i1 == len) i1 = 0;
-    float2 b = s[i1];
+    float2 b = gload2(s + i1);
     return make_float4(a.x, a.y, b.x, b.y);
 }
 // x mod len for x < 2^32 with magic = floor(2^32 / len): q underestimates x / len by at most 1
@@ -99,15 +120,12 @@ TD_DEV uint32_t barrett_mod(uint32_t x, uint32_t len, uint32_t magic) {
 // for a whole tile of a given source), else two 8-byte loads.
 TD_DEV float4 loop_pair32(const float2* s, uint32_t len, uint32_t magic, uint32_t x) {
     const uint32_t idx = barrett_mod(x, len, magic);
-    if (((idx & 1u) == 0u) && idx + 1u < len) return *reinterpret_cast<const float4*>(s + idx);
+    if (((idx & 1u) == 0u) && idx + 1u < len) return gload4(s + idx);
     return loop_pair<uint32_t>(s, len, idx);
 }
 // stand-alone sample_loop vertex (k_sample_loop): wave-uniform choice of the 32-bit form
-TD_DEV float4 gather_loop_pair(const float2* s, uint64_t len64, uint64_t t0, uint32_t m, uint32_t M) {
-    if (len64 <= 0xFFFFFFFFull && t0 + M + kTileFrames <= 0xFFFFFFFFull) {
-        const uint32_t len = (uint32_t)len64;
-        return loop_pair<uint32_t>(s, len, ((uint32_t)t0 + m) % len);
-    }
+TD_DEV float4 gather_loop_pair(const float2* s, uint64_t len64, uint64_t t0, uint32_t magic, uint32_t m) {
+    if (magic) return loop_pair32(s, (uint32_t)len64, magic, (uint32_t)t0 + m);
     return loop_pair<uint64_t>(s, len64, (t0 + m) % len64);
 }
 
@@ -117,31 +135,59 @@ TD_DEV float4 zero_tail(float4 v, uint32_t m, uint32_t M) {   // frames at or be
     return v;
 }
 
-// value of one input term for the frame pair starting at m (generic form)
-TD_DEV float4 term_pair(const InTerm& t, uint32_t m, uint32_t M) {
-    if (t.kind == 0) return load_pair(t.p, m, M);
-    float4 v = t.kind == 1 ? loop_pair32(t.p, (uint32_t)t.len, t.magic, (uint32_t)t.t0 + m)
-                           : loop_pair<uint64_t>(t.p, t.len, (t.t0 + m) % t.len);
-    return zero_tail(epilogue4(v, t.pg), m, M);
+// The term table of a vertex is read-only for the whole launch and indexed uniformly: reading it through
+// the constant address space turns every field access into a scalar load (s_load) instead of a per-lane
+// flat load.
+#define TD_CONST __attribute__((address_space(4)))
+typedef const InTerm TD_CONST* TermTab;
+TD_DEV TermTab term_tab(const InTerm* p) { return (TermTab)(const TD_CONST char*)p; }
+TD_DEV PanGain term_pg(TermTab t, uint32_t j) {
+    PanGain pg;
+    pg.l_amp = t[j].pg.l_amp; pg.r_amp = t[j].pg.r_amp; pg.gain = t[j].pg.gain; pg.flags = t[j].pg.flags;
+    return pg;
 }
-TD_DEV float4 loop_term_pair(const InTerm& t, uint32_t m, uint32_t M) {
-    return zero_tail(epilogue4(loop_pair32(t.p, (uint32_t)t.len, t.magic, (uint32_t)t.t0 + m), t.pg), m, M);
+// value of one input term for the frame pair starting at m (generic form)
+TD_DEV float4 term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
+    const float2* p = t[j].p;
+    const uint32_t kind = t[j].kind;
+    if (kind == 0) return load_pair(p, m, M);
+    const uint64_t len = t[j].len, t0 = t[j].t0;
+    float4 v = kind == 1 ? loop_pair32(p, (uint32_t)len, t[j].magic, (uint32_t)t0 + m)
+                         : loop_pair<uint64_t>(p, len, (t0 + m) % len);
+    return zero_tail(epilogue4(v, term_pg(t, j)), m, M);
+}
+TD_DEV float4 loop_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
+    return zero_tail(epilogue4(loop_pair32(t[j].p, (uint32_t)t[j].len, t[j].magic, (uint32_t)t[j].t0 + m), term_pg(t, j)), m, M);
 }
 
 // sum_inputs (extensions.rs:310-319): zero, then += each input in edge order.  Terms are fetched four
 // (edge buffers: eight) at a time so that 8-16 x 16 B loads are in flight per lane before the first add;
 // the adds themselves stay strictly sequential per element.
 template <int MODE>
-TD_DEV void sum_terms(const InTerm* __restrict__ ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_t M,
-                      float4& a0, float4& a1) {
+TD_DEV void sum_terms(TermTab ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_t M, float4& acc0, float4& acc1) {
     uint32_t j = 0;
-    if (MODE == TERMS_ALL_EDGE) {
+    if (MODE == TERMS_ALL_EDGE && k >= 8) {
+        // software pipeline over groups of four edge buffers, two register sets (no copies): the eight loads
+        // of the next group are in flight while this group's adds retire (counted vmcnt waits)
+        float4 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const float2* p = ins[u].p; a0[u] = load_pair(p, m0, M); a1[u] = load_pair(p, m1, M); }
         for (; j + 8 <= k; j += 8) {
-            float4 x0[8], x1[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const float2* p = ins[j + u].p; x0[u] = load_pair(p, m0, M); x1[u] = load_pair(p, m1, M); }
+            for (int u = 0; u < 4; ++u) { const float2* p = ins[j + 4 + u].p; b0[u] = load_pair(p, m0, M); b1[u] = load_pair(p, m1, M); }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a0 = add4(a0, x0[u]); a1 = add4(a1, x1[u]); }
+            for (int u = 0; u < 4; ++u) { acc0 = add4(acc0, a0[u]); acc1 = add4(acc1, a1[u]); }
+            if (j + 12 <= k) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const float2* p = ins[j + 8 + u].p; a0[u] = load_pair(p, m0, M); a1[u] = load_pair(p, m1, M); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc0 = add4(acc0, b0[u]); acc1 = add4(acc1, b1[u]); }
+        }
+        if (j + 4 <= k) {   // one more full group is already loaded in a*
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { acc0 = add4(acc0, a0[u]); acc1 = add4(acc1, a1[u]); }
+            j += 4;
         }
     }
     for (; j + 4 <= k; j += 4) {
@@ -149,19 +195,20 @@ TD_DEV void sum_terms(const InTerm* __restrict__ ins, uint32_t k, uint32_t m0, u
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (MODE == TERMS_ALL_EDGE) { const float2* p = ins[j + u].p; x0[u] = load_pair(p, m0, M); x1[u] = load_pair(p, m1, M); }
-            else if (MODE == TERMS_ALL_LOOP32) { x0[u] = loop_term_pair(ins[j + u], m0, M); x1[u] = loop_term_pair(ins[j + u], m1, M); }
-            else { x0[u] = term_pair(ins[j + u], m0, M); x1[u] = term_pair(ins[j + u], m1, M); }
+            else if (MODE == TERMS_ALL_LOOP32) { x0[u] = loop_term_pair(ins, j + u, m0, M); x1[u] = loop_term_pair(ins, j + u, m1, M); }
+            else { x0[u] = term_pair(ins, j + u, m0, M); x1[u] = term_pair(ins, j + u, m1, M); }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { a0 = add4(a0, x0[u]); a1 = add4(a1, x1[u]); }
+        for (int u = 0; u < 4; ++u) { acc0 = add4(acc0, x0[u]); acc1 = add4(acc1, x1[u]); }
     }
     for (; j < k; ++j) {
-        a0 = add4(a0, term_pair(ins[j], m0, M));
-        a1 = add4(a1, term_pair(ins[j], m1, M));
+        acc0 = add4(acc0, term_pair(ins, j, m0, M));
+        acc1 = add4(acc1, term_pair(ins, j, m1, M));
     }
 }
-TD_DEV void sum_inputs_pairs(const InTerm* ins, uint32_t k, uint32_t term_mode, uint32_t m0, uint32_t m1, uint32_t M,
+TD_DEV void sum_inputs_pairs(const InTerm* ins_generic, uint32_t k, uint32_t term_mode, uint32_t m0, uint32_t m1, uint32_t M,
                              float4& a0, float4& a1) {
+    const TermTab ins = term_tab(ins_generic);
     a0 = make_float4(0.f, 0.f, 0.f, 0.f);
     a1 = a0;
     if (term_mode == TERMS_ALL_EDGE) sum_terms<TERMS_ALL_EDGE>(ins, k, m0, m1, M, a0, a1);
@@ -328,8 +375,8 @@ __global__ __launch_bounds__(kThreads) void k_sample_loop(const LoopDesc* __rest
     const LoopDesc& d = descs[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
-    const float4 v0 = gather_loop_pair(d.sample, d.len, d.t0, m0, M);
-    const float4 v1 = gather_loop_pair(d.sample, d.len, d.t0, m1, M);
+    const float4 v0 = gather_loop_pair(d.sample, d.len, d.t0, d.magic, m0);
+    const float4 v1 = gather_loop_pair(d.sample, d.len, d.t0, d.magic, m1);
     store_pair(d.out, m0, M, epilogue4(v0, d.pg));
     store_pair(d.out, m1, M, epilogue4(v1, d.pg));
 }
@@ -713,7 +760,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     const uint32_t start = seg * d.S;
     const uint32_t end = min(start + d.S, M);
     // exact state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
-    const float y_true0 = d.state->first ? xf[ch] : reinterpret_cast<const float*>(d.state)[c];
+    const float y_true0 = d.state->first ? gload1(xf + ch) : gload1(reinterpret_cast<const float*>(d.state) + c);
     // Input fetch: the four lanes of a quad load four consecutive 16-byte words (8 frames, 64 B) with ONE
     // instruction and hand them round with DPP quad broadcasts -- one vector-memory instruction per 8
     // steps instead of 8, which is what the address path of 16 independent streams per wave can sustain.
@@ -721,7 +768,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     const uint32_t M2 = (M + 1u) >> 1;                       // 16-byte words in the (even-padded) buffer
     auto fetch8 = [&](uint32_t frame) -> float4 {            // frame is a multiple of 8
         const uint32_t w = (frame >> 1) + c;
-        return w < M2 ? x4[w] : make_float4(0.f, 0.f, 0.f, 0.f);
+        return gload4(x4 + min(w, M2 - 1u));   // clamped: frames past the end are never stepped over
     };
     // (the broadcasts are cross-lane operations: they must execute unconditionally, the per-lane channel
     // select comes after)
@@ -768,26 +815,37 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     for (int off = 32; off > 0; off >>= 1) wave_begin = min(wave_begin, (uint32_t)__shfl_xor((int)wave_begin, off, 64));
     uint32_t n = wave_begin;
     float y = y_true0;
-    auto seed = [&]() {   // at this lane's own warm-up start: exact state at frame 0, constant chain, or the guess
-        if (n == my_begin) y = (my_begin == 0u || gam == 0.0f) ? y_true0 : xf[2u * n + ch];
-    };
+    // at this lane's own warm-up start: exact state at frame 0, constant chain, or the guess (loaded up front
+    // so that the loop body contains no other memory operation than the batched prefetches)
+    const float seed_val = (my_begin == 0u || gam == 0.0f) ? y_true0 : gload1(xf + 2u * my_begin + ch);
+    auto seed = [&]() { if (n == my_begin) y = seed_val; };
     if (n + 32u <= start && (n & 31u) == 0u) {
-        float4 p0 = fetch8(n), p1 = fetch8(n + 8u), p2 = fetch8(n + 16u), p3 = fetch8(n + 24u);
-        for (; n + 32u <= start; n += 32u) {
-            const float4 q0 = fetch8(n + 32u), q1 = fetch8(n + 40u), q2 = fetch8(n + 48u), q3 = fetch8(n + 56u);
+        // ping-pong register sets A / B (no copies): while A's 32 steps retire, B's four loads stay in flight
+        float4 a0 = fetch8(n), a1 = fetch8(n + 8u), a2 = fetch8(n + 16u), a3 = fetch8(n + 24u);
+        while (n + 64u <= start) {
+            const float4 b0 = fetch8(n + 32u), b1 = fetch8(n + 40u), b2 = fetch8(n + 48u), b3 = fetch8(n + 56u);
             seed();
-            TD_BAND_STEP8(p0) TD_BAND_STEP8(p1) TD_BAND_STEP8(p2) TD_BAND_STEP8(p3)
-            p0 = q0; p1 = q1; p2 = q2; p3 = q3;
+            TD_BAND_STEP8(a0) TD_BAND_STEP8(a1) TD_BAND_STEP8(a2) TD_BAND_STEP8(a3)
+            n += 32u;
+            a0 = fetch8(n + 32u); a1 = fetch8(n + 40u); a2 = fetch8(n + 48u); a3 = fetch8(n + 56u);
+            seed();
+            TD_BAND_STEP8(b0) TD_BAND_STEP8(b1) TD_BAND_STEP8(b2) TD_BAND_STEP8(b3)
+            n += 32u;
+        }
+        if (n + 32u <= start) {
+            seed();
+            TD_BAND_STEP8(a0) TD_BAND_STEP8(a1) TD_BAND_STEP8(a2) TD_BAND_STEP8(a3)
+            n += 32u;
         }
     }
     if ((n & 7u) == 0u)
         for (; n + 8u <= start; n += 8u) { seed(); TD_BAND_STEP8(fetch8(n)) }
 #undef TD_BAND_STEP8
-    for (; n < start; ++n) { seed(); y = y + gam * (xf[2u * n + ch] - y); }
+    for (; n < start; ++n) { seed(); y = y + gam * (gload1(xf + 2u * n + ch) - y); }
     seed();   // n == start == my_begin: segment 0 / no warm-up
     if (live) d.seg_start[seg * 4u + c] = y;
     // the segment itself: recurrence + output
-    const float x_first = xf[2u * start + ch];
+    const float x_first = gload1(xf + 2u * start + ch);
     bool same = true, zero = true;
     auto step = [&](uint32_t m, float l, float r) {
         if (m >= end) return;
@@ -796,7 +854,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         zero = zero && (x == 0.0f);
         y = y + gam * (x - y);
         const float2 o = band_out(kf, l, r, quad_bcast<0>(y), quad_bcast<1>(y), quad_bcast<2>(y), quad_bcast<3>(y));
-        if (c == 0u && live) d.out[m] = epilogue(o, d.pg);
+        if (c == 0u && live) gstore2(d.out + m, epilogue(o, d.pg));
     };
     if ((start & 7u) == 0u) {
         float4 a = fetch8(start);
