@@ -359,7 +359,7 @@ struct Staging {
 struct VTables {   // per-vertex compile result: offsets into the staging arena
     size_t hits_off = 0;
     uint32_t n_hits = 0;
-    size_t istart_off = 0, ivoff_off = 0, voices_off = 0;
+    size_t istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0;
     uint32_t n_int = 0;
     uint64_t t0 = 0;
 };
@@ -439,6 +439,15 @@ static void compile_lerp(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
 static void put_intervals(IntervalBuilder& ib, Staging& st, VTables& vt) {
     ib.finish();
     vt.n_int = (uint32_t)ib.istart.size();
+    // per 1024-frame tile: the interval that holds the tile's first frame (istart[0] == 0, ascending)
+    std::vector<uint32_t> tile_first((ib.limit + kTileFrames - 1) / kTileFrames + 1);
+    uint32_t it = 0;
+    for (size_t t = 0; t < tile_first.size(); ++t) {
+        const uint32_t m = (uint32_t)(t * kTileFrames);
+        while (it + 1 < ib.istart.size() && ib.istart[it + 1] <= m) ++it;
+        tile_first[t] = it;
+    }
+    vt.tile_first_off = st.put(tile_first);
     vt.istart_off = st.put(ib.istart);
     vt.ivoff_off = st.put(ib.ivoff);
     vt.voices_off = st.put(ib.voices);
@@ -1002,6 +1011,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SineDesc) + offsetof(SineDesc, tab);
                         ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
                         ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
                         ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
                     }
@@ -1030,6 +1040,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SynthDesc) + offsetof(SynthDesc, tab);
                         ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
                         ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
                         ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
                     }
@@ -1053,6 +1064,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SampsynDesc) + offsetof(SampsynDesc, tab);
                         ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
                         ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
                         ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
                     }
@@ -1139,6 +1151,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         ptr_field(o, offsetof(AdsrVDesc, ins), ins_off[vs[i]]);
                         const size_t t = o + offsetof(AdsrVDesc, tab);
                         ptr_field(t, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
+                        ptr_field(t, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
                         ptr_field(t, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
                         ptr_field(t, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
                     }

@@ -132,6 +132,7 @@ struct IntervalTab {
     const uint32_t* istart;
     const uint32_t* ivoff;
     const float4* voices;
+    const uint32_t* tile_first;   // [tiles] index of the interval holding each 1024-frame tile's first frame
     uint32_t n_int;
     uint32_t pad;
 };

@@ -462,10 +462,14 @@ __global__ __launch_bounds__(kThreads) void k_sample_lerp(const LerpDesc* __rest
 
 // envelope math: adsr_math.h (shared with the host event compiler)
 
-TD_DEV uint32_t find_interval(const uint32_t* __restrict__ s, uint32_t n, uint32_t m) {
-    uint32_t lo = 0, hi = n;   // last i with s[i] <= m ; s[0] == 0
-    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (s[mid] <= m) lo = mid; else hi = mid; }
-    return lo;
+// Interval of frame m: start from the tile's first interval (host-made table, one scalar load) and walk
+// forward -- a tile holds its block-start interval plus a handful of event intervals, so the walk is short
+// and replaces a 13-step dependent binary search per frame.
+TD_DEV uint32_t find_interval(const IntervalTab& tab, uint32_t m) {
+    const uint32_t TD_GLOBAL* s = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)tab.istart);
+    uint32_t it = *reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)(tab.tile_first + m / kTileFrames));
+    while (it + 1u < tab.n_int && s[it + 1u] <= m) ++it;
+    return it;
 }
 
 constexpr float kPi = 3.14159274101257324f;   // core::f32::consts::PI
@@ -474,7 +478,7 @@ constexpr float kPi = 3.14159274101257324f;   // core::f32::consts::PI
 // k_debug_sine (extensions.rs:423-457)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float sine_frame(const SineDesc& d, uint32_t m) {
-    const uint32_t it = find_interval(d.tab.istart, d.tab.n_int, m);
+    const uint32_t it = find_interval(d.tab, m);
     const uint32_t v0 = d.tab.ivoff[it], v1 = d.tab.ivoff[it + 1];
     const float time = (float)(d.t0 + m) / (float)d.sr;
     float acc = 0.0f;
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(kThreads) void k_debug_sine(const SineDesc* __restr
 // k_synth (extensions.rs:460-529, synth.rs:21-34)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float synth_frame(const SynthDesc& d, uint32_t m) {
-    const uint32_t it = find_interval(d.tab.istart, d.tab.n_int, m);
+    const uint32_t it = find_interval(d.tab, m);
     const uint32_t v0 = d.tab.ivoff[it], v1 = d.tab.ivoff[it + 1];
     const float time = (float)(d.t0 + m) / (float)d.sr;
     const float off = (float)(m % d.bl) / (float)d.sr;
@@ -575,7 +579,7 @@ TD_DEV float wavetable_act(const WaveTableD& w, float hz, float t) {
     return lerpf(s0, s1, b);
 }
 TD_DEV float sampsyn_frame(const SampsynDesc& d, uint32_t m) {
-    const uint32_t it = find_interval(d.tab.istart, d.tab.n_int, m);
+    const uint32_t it = find_interval(d.tab, m);
     const uint32_t v0 = d.tab.ivoff[it], v1 = d.tab.ivoff[it + 1];
     const float off = (float)(m % d.bl) / (float)d.sr;
     float acc = 0.0f;
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restr
 // k_adsr: envelope-follower vertex (extensions.rs:593-651)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
-    const uint32_t it = find_interval(d.tab.istart, d.tab.n_int, m);
+    const uint32_t it = find_interval(d.tab, m);
     const float4 p = d.tab.voices[2 * it], g = d.tab.voices[2 * it + 1];   // (t_off, vel, release_val, skip)
     if (p.w != 0.0f) return x;   // extensions.rs:632-635: `continue` leaves this frame untouched
     const float offset = (float)(m % d.bl) / (float)d.sr;
