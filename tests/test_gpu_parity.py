@@ -295,3 +295,27 @@ def test_branch_streams_do_not_change_results(gpu_api, oracle, streams):
     obuilt = p.build(oracle)
     for _ in range(3):                         # repeated renders reuse pooled buffers across levels
         assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
+
+
+def test_long_timeline_crosses_the_chunk_cap(gpu_api, oracle):
+    """6 minutes @ 48 kHz = 17.3 M frames > the 2^24-frame edge-buffer chunk cap: the engine renders two chunks
+    with carried state (loop cursors, running peak, band-pass state); the PCM must equal the oracle's."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(360.0)
+    p.assets["a"] = W.Asset(W.kick_int16(31, 30011))
+    p.assets["b"] = W.Asset(W.noise_int16(32, 77777))
+    p.load_sample("a", "a", "")
+    p.load_sample("b", "b", "")
+    p.add_sampleloop("la", 0.9, -20.0, "a")
+    p.add_sampleloop("lb", 0.2, 35.0, "b")
+    p.add_bandpass("bp", 1.0, 0.0, 1.0, 150.0, 6000.0, True)
+    p.add_normalize("out", 1.0, 0.0)
+    p.connect("la", "bp")
+    p.connect("lb", "bp")
+    p.connect("bp", "out")
+    p.set_output("out")
+    assert p.cs * 1024 > (1 << 24)
+    gp, _ = p.render(gpu_api, want_f32=False)
+    op, _ = p.render(oracle, want_f32=False)
+    assert gp.shape == op.shape == (p.cs * 1024, 2)
+    assert np.array_equal(gp, op)

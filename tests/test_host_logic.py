@@ -165,3 +165,15 @@ def test_project_toml(api, tmp_path):
     s = api.State(open_dir=str(tmp_path))
     assert s.refresh(), api.last_error()
     assert s.cs == int(np.ceil(np.float32(44100) * np.float32(1.0) / np.float32(512)))   # psr defaults to 44100 (config.rs:62-64)
+
+
+def test_c_abi_from_plain_c(api, tmp_path):
+    """include/termdaw_amd.h compiled as C (gcc -std=c99 -pedantic) and linked against the library."""
+    import subprocess
+    exe = str(tmp_path / "c_abi_smoke")
+    libdir = os.path.dirname(api.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", exe, "-L", libdir, "-ltermdaw_amd",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "c abi ok" in out.stdout, out.stdout + out.stderr
