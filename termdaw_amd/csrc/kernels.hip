@@ -939,22 +939,40 @@ __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __
                 float y = __shfl(__uint_as_float(Fu[(seg - 1u) * 4u + c]), (int)c, 64);
                 // cascade: recompute from y until a recomputed exit state reproduces the stored one, or the
                 // next segment is found to have entered with exactly the new exit state
+                bool first_round = true;
                 for (;;) {
                     const uint32_t start = seg * d.S, end = min(start + d.S, M), len = end - start;
+                    // everything this round needs from global memory, issued together (one round trip): the
+                    // segment's flags / first frame / speculative entry state / stored exit state and the first
+                    // 64 input frames.  The input is staged in LDS 64 frames at a time, only as far as the
+                    // stepping gets (most repairs park or coalesce within the first few frames).
                     const uint32_t flags = d.seg_flags[seg];
-                    uint32_t last = seg;   // last segment covered by this round
-                    // stage the segment's input in LDS (one coalesced sweep), step through it, flush the output
-                    for (uint32_t q = lane; q < len; q += 64u) xs[q] = d.x[start + q];
+                    const uint2 x0 = X0[seg];
+                    const uint32_t su = Su[seg * 4u + c];
+                    const uint32_t fu_old = Fu[seg * 4u + c];
+                    if (lane < len) xs[lane] = gload2(d.x + start + lane);
+                    uint32_t staged = min(64u, len);
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (!first_round && __any((lane < 4u && su != __float_as_uint(y)) ? 1 : 0) == 0) {
+                        ++seg;   // this segment entered with exactly the new state: its pass-1 result stands
+                        break;
+                    }
+                    first_round = false;
+                    uint32_t last = seg;   // last segment covered by this round
                     const float* xsf = reinterpret_cast<const float*>(xs);
                     // Quad 0 (lanes 0..3) follows the TRUE trajectory from y; quad 1 (lanes 4..7) re-runs the
                     // speculative one from the entry state pass 1 used.  As soon as the two are bit-identical
                     // the rest of the segment -- output and exit state -- is already right (checked every 8
                     // steps).  The other lanes idle along as copies of quad 0.
-                    float yy = (lane >= 4u && lane < 8u) ? __uint_as_float(Su[seg * 4u + c]) : y;
+                    float yy = (lane >= 4u && lane < 8u) ? __uint_as_float(su) : y;
                     uint32_t n = 0;
                     bool parked = false, coalesced = false;
                     while (n < len && !parked && !coalesced) {
+                        if (n >= staged) {
+                            if (staged + lane < len) xs[staged + lane] = gload2(d.x + start + staged + lane);
+                            staged = min(staged + 64u, len);
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        }
                         const uint32_t nb = min(8u, len - n);
                         float xv[8];
 #pragma unroll
@@ -974,7 +992,6 @@ __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __
                             const bool zero_ok = (flags & 2u) && __all((lane >= 4u || gam == 0.0f || yy != 0.0f) ? 1 : 0);
                             const bool const_ok = (flags & 1u) != 0u;
                             if (!zero_ok && !const_ok) continue;
-                            const uint2 x0 = X0[seg];
                             uint32_t e = seg + 1u;
                             for (;;) {   // extend over following segments, 64 at a time
                                 const uint32_t s2 = e + lane;
@@ -1025,12 +1042,11 @@ __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __
                         break;
                     }
                     recomputed += last - seg + 1u;
-                    const bool changed = __any((lane < 4u && Fu[last * 4u + c] != __float_as_uint(y)) ? 1 : 0) != 0;
+                    const uint32_t fu_cmp = last == seg ? fu_old : Fu[last * 4u + c];
+                    const bool changed = __any((lane < 4u && fu_cmp != __float_as_uint(y)) ? 1 : 0) != 0;
                     if (lane < 4u) Fu[last * 4u + c] = __float_as_uint(y);
                     seg = last + 1u;
                     if (!changed || seg >= d.nseg) break;
-                    const bool next_ok = __any((lane < 4u && Su[seg * 4u + c] != __float_as_uint(y)) ? 1 : 0) == 0;
-                    if (next_ok) { ++seg; break; }   // seg entered with exactly this state: its pass-1 result stands
                 }
             }
         }
