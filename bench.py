@@ -93,8 +93,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     api.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- build this rank's project: config 2 with seed offset 64 * rank (config 5 sharding) ----
@@ -112,14 +114,14 @@ def main():
     def barrier():
         g.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
         step()
     g.sync()
     # warm the exchange path too (first CUDA tensor / first collective initialise lazily: not render work)
-    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if world > 1 else None, "cuda")
+    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda")
     barrier()
     g.set_profiling(True)   # HIP events around every launch on the engine's stream
     barrier()
@@ -128,14 +130,14 @@ def main():
         step()
     g.sync()
     # the path's only exchange: per-project (pre-normalisation) peak table, one all-reduce(max) over RCCL
-    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if world > 1 else None, "cuda")
+    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda")
     barrier()
     dt = time.perf_counter() - t0
     ktimes = g.kernel_times()
     g.set_profiling(False)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -192,10 +194,21 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(project, frames)
             out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        result_line = json.dumps(out)
+    else:
+        result_line = None
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if result_line is not None:
+        # RCCL writes its version banner to the C stdout buffer; flush that first so the JSON line is the
+        # last (and only JSON) line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
+        print(result_line, flush=True)
 
 
 if __name__ == "__main__":

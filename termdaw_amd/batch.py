@@ -24,6 +24,6 @@ def exchange_peaks(local_peaks, n_projects, dist=None, device="cpu"):
         if not (0 <= pid < n_projects):
             raise IndexError("project id %d outside the table" % pid)
         t[pid] = float(pk)
-    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist is not None and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return t.cpu().numpy()

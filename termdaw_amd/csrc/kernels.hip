@@ -318,6 +318,8 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
     const uint32_t m1 = m0 + kTileFrames / 2;
     const uint32_t b_lo = tile0 / bl;
     const float init = d.init_copy[0];
+    // the tile's own frames first: their loads fly while the peak table is reduced
+    const float4 in0 = load_pair(d.buf, m0, M), in1 = load_pair(d.buf, m1, M);
     // max of the peaks of all blocks before this tile's first block (identity 0: peaks are >= 0, never NaN)
     __shared__ float wmax[kThreads / 64];
     float p = 0.0f;
@@ -339,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
     for (int h = 0; h < 2; ++h) {
         const uint32_t m = h ? m1 : m0;
         if (m < M) {
-            float4 v = load_pair(d.buf, m, M);
+            float4 v = h ? in1 : in0;
             const float r0 = rscale_of(m);
             const float r1 = (m + 1 < M) ? rscale_of(m + 1) : r0;
             v = epilogue4(make_float4(v.x * r0, v.y * r0, v.z * r1, v.w * r1), d.pg);
