@@ -155,6 +155,8 @@ size_t td_graph_device_bytes(const td_graph* g);
 /* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
  * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);
  * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders);
+ * "packed_samples" 0|1 (default 1: inlined sources gather the packed 16-bit form of samples that came from
+ * <= 16-bit integer PCM -- (float)int * scale is how the f32 bank entry was made, so values are identical);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
  * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
  * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */

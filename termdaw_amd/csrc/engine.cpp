@@ -220,8 +220,30 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     TD_HIP(hipMalloc(&e.d, (n + (n & 1)) * sizeof(float2)));
     TD_HIP(hipMemsetAsync(e.d + (n - 1 + (n & 1)), 0, sizeof(float2), st));   // pad frame of an odd length
     launch_sample_pack(d_l, d_r, p_max_l, p_max_r, e.d, (uint32_t)n, st);
+    // packed 16-bit twin: only when l / r are still the raw integer PCM values times one scale per channel
+    // (every mode but mix-down) and no resample follows
+    bool want16 = method != LM_MIX && sr == sb->sample_rate && n >= 1 && n < 0x3FFFFFF0u;
+    if (want16) {
+        TD_HIP(hipMalloc(&e.d16, 4 * ((n + 3) & ~(size_t)3) * sizeof(uint32_t)));   // four phase-shifted copies
+        TD_HIP(hipMemsetAsync(d_s + 8, 0, sizeof(uint32_t), st));
+        launch_sample_pack16(d_l, d_r, e.d16, (uint32_t)n, reinterpret_cast<uint32_t*>(d_s + 8), st);
+    }
+    float host_s[12] = {0};
+    TD_HIP(hipMemcpyAsync(host_s, d_s, sizeof host_s, hipMemcpyDeviceToHost, st));
     TD_HIP(hipStreamSynchronize(st));
     TD_HIP(hipGetLastError());
+    if (want16) {
+        uint32_t bad;
+        memcpy(&bad, &host_s[8], 4);
+        const float ml = host_s[p_max_l - d_s], mr = host_s[p_max_r - d_s];
+        if (bad) {
+            (void)hipFree(e.d16);
+            e.d16 = nullptr;
+        } else {
+            e.scale_l = 1.0f / ml;   // the same `1.0 / max` k_sample_pack multiplied by
+            e.scale_r = 1.0f / mr;
+        }
+    }
     cleanup();
     if (sr != sb->sample_rate) {   // sample.rs:305-310: Sample::resample after the normalisation
         float2* rs = nullptr;
@@ -942,14 +964,26 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     const bool fits32 = s.len <= 0xFFFFFFFFull && t.t0 + M + kTileFrames <= 0xFFFFFFFFull;
                     t.kind = fits32 ? 1u : 2u;
                     t.magic = fits32 ? (s.len >= 2 ? (uint32_t)(0x100000000ull / s.len) : 0xFFFFFFFFu) : 0u;
+                    if (fits32 && s.d16 && g->packed_samples) {   // half the gather bytes, same values
+                        t.kind = 3u;
+                        t.p = reinterpret_cast<const float2*>(s.d16);
+                        t.scale_l = s.scale_l;
+                        t.scale_r = s.scale_r;
+                    }
                 } else {
                     t.p = g->vbuf[u];
                 }
                 ins.push_back(t);
             }
-            bool all_edge = true, all_loop = !ins.empty();
-            for (auto& t : ins) { all_edge = all_edge && t.kind == 0; all_loop = all_loop && t.kind == 1; }
-            term_mode[vi] = all_edge ? TERMS_ALL_EDGE : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED);
+            bool all_edge = true, all_loop = !ins.empty(), all_loop16 = !ins.empty();
+            for (auto& t : ins) {
+                all_edge = all_edge && t.kind == 0;
+                all_loop = all_loop && t.kind == 1;
+                all_loop16 = all_loop16 && t.kind == 3;
+            }
+            // (the band-pass pre-sum keeps the pair mapping: its block-liveness reduction is written for it)
+            if (all_loop16 && g->vertices[vi].kind == K_BAND_PASS) all_loop16 = false;
+            term_mode[vi] = all_edge ? TERMS_ALL_EDGE : (all_loop16 ? TERMS_ALL_LOOP16 : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED));
             ins_off[vi] = st.put(ins);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
@@ -1433,7 +1467,7 @@ td_samplebank* td_samplebank_new(size_t sample_rate) {
 void td_samplebank_free(td_samplebank* sb) {
     if (!sb) return;
     if (!sb->samples.empty() && hipSetDevice(sb->device) == hipSuccess)
-        for (auto& e : sb->samples) (void)hipFree(e.d);
+        for (auto& e : sb->samples) { (void)hipFree(e.d); if (e.d16) (void)hipFree(e.d16); }
     delete sb;
 }
 int td_samplebank_add_decoded(td_samplebank* sb, const char* name, const float* linear, size_t n, int channels,
@@ -1947,6 +1981,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
+    if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }
     if (k == "max_chunk_frames") {
         if (value < 1) return fail("max_chunk_frames must be >= 1");

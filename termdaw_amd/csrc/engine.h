@@ -25,6 +25,12 @@ size_t f32_as_usize(float x);
 struct SampleEntry {
     float2* d = nullptr;   // interleaved frames in HBM
     size_t len = 0;
+    // Optional packed form for samples that came from <= 16-bit integer PCM through a per-channel-scale load
+    // mode: one word per frame (int16 l | int16 r << 16), four phase-shifted copies (kernels.h, InTerm kind 3),
+    // + the two normalisation scales.  (float)int * scale
+    // rebuilds the f32 frame bit for bit (it IS how the f32 frame was made) at half the bytes.
+    uint32_t* d16 = nullptr;
+    float scale_l = 0.0f, scale_r = 0.0f;
 };
 
 }  // namespace tde
@@ -149,6 +155,7 @@ struct td_graph {
     float2* d_resampled = nullptr;            // output of the last td_graph_render_all_resampled
     size_t device_bytes = 0;
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
+    bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
     std::vector<size_t> band_stats_off;        // scratch offsets of the last chunk's k_band_fix counters
     size_t band_stats_base = 0;

@@ -31,6 +31,11 @@ struct PanGain {
 //           "source inlining").  32-bit form: t0 + m < 2^32, modulo by Barrett reduction with
 //           magic = floor(2^32 / len).
 //   kind 2: the same with 64-bit cursor / length (generic modulo).
+//   kind 3: kind 1 over the sample's packed 16-bit form: one 32-bit word per frame (int16 l | int16 r << 16),
+//           stored as four phase-shifted copies (copy c, word p = frame (p + c) % len, stride roundup(len, 4))
+//           so that any four consecutive loop frames are one aligned 16-byte load; the f32 frame is rebuilt as (float)l * scale_l, (float)r * scale_r -- the very
+//           expression the load pipeline used to produce the f32 bank entry (sample.rs:270-273 `as f32`,
+//           sample.rs:121-129 `* (1.0 / max)`), so the values are bit-identical at half the gather bytes.
 struct InTerm {
     const float2* p;   // edge buffer (kind 0) or sample frames (kind 1, 2)
     uint64_t len;      // sample length
@@ -38,9 +43,9 @@ struct InTerm {
     PanGain pg;        // the source vertex' epilogue
     uint32_t kind;
     uint32_t magic;
-    uint32_t pad[2];
+    float scale_l, scale_r;   // kind 3
 };
-enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2 };
+enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2, TERMS_ALL_LOOP16 = 3 };
 
 // Running-peak bookkeeping of normalize_gen (extensions.rs:321-329), carried across chunks / passes.
 struct NormState { float max, scan_max; };
@@ -260,6 +265,9 @@ void launch_add_planar(const float* a, const float* b, float* out, uint32_t n, h
 // frames[i] = {l[i] * scale_l, r[i] * scale_r} with scale = 1.0f / *max (normalize / normalize_seperate / mix_down)
 void launch_sample_pack(const float* l, const float* r, const float* max_l, const float* max_r, float2* frames,
                         uint32_t n, hipStream_t s);
+// packed 16-bit form of the same sample (un-scaled integer PCM values); *not_int16 is set when a value is
+// not an integer in [-32768, 32767] (then the packed form is not usable)
+void launch_sample_pack16(const float* l, const float* r, uint32_t* packed, uint32_t n, uint32_t* not_int16, hipStream_t s);
 
 void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);

@@ -146,14 +146,23 @@ TD_DEV PanGain term_pg(TermTab t, uint32_t j) {
     pg.l_amp = t[j].pg.l_amp; pg.r_amp = t[j].pg.r_amp; pg.gain = t[j].pg.gain; pg.flags = t[j].pg.flags;
     return pg;
 }
+TD_DEV float2 unpack16(uint32_t w, float sl, float sr);
 // value of one input term for the frame pair starting at m (generic form)
 TD_DEV float4 term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     const float2* p = t[j].p;
     const uint32_t kind = t[j].kind;
     if (kind == 0) return load_pair(p, m, M);
     const uint64_t len = t[j].len, t0 = t[j].t0;
-    float4 v = kind == 1 ? loop_pair32(p, (uint32_t)len, t[j].magic, (uint32_t)t0 + m)
-                         : loop_pair<uint64_t>(p, len, (t0 + m) % len);
+    float4 v;
+    if (kind == 3) {   // packed 16-bit form, two frames
+        const uint32_t TD_GLOBAL* g = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)p);
+        const uint32_t l32 = (uint32_t)len, i0 = barrett_mod((uint32_t)t0 + m, l32, t[j].magic);
+        const uint32_t i1 = i0 + 1u == l32 ? 0u : i0 + 1u;
+        const float2 a = unpack16(g[i0], t[j].scale_l, t[j].scale_r), b = unpack16(g[i1], t[j].scale_l, t[j].scale_r);
+        v = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+        v = kind == 1 ? loop_pair32(p, (uint32_t)len, t[j].magic, (uint32_t)t0 + m) : loop_pair<uint64_t>(p, len, (t0 + m) % len);
+    }
     return zero_tail(epilogue4(v, term_pg(t, j)), m, M);
 }
 TD_DEV float4 loop_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
@@ -206,6 +215,51 @@ TD_DEV void sum_terms(TermTab ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_
         acc1 = add4(acc1, term_pair(ins, j, m1, M));
     }
 }
+// ---- packed 16-bit sample form (InTerm kind 3): four consecutive frames per lane ----
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+TD_DEV float2 unpack16(uint32_t w, float sl, float sr) {
+    return make_float2((float)(int16_t)(w & 0xFFFFu) * sl, (float)(int16_t)(w >> 16) * sr);
+}
+// Frames idx .. idx+3 of a looping sample in ONE aligned 16-byte load: the packed form is stored four times,
+// phase-shifted -- copy c holds word p = frame (p + c) % len for p < stride -- so frame idx sits at the aligned
+// position idx & ~3 of copy idx & 3 and the three frames after it (loop wrap included) follow it.
+TD_DEV void loop16_quad(const uint32_t* s, uint32_t len, uint32_t idx, uint32_t out[4]) {
+    const uint32_t stride = (len + 3u) & ~3u;
+    const uint32_t TD_GLOBAL* g = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)s);
+    const u4v q = *reinterpret_cast<const u4v TD_GLOBAL*>(g + (size_t)(idx & 3u) * stride + (idx & ~3u));
+    out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+}
+// all terms kind 3: lane t owns frames m, m+1 (acc0) and m+2, m+3 (acc1) with m = tile + 4t
+TD_DEV void sum_terms16(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4& acc0, float4& acc1) {
+    uint32_t j = 0;
+    for (; j + 4 <= k; j += 4) {
+        uint32_t w[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t len = (uint32_t)ins[j + u].len;
+            loop16_quad(reinterpret_cast<const uint32_t*>(ins[j + u].p), len, barrett_mod((uint32_t)ins[j + u].t0 + m, len, ins[j + u].magic), w[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float sl = ins[j + u].scale_l, sr = ins[j + u].scale_r;
+            const PanGain pg = term_pg(ins, j + u);
+            const float2 f0 = unpack16(w[u][0], sl, sr), f1 = unpack16(w[u][1], sl, sr), f2 = unpack16(w[u][2], sl, sr), f3 = unpack16(w[u][3], sl, sr);
+            acc0 = add4(acc0, zero_tail(epilogue4(make_float4(f0.x, f0.y, f1.x, f1.y), pg), m, M));
+            acc1 = add4(acc1, zero_tail(epilogue4(make_float4(f2.x, f2.y, f3.x, f3.y), pg), m + 2u, M));
+        }
+    }
+    for (; j < k; ++j) {
+        uint32_t w[4];
+        const uint32_t len = (uint32_t)ins[j].len;
+        loop16_quad(reinterpret_cast<const uint32_t*>(ins[j].p), len, barrett_mod((uint32_t)ins[j].t0 + m, len, ins[j].magic), w);
+        const float sl = ins[j].scale_l, sr = ins[j].scale_r;
+        const PanGain pg = term_pg(ins, j);
+        const float2 f0 = unpack16(w[0], sl, sr), f1 = unpack16(w[1], sl, sr), f2 = unpack16(w[2], sl, sr), f3 = unpack16(w[3], sl, sr);
+        acc0 = add4(acc0, zero_tail(epilogue4(make_float4(f0.x, f0.y, f1.x, f1.y), pg), m, M));
+        acc1 = add4(acc1, zero_tail(epilogue4(make_float4(f2.x, f2.y, f3.x, f3.y), pg), m + 2u, M));
+    }
+}
+
 TD_DEV void sum_inputs_pairs(const InTerm* ins_generic, uint32_t k, uint32_t term_mode, uint32_t m0, uint32_t m1, uint32_t M,
                              float4& a0, float4& a1) {
     const TermTab ins = term_tab(ins_generic);
@@ -230,10 +284,19 @@ TD_DEV float absmax4(float m, float4 v) {
 __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ descs, uint32_t M, uint32_t bl,
                                                   uint32_t tiles_per_block) {
     const SumDesc& d = descs[blockIdx.y];
-    const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
-    const uint32_t m1 = m0 + kTileFrames / 2;
+    // frame mapping: lane t owns pairs tile+2t and tile+512+2t -- or, when every term is a packed 16-bit
+    // source, the four consecutive frames tile+4t.. (one 16-byte word of packed frames per source)
+    const bool quad_map = d.term_mode == TERMS_ALL_LOOP16;
+    const uint32_t m0 = blockIdx.x * kTileFrames + (quad_map ? 4 : 2) * threadIdx.x;
+    const uint32_t m1 = m0 + (quad_map ? 2 : kTileFrames / 2);
     float4 a0, a1;
-    sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
+    if (quad_map) {
+        a0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        a1 = a0;
+        sum_terms16(term_tab(d.ins), d.k, m0, M, a0, a1);
+    } else {
+        sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
+    }
     if (d.mode == 0) {
         store_pair(d.out, m0, M, epilogue4(a0, d.pg));
         store_pair(d.out, m1, M, epilogue4(a1, d.pg));
@@ -1276,6 +1339,24 @@ void launch_abs_sum_serial(const float* v, uint32_t n, float* out, hipStream_t s
 }
 void launch_add_planar(const float* a, const float* b, float* out, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_add_planar, dim3(grid_for(n)), dim3(kThreads), 0, s, a, b, out, n);
+}
+__global__ __launch_bounds__(kThreads) void k_sample_pack16(const float* __restrict__ l, const float* __restrict__ r,
+                                                            uint32_t* __restrict__ packed, uint32_t n, uint32_t* not_int16) {
+    // four phase-shifted copies of stride roundup(n, 4): copy c, word p = frame (p + c) % n
+    const uint32_t stride = (n + 3u) & ~3u;
+    bool bad = false;
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < 4u * stride; i += gridDim.x * kThreads) {
+        const uint32_t c = i / stride, p = i - c * stride;
+        const uint32_t f = (p + c) % n;
+        const float a = l[f], b = r[f];
+        const int ia = (int)fminf(fmaxf(a, -32768.0f), 32767.0f), ib = (int)fminf(fmaxf(b, -32768.0f), 32767.0f);
+        bad = bad || (float)ia != a || (float)ib != b;   // NaN, fractions and out-of-range values all fail here
+        packed[i] = ((uint32_t)ia & 0xFFFFu) | ((uint32_t)ib << 16);
+    }
+    if (__any(bad ? 1 : 0) && (threadIdx.x & 63) == 0) atomicOr(not_int16, 1u);
+}
+void launch_sample_pack16(const float* l, const float* r, uint32_t* packed, uint32_t n, uint32_t* not_int16, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_sample_pack16, dim3(grid_for(4u * ((n + 3u) & ~3u))), dim3(kThreads), 0, s, l, r, packed, n, not_int16);
 }
 void launch_sample_pack(const float* l, const float* r, const float* max_l, const float* max_r, float2* frames, uint32_t n,
                         hipStream_t s) {

@@ -123,7 +123,10 @@ void bank_remove(td_samplebank* sb, const std::string& name) {   // mark_dead + 
     auto it = sb->names.find(name);
     if (it == sb->names.end()) return;
     const size_t idx = it->second;
-    if (hipSetDevice(sb->device) == hipSuccess) (void)hipFree(sb->samples[idx].d);
+    if (hipSetDevice(sb->device) == hipSuccess) {
+        (void)hipFree(sb->samples[idx].d);
+        if (sb->samples[idx].d16) (void)hipFree(sb->samples[idx].d16);
+    }
     sb->samples.erase(sb->samples.begin() + (long)idx);
     sb->names.erase(it);
     for (auto& kv : sb->names)

@@ -319,3 +319,33 @@ def test_long_timeline_crosses_the_chunk_cap(gpu_api, oracle):
     op, _ = p.render(oracle, want_f32=False)
     assert gp.shape == op.shape == (p.cs * 1024, 2)
     assert np.array_equal(gp, op)
+
+
+@pytest.mark.parametrize("packed", [0, 1])
+@pytest.mark.parametrize("lens", [(5, 7, 1001), (48000, 4099, 6), (4, 13, 64)])
+def test_packed_16bit_sample_form_is_value_identical(gpu_api, oracle, packed, lens):
+    """Inlined sources read the packed int16 form of the samples (half the gather bytes); (float)int * scale is
+    how the f32 bank entry was made, so the render must not change by a bit -- including loop lengths that are
+    not multiples of 4, shorter than a lane's four frames, and every per-channel-scale load mode."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(0.4)
+    modes = ["", "normalize-seperate", "left", "loudest"]
+    for i, n in enumerate(lens):
+        p.assets["a%d" % i] = W.Asset(W.noise_int16(40 + i, n))
+        p.load_sample("a%d" % i, "a%d" % i, modes[i % len(modes)])
+        p.add_sampleloop("l%d" % i, 0.3 + 0.4 * i, -60.0 + 50.0 * i, "a%d" % i)
+    p.assets["mix"] = W.Asset(W.noise_int16(50, 333))
+    p.load_sample("mix", "mix", "mix-down")            # no packed form: exercises the mixed-term path
+    p.add_sampleloop("lm", 0.5, 0.0, "mix")
+    p.add_normalize("out", 1.0, 0.0)
+    p.add_sum("side", 1.0, 0.0)
+    for i in range(len(lens)):
+        p.connect("l%d" % i, "out")
+        p.connect("l%d" % i, "side")
+    p.connect("lm", "side")
+    p.connect("side", "out")
+    p.set_output("out")
+    built = p.build(gpu_api)
+    built[2].set_option("packed_samples", packed)
+    for scan in (False, True):
+        assert_bit_exact(p.render(gpu_api, built=built, scan=scan), p.render(oracle, scan=scan))
