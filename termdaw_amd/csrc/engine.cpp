@@ -1107,6 +1107,8 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     std::vector<SumDesc> d;
                     // parallel band-pass vertices first get their summed input materialised (no epilogue)
                     for (size_t vi : fam_v[F_BAND_SPEC]) vs.push_back(vi);
+                    // one launch per term mode (k_sum is instantiated per mode): group the vertices by it
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[a] < term_mode[b]; });
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
                         SumDesc x{};
@@ -1250,6 +1252,16 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_BAND_FILL: off = band_desc_off; break;   // reuse the k_band_spec descriptors
                 default: continue;
             }
+            if (fam == F_SUM) {   // split at term-mode boundaries (vs is sorted by it)
+                size_t b = 0;
+                while (b < vs.size()) {
+                    size_t e2 = b;
+                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) ++e2;
+                    launches.push_back({F_SUM, off + b * sizeof(SumDesc), (int)(e2 - b), term_mode[vs[b]], lv});
+                    b = e2;
+                }
+                continue;
+            }
             launches.push_back({fam, off, (int)vs.size(), max_nseg, lv});
         }
         for (float2* t : level_tmp) g->free_bufs.push_back(t);
@@ -1323,7 +1335,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
+                case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, L.aux, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, s); break;
                 case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, s); break;

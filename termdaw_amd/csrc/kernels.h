@@ -272,7 +272,8 @@ void launch_sample_pack16(const float* l, const float* r, uint32_t* packed, uint
 void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
-void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
+// every descriptor of one launch_sum call has the same term_mode (the engine groups them)
+void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStream_t s);

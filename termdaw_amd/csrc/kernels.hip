@@ -281,22 +281,20 @@ TD_DEV float absmax4(float m, float4 v) {
 // k_sum: Sum vertex / Normalize pass A (k-input sum + per-reference-block peak)
 // ------------------------------------------------------------------------------------------------
 // tiles_per_block = bl / 1024 when bl is a multiple of the tile, else 0 (generic per-frame peak path).
+// One instantiation per term mode (every descriptor of a launch shares it): each keeps only its own summing
+// loop, so the register budget -- and with it the waves per SIMD -- is set by that loop alone.
+template <int TMODE>
 __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ descs, uint32_t M, uint32_t bl,
                                                   uint32_t tiles_per_block) {
     const SumDesc& d = descs[blockIdx.y];
     // frame mapping: lane t owns pairs tile+2t and tile+512+2t -- or, when every term is a packed 16-bit
     // source, the four consecutive frames tile+4t.. (one 16-byte word of packed frames per source)
-    const bool quad_map = d.term_mode == TERMS_ALL_LOOP16;
+    constexpr bool quad_map = TMODE == TERMS_ALL_LOOP16;
     const uint32_t m0 = blockIdx.x * kTileFrames + (quad_map ? 4 : 2) * threadIdx.x;
     const uint32_t m1 = m0 + (quad_map ? 2 : kTileFrames / 2);
-    float4 a0, a1;
-    if (quad_map) {
-        a0 = make_float4(0.f, 0.f, 0.f, 0.f);
-        a1 = a0;
-        sum_terms16(term_tab(d.ins), d.k, m0, M, a0, a1);
-    } else {
-        sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
-    }
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    if (quad_map) sum_terms16(term_tab(d.ins), d.k, m0, M, a0, a1);
+    else sum_terms<TMODE>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
     if (d.mode == 0) {
         store_pair(d.out, m0, M, epilogue4(a0, d.pg));
         store_pair(d.out, m1, M, epilogue4(a1, d.pg));
@@ -1257,10 +1255,15 @@ constexpr int kMaxGridY = 65535;
     for (int o_ = 0; o_ < (N); o_ += kMaxGridY)                                                             \
         hipLaunchKernelGGL(KERNEL, dim3((GRID_X), std::min((N) - o_, kMaxGridY)), dim3(BLOCK), 0, s, (D) + o_, __VA_ARGS__)
 
-void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, hipStream_t s) {
+void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
-    TD_BATCHED(k_sum, tiles(frames), kThreads, d, n, frames, bl, tpb);
+    switch (term_mode) {
+        case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        case TERMS_ALL_LOOP32: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        case TERMS_ALL_LOOP16: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        default: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_MIXED>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+    }
 }
 void launch_scale(const ScaleDesc* d, int n, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s) {
     if (!n || !frames) return;
