@@ -36,11 +36,15 @@ SECONDS = 60.0
 N_SRC = 64
 
 
-def algorithmic_bytes_per_frame(k):
-    """8-byte stereo f32 per edge read and per vertex write."""
+def algorithmic_bytes_per_frame(k, fused, packed):
+    """Bytes each kernel has to move per output frame.  Edge-buffer mode is SURVEY.md
+    8(d)'s model: an 8-byte stereo f32 per edge read and per vertex write.  With source inlining the
+    sample_loop vertices have no edge buffers: k_sum gathers each source's sample frame itself -- 4 B in the
+    packed 16-bit form, 8 B as f32 -- and writes the raw sum once."""
+    per_src = (4.0 if packed else 8.0) if fused else 8.0
     return {
         "k_sample_loop": 16.0 * k,        # per source: 8 B sample read + 8 B edge write, k sources per launch
-        "k_sum": 8.0 * k + 8.0,           # Normalize pass A: k edge (or inlined sample) reads + raw sum write
+        "k_sum": per_src * k + 8.0,       # Normalize pass A: k edge (or inlined sample) reads + raw sum write
         "k_scale": 8.0 + 8.0 + 4.0,       # Normalize pass B with fused int16 quantise
     }
 
@@ -76,6 +80,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=SECONDS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fuse", action="store_true", help="edge-buffer model: one HBM buffer per source vertex (no source inlining)")
+    ap.add_argument("--no-pack", action="store_true", help="inlined sources gather the f32 sample form (8 B/frame) instead of the packed 16-bit one")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,6 +109,7 @@ def main():
     sb, fb, g = project.build(api)
     cs, bl = project.cs, project.bl
     g.set_option("fuse_sources", 0 if args.no_fuse else 1)
+    g.set_option("packed_samples", 0 if args.no_pack else 1)
     frames = cs * bl
 
     def step():
@@ -144,7 +150,9 @@ def main():
     if rank == 0:
         total_frames = frames * args.steps * world
         value = total_frames / dt / 1e6
-        abf = algorithmic_bytes_per_frame(N_SRC)
+        fused, packed = not args.no_fuse, not args.no_pack
+        abf = algorithmic_bytes_per_frame(N_SRC, fused, packed)
+        survey_abf = algorithmic_bytes_per_frame(N_SRC, False, False)   # SURVEY 8(d) edge-buffer figure
         kernels = []
         for name, (ms, launches) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
             avg_ms = ms / max(launches, 1)
@@ -158,7 +166,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if dom and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("nofuse" if args.no_fuse else "fused", {}).get(dom["kernel"])
+                traffic = json.load(open(tpath)).get("nofuse" if args.no_fuse else ("fused_f32" if args.no_pack else "fused"), {}).get(dom["kernel"])
             except Exception:
                 traffic = None
         out = {
@@ -177,16 +185,27 @@ def main():
             "config": {"workload": "BASELINE config 2: 64 sampleloop -> 1 normalize, %g s @48 kHz, bl 1024, 16-bit PCM out "
                                    "(one project per GPU, seed offset 64*rank)" % args.seconds,
                        "frames_per_step_per_gpu": frames, "vertices": N_SRC + 1,
-                       "source_inlining": not args.no_fuse,
+                       "source_inlining": not args.no_fuse, "packed_samples": (not args.no_fuse) and (not args.no_pack),
                        "parallelism": "projects sharded 1 per GPU; RCCL all-reduce(max) of the peak table only"},
             "roofline": None if not dom else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": dom["frac_of_8TBs"], "frac_of_measured_copy_6.29TBs": dom["frac_of_measured_copy"], "traffic": traffic,
-                "note": ("algorithmic bytes = (8k+8) B/frame x frames (SURVEY 8d); with source inlining the k=64 reads are "
-                         "gathers from the 40 MB sample set, served by L2 / Infinity Cache rather than HBM -- `traffic` is "
-                         "the PMC L2-miss-side byte count per launch (profiles/traffic.json); run with --no-fuse for the "
-                         "edge-buffer model where every algorithmic byte is an HBM byte") if not args.no_fuse else
-                        "edge-buffer model: every algorithmic byte is an HBM byte (PMC traffic == algorithmic bytes)"},
+                "bytes_per_frame": abf.get(dom["kernel"]),
+                "note": ("edge-buffer model (SURVEY 8d): every algorithmic byte is an HBM byte (PMC traffic == algorithmic "
+                         "bytes)") if not fused else
+                        ("source inlining: k_sum's algorithmic bytes are its own gathers, (%dk+8) B/frame -- k looping "
+                         "samples read in place (%s) + one raw-sum write; the k source edge buffers of SURVEY 8(d)'s "
+                         "(8k+8) model never exist.  The gathers re-read the %s sample set ~9x per launch, so they are "
+                         "served by the 256 MB Infinity Cache, not HBM (`traffic` = PMC L2-miss-side bytes per launch, "
+                         "profiles/traffic.json): the bound that applies is the Infinity Cache gather rate "
+                         "(MI355X_MICROARCH.md: 8.6 TB/s for a 38 MB table), frac_of_mall_gather below; "
+                         "`survey_model` restates the same launch time against SURVEY's (8k+8) figure; --no-fuse runs "
+                         "the edge-buffer model itself" % ((4, "packed 16-bit, 4 B", "80 MB") if packed else (8, "f32, 8 B", "40 MB"))),
+                "frac_of_mall_gather_8.6TBs": None if not fused else round(dom["achieved_GBs"] / 8600.0, 4),
+                "survey_model": None if not fused else {
+                    "bytes_per_frame": survey_abf[dom["kernel"]] if dom["kernel"] in survey_abf else None,
+                    "achieved": round(survey_abf.get(dom["kernel"], 0.0) * frames / (dom["avg_ms"] * 1e-3) / 1e9, 1),
+                    "frac": round(survey_abf.get(dom["kernel"], 0.0) * frames / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
             "kernels": kernels,
             "peak_table": [round(float(x), 6) for x in peaks],
             "device_bytes": g.device_bytes(),

@@ -229,35 +229,49 @@ TD_DEV void loop16_quad(const uint32_t* s, uint32_t len, uint32_t idx, uint32_t 
     const u4v q = *reinterpret_cast<const u4v TD_GLOBAL*>(g + (size_t)(idx & 3u) * stride + (idx & ~3u));
     out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
 }
-// all terms kind 3: lane t owns frames m, m+1 (acc0) and m+2, m+3 (acc1) with m = tile + 4t
+// all terms kind 3: lane t owns frames m, m+1 (acc0) and m+2, m+3 (acc1) with m = tile + 4t.
+// Per value: int16 -> f32, x scale, x pan amplitude, x gain, += -- the reference's roundings in the
+// reference's order.  A term whose pan or gain step is skipped (flags) multiplies by 1.0f instead (make_pg
+// leaves the unused amplitudes at 1.0f): the values are finite (they come from int16), so x * 1.0f == x
+// bit for bit and no select is needed.  L/R pairs are kept as 2-vectors so the multiplies and adds can issue packed.
+// Frames at or beyond M pick up garbage-free but meaningless sums; they are zeroed once, after the loop.
+TD_DEV f2v cvt16(uint32_t w) { f2v v; v.x = (float)(int16_t)(w & 0xFFFFu); v.y = (float)(int16_t)(w >> 16); return v; }
 TD_DEV void sum_terms16(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4& acc0, float4& acc1) {
+    f2v c[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) { c[f].x = 0.f; c[f].y = 0.f; }
+    auto add_term = [&](uint32_t j, const uint32_t w[4]) {
+        f2v sc, am, gn;   // (the host leaves l_amp / r_amp / gain at 1.0f when their flag is clear)
+        sc.x = ins[j].scale_l; sc.y = ins[j].scale_r;
+        am.x = ins[j].pg.l_amp; am.y = ins[j].pg.r_amp;
+        gn.x = gn.y = ins[j].pg.gain;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f2v v = cvt16(w[f]) * sc;
+            v = v * am;
+            v = v * gn;
+            c[f] = c[f] + v;
+        }
+    };
+    auto gather = [&](uint32_t j, uint32_t w[4]) {
+        const uint32_t len = (uint32_t)ins[j].len;
+        loop16_quad(reinterpret_cast<const uint32_t*>(ins[j].p), len, barrett_mod((uint32_t)ins[j].t0 + m, len, ins[j].magic), w);
+    };
     uint32_t j = 0;
     for (; j + 4 <= k; j += 4) {
         uint32_t w[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t len = (uint32_t)ins[j + u].len;
-            loop16_quad(reinterpret_cast<const uint32_t*>(ins[j + u].p), len, barrett_mod((uint32_t)ins[j + u].t0 + m, len, ins[j + u].magic), w[u]);
-        }
+        for (int u = 0; u < 4; ++u) gather(j + u, w[u]);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float sl = ins[j + u].scale_l, sr = ins[j + u].scale_r;
-            const PanGain pg = term_pg(ins, j + u);
-            const float2 f0 = unpack16(w[u][0], sl, sr), f1 = unpack16(w[u][1], sl, sr), f2 = unpack16(w[u][2], sl, sr), f3 = unpack16(w[u][3], sl, sr);
-            acc0 = add4(acc0, zero_tail(epilogue4(make_float4(f0.x, f0.y, f1.x, f1.y), pg), m, M));
-            acc1 = add4(acc1, zero_tail(epilogue4(make_float4(f2.x, f2.y, f3.x, f3.y), pg), m + 2u, M));
-        }
+        for (int u = 0; u < 4; ++u) add_term(j + u, w[u]);
     }
     for (; j < k; ++j) {
         uint32_t w[4];
-        const uint32_t len = (uint32_t)ins[j].len;
-        loop16_quad(reinterpret_cast<const uint32_t*>(ins[j].p), len, barrett_mod((uint32_t)ins[j].t0 + m, len, ins[j].magic), w);
-        const float sl = ins[j].scale_l, sr = ins[j].scale_r;
-        const PanGain pg = term_pg(ins, j);
-        const float2 f0 = unpack16(w[0], sl, sr), f1 = unpack16(w[1], sl, sr), f2 = unpack16(w[2], sl, sr), f3 = unpack16(w[3], sl, sr);
-        acc0 = add4(acc0, zero_tail(epilogue4(make_float4(f0.x, f0.y, f1.x, f1.y), pg), m, M));
-        acc1 = add4(acc1, zero_tail(epilogue4(make_float4(f2.x, f2.y, f3.x, f3.y), pg), m + 2u, M));
+        gather(j, w);
+        add_term(j, w);
     }
+    acc0 = zero_tail(make_float4(c[0].x, c[0].y, c[1].x, c[1].y), m, M);
+    acc1 = zero_tail(make_float4(c[2].x, c[2].y, c[3].x, c[3].y), m + 2u, M);
 }
 
 TD_DEV void sum_inputs_pairs(const InTerm* ins_generic, uint32_t k, uint32_t term_mode, uint32_t m0, uint32_t m1, uint32_t M,
