@@ -802,7 +802,8 @@ static int aux_stream_of(int fam) {
 struct BandPlan {
     bool parallel = false;
     uint32_t S = 0, W = 0, Ws = 0, nseg = 0;
-    float2* tmp = nullptr;
+    float2* tmp = nullptr;    // materialised input sum
+    float2* tmpq = nullptr;   // ... and its planar-in-4 copy (warm-up input)
     size_t blk_peaks_off = 0;
 };
 static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
@@ -934,8 +935,10 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         BandPlan bp = plan_band(g, v, M);
                         if (bp.parallel) {
                             bp.tmp = take_buffer(g);
-                            if (!bp.tmp) return fail("termdaw_amd: out of device memory for edge buffers");
+                            bp.tmpq = take_buffer(g);
+                            if (!bp.tmp || !bp.tmpq) return fail("termdaw_amd: out of device memory for edge buffers");
                             level_tmp.push_back(bp.tmp);
+                            level_tmp.push_back(bp.tmpq);
                             band_plan[vi] = bp;
                             fam_v[F_BAND_SPEC].push_back(vi);
                         } else {
@@ -1114,6 +1117,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         SumDesc x{};
                         const bool presum = band_plan.count(vi) != 0;
                         x.out = presum ? band_plan[vi].tmp : g->vbuf[vi];
+                        x.out_q4 = presum ? band_plan[vi].tmpq : nullptr;
                         x.k = (uint32_t)g->edges[vi].size();
                         x.mode = v.kind == K_NORMALIZE ? 1u : (presum ? 2u : 0u);
                         x.term_mode = term_mode[vi];
@@ -1218,6 +1222,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         const BandPlan& bp = band_plan[vi];
                         BandSpecDesc x{};
                         x.x = bp.tmp;
+                        x.xq4 = bp.tmpq;
                         x.out = g->vbuf[vi];
                         x.state = &g->dstate[v.state_slot].band;
                         x.nseg = bp.nseg;

@@ -68,6 +68,10 @@ struct SumDesc {
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
     uint32_t pad;
     PanGain pg;
+    // mode 2: a second copy of the raw sum, planar within every aligned 4-frame block --
+    // {l0 l1 l2 l3}{r0 r1 r2 r3} instead of {l0 r0 l1 r1}{l2 r2 l3 r3} -- the form k_band_spec's warm-up
+    // walks (one register = one chain's next four inputs).  Same size and word addresses as `out`.
+    float2* out_q4;
 };
 
 // Normalize pass B: running max over the block peaks (`*max = buf_max.max(*max)`), buf.scale(len, 1.0 / max)
@@ -224,6 +228,7 @@ struct BandDesc {
 struct BandJob { uint32_t begin, end; float y[4]; uint32_t pad[2]; };   // frames [begin, end) with parked state y
 struct BandSpecDesc {
     const float2* x;        // summed input of the vertex, materialised (sum_inputs, no epilogue)
+    const float2* xq4;      // the same frames, planar within 4-frame blocks (SumDesc::out_q4)
     float2* out;
     BandState* state;       // carried across chunks
     float* seg_start;       // [nseg][4] state on entry (after warm-up)

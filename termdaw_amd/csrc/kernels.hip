@@ -317,6 +317,21 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
     store_pair(d.out, m0, M, a0);
     store_pair(d.out, m1, M, a1);
     if (d.mode == 2) {
+        if (!quad_map) {
+            // planar-in-4 copy: lanes 2u / 2u+1 hold frames 4u..4u+3; the even lane assembles the L word, the
+            // odd lane the R word, each with its neighbour's two values (DPP quad_perm [1,0,3,2]) and stores
+            // it at its own word address.  Only whole blocks are written (the warm-up never reads others).
+            auto nb = [](float v) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+            };
+            const bool odd = (threadIdx.x & 1u) != 0u;
+            const float n0x = nb(a0.x), n0y = nb(a0.y), n0z = nb(a0.z), n0w = nb(a0.w);
+            const float n1x = nb(a1.x), n1y = nb(a1.y), n1z = nb(a1.z), n1w = nb(a1.w);
+            const float4 q0 = odd ? make_float4(n0y, n0w, a0.y, a0.w) : make_float4(a0.x, a0.z, n0x, n0z);
+            const float4 q1 = odd ? make_float4(n1y, n1w, a1.y, a1.w) : make_float4(a1.x, a1.z, n1x, n1z);
+            if ((m0 | 3u) < M) gstore4(d.out_q4 + m0, q0);
+            if ((m1 | 3u) < M) gstore4(d.out_q4 + m1, q1);
+        }
         // Liveness of the tile's four 256-frame blocks (threads 0..127 / 128..255 x first / second frame pair):
         // the block's absolute peak, or -1 when every frame of the block is bit-identical (a held constant
         // parks the filter state just like silence does).
@@ -851,24 +866,35 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         const uint32_t w = (frame >> 1) + c;
         return gload4(x4 + min(w, M2 - 1u));   // clamped: frames past the end are never stepped over
     };
-    // (the broadcasts are cross-lane operations: they must execute unconditionally, the per-lane channel
-    // select comes after)
-#define TD_BAND_UNPACK(J)                                                                          \
-    const float bx_##J = quad_bcast<J>(a.x), by_##J = quad_bcast<J>(a.y);                          \
-    const float bz_##J = quad_bcast<J>(a.z), bw_##J = quad_bcast<J>(a.w);                          \
-    const float e0_##J = ch ? by_##J : bx_##J;                                                     \
-    const float e1_##J = ch ? bw_##J : bz_##J;
-    // warm-up: recurrence only.  n and start are multiples of 32 (S and W are), so the loop runs in batches
-    // of 32 frames: four quad-wide fetches (256 B per quad) issued one whole batch ahead -- ~32 steps of
-    // dependent VALU (3 ops per step) cover an Infinity Cache / L2 round trip.
-#define TD_BAND_STEP8(A)                                                                           \
-    {                                                                                              \
-        const float4 a = A;                                                                        \
-        TD_BAND_UNPACK(0) TD_BAND_UNPACK(1) TD_BAND_UNPACK(2) TD_BAND_UNPACK(3)                    \
-        y = y + gam * (e0_0 - y); y = y + gam * (e1_0 - y);                                        \
-        y = y + gam * (e0_1 - y); y = y + gam * (e1_1 - y);                                        \
-        y = y + gam * (e0_2 - y); y = y + gam * (e1_2 - y);                                        \
-        y = y + gam * (e0_3 - y); y = y + gam * (e1_3 - y);                                        \
+    // warm-up: recurrence only, fed from the planar-in-4 copy: lane c of the quad loads 16-byte word c of an
+    // 8-frame group = {L 0..3 | R 0..3 | L 4..7 | R 4..7}, so step j of the group needs register j & 3 of lane
+    // (j >> 2) * 2 + ch -- a DPP quad_perm ([0,1,0,1] / [2,3,2,3]) applied right in the subtract's operand.
+    // One 64-byte fetch per quad per 8 steps, three dependent VALU instructions per step and nothing else.
+    // n and start are multiples of 32 (S and W are), so the loop runs in batches of 32 frames: four fetches
+    // issued one whole batch ahead -- ~32 steps of dependent VALU cover an Infinity Cache / L2 round trip.
+    const float4* __restrict__ q4 = reinterpret_cast<const float4*>(d.xq4);
+    auto fetchq = [&](uint32_t frame) -> float4 {            // frame is a multiple of 8 and below start
+        return gload4(q4 + (frame >> 1) + c);
+    };
+    // The eight steps are written as one instruction block: the compiler's DPP hazard rule also pads a DPP
+    // instruction whose NON-DPP operand (y, just written by the previous add) is fresh -- 3.3 ns of s_nop per
+    // 7.7 ns step.  The rule that matters in hardware is about the DPP-read register; those are load results,
+    // and the one s_nop at the top covers a compiler copy placed right before the block.
+#define TD_BAND_S(X, PERM)                                                                          \
+    "v_sub_f32_dpp %1, " X ", %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"      \
+    "v_mul_f32 %1, %2, %1\n"                                                                        \
+    "v_add_f32 %0, %0, %1\n"
+#define TD_BAND_STEP8(A)                                                                            \
+    {                                                                                               \
+        const float4 a = A;                                                                         \
+        float t_;                                                                                   \
+        asm volatile("s_nop 1\n"                                                                    \
+                     TD_BAND_S("%3", "[0,1,0,1]") TD_BAND_S("%4", "[0,1,0,1]")                      \
+                     TD_BAND_S("%5", "[0,1,0,1]") TD_BAND_S("%6", "[0,1,0,1]")                      \
+                     TD_BAND_S("%3", "[2,3,2,3]") TD_BAND_S("%4", "[2,3,2,3]")                      \
+                     TD_BAND_S("%5", "[2,3,2,3]") TD_BAND_S("%6", "[2,3,2,3]")                      \
+                     : "+v"(y), "=&v"(t_)                                                           \
+                     : "v"(gam), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));                           \
     }
     // Warm-up length.  The long warm-up W covers a full-scale tail decaying to the denormal floor (needed when
     // the segment sits in or after a silence or a held constant); when the whole short window Ws is live
@@ -902,13 +928,13 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     auto seed = [&]() { if (n == my_begin) y = seed_val; };
     if (n + 32u <= start && (n & 31u) == 0u) {
         // ping-pong register sets A / B (no copies): while A's 32 steps retire, B's four loads stay in flight
-        float4 a0 = fetch8(n), a1 = fetch8(n + 8u), a2 = fetch8(n + 16u), a3 = fetch8(n + 24u);
+        float4 a0 = fetchq(n), a1 = fetchq(n + 8u), a2 = fetchq(n + 16u), a3 = fetchq(n + 24u);
         while (n + 64u <= start) {
-            const float4 b0 = fetch8(n + 32u), b1 = fetch8(n + 40u), b2 = fetch8(n + 48u), b3 = fetch8(n + 56u);
+            const float4 b0 = fetchq(n + 32u), b1 = fetchq(n + 40u), b2 = fetchq(n + 48u), b3 = fetchq(n + 56u);
             seed();
             TD_BAND_STEP8(a0) TD_BAND_STEP8(a1) TD_BAND_STEP8(a2) TD_BAND_STEP8(a3)
             n += 32u;
-            a0 = fetch8(n + 32u); a1 = fetch8(n + 40u); a2 = fetch8(n + 48u); a3 = fetch8(n + 56u);
+            a0 = fetchq(n + 32u); a1 = fetchq(n + 40u); a2 = fetchq(n + 48u); a3 = fetchq(n + 56u);
             seed();
             TD_BAND_STEP8(b0) TD_BAND_STEP8(b1) TD_BAND_STEP8(b2) TD_BAND_STEP8(b3)
             n += 32u;
@@ -920,8 +946,9 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         }
     }
     if ((n & 7u) == 0u)
-        for (; n + 8u <= start; n += 8u) { seed(); TD_BAND_STEP8(fetch8(n)) }
+        for (; n + 8u <= start; n += 8u) { seed(); TD_BAND_STEP8(fetchq(n)) }
 #undef TD_BAND_STEP8
+#undef TD_BAND_S
     for (; n < start; ++n) { seed(); y = y + gam * (gload1(xf + 2u * n + ch) - y); }
     seed();   // n == start == my_begin: segment 0 / no warm-up
     if (live) d.seg_start[seg * 4u + c] = y;
@@ -952,7 +979,6 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     } else {
         for (n = start; n < end; ++n) { const float2 x = d.x[n]; step(n, x.x, x.y); }
     }
-#undef TD_BAND_UNPACK
     if (live) d.seg_final[seg * 4u + c] = y;
     const float s0 = quad_bcast<0>(same ? 1.0f : 0.0f), s1 = quad_bcast<1>(same ? 1.0f : 0.0f);
     const float z0 = quad_bcast<0>(zero ? 1.0f : 0.0f), z1 = quad_bcast<1>(zero ? 1.0f : 0.0f);
