@@ -1248,7 +1248,8 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         scratch_field(o, offsetof(BandSpecDesc, blk_peaks), band_plan[vs[i]].blk_peaks_off);
                         scratch_field(o, offsetof(BandSpecDesc, seg_x0), scratch((size_t)ns * 8));
                         scratch_field(o, offsetof(BandSpecDesc, jobs), scratch((size_t)ns * sizeof(BandJob)));
-                        const size_t so = scratch(16);
+                        scratch_field(o, offsetof(BandSpecDesc, seg_job), scratch((size_t)ns * 4));
+                        const size_t so = scratch(32);
                         scratch_field(o, offsetof(BandSpecDesc, stats), so);
                         g->band_stats_off.push_back(so);
                     }
@@ -1345,7 +1346,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
-                case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
                 case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, (uint32_t)M, s); break;
             }

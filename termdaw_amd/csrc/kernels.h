@@ -221,7 +221,8 @@ struct BandDesc {
 //   a guess, records the state it entered the segment with and the state it left with, and writes the
 //   segment's output.  k_band_fix then checks, bit for bit, that every segment entered with exactly the
 //   state its predecessor left with -- by induction from the exactly-known first segment this proves the
-//   whole output exact -- and recomputes (only) segments where the check fails.  The usual failures are
+//   whole output exact -- and recomputes (only) segments where the check fails, keeping seg_start honest
+//   (= the entry state the stored output was computed from) so that the check can simply be repeated.  The usual failures are
 //   constant or silent input stretches, where f32 trajectories park on different sticky points: there the
 //   true state is a fixed point, so k_band_fix skips the whole stretch in one step and leaves its output
 //   (state fixed, input known) to the parallel k_band_fill.
@@ -237,7 +238,8 @@ struct BandSpecDesc {
     uint32_t* seg_flags;    // [nseg] bit0: input bit-identical over the whole segment, bit1: input all (+-)0
     float2* seg_x0;         // [nseg] first input frame of the segment
     BandJob* jobs;          // [nseg] parked stretches found by k_band_fix, executed by k_band_fill
-    uint32_t* stats;        // [4]: mismatches found, segments recomputed, segments parked, jobs
+    uint32_t* seg_job;      // [nseg] index of the job whose stretch covers (part of) the segment, or ~0
+    uint32_t* stats;        // [8]: cascades repaired, segments recomputed, segments parked, jobs, ticket (zeroed by k_band_spec)
     uint32_t nseg, S, W;
     uint32_t Ws;            // short warm-up (k_band_spec picks W or Ws per segment from blk_peaks)
     float live_thr;         // quietest / loudest block peak ratio above which a window counts as live (1e-6)
@@ -275,7 +277,7 @@ void launch_sample_pack(const float* l, const float* r, const float* max_l, cons
 void launch_sample_pack16(const float* l, const float* r, uint32_t* packed, uint32_t n, uint32_t* not_int16, hipStream_t s);
 
 void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
-void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
 void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, hipStream_t s);

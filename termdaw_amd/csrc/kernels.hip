@@ -842,6 +842,7 @@ TD_DEV float2 band_out(const BandCoef& k, float l, float r, float ll, float lr, 
 
 __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __restrict__ descs, uint32_t M) {
     const BandSpecDesc& d = descs[blockIdx.y];
+    if (blockIdx.x == 0 && threadIdx.x < 8u) d.stats[threadIdx.x] = 0u;   // k_band_fix's counters and ticket
     const uint32_t c = threadIdx.x & 3u;                       // chain: 0 low L, 1 low R, 2 high L, 3 high R
     const uint32_t seg_raw = blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2);
     if (blockIdx.x * (kThreads / 4) >= d.nseg) return;         // whole workgroup beyond this vertex' segments
@@ -989,201 +990,297 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     }
 }
 
-// One workgroup per vertex.  Phase A (1024 lanes): bitmap (LDS) of segments whose entry state differs from
-// the predecessor's exit state.  Phase B (wave 0; lanes 0..3 = the four chains, the other lanes mirror
-// them): repair cascades, in segment order.
-constexpr int kFixThreads = 1024;
+// One workgroup per vertex, 16 waves.  Rounds of
+//   Phase A (1024 lanes): bitmap + ordered list (LDS) of the segments whose entry state differs from the
+//            predecessor's exit state ("events");
+//   Phase B: the waves take the events round-robin and repair each one's cascade INDEPENDENTLY, assuming the
+//            predecessor's stored exit state is the true one -- true for the first event, and for every
+//            event that no earlier cascade reaches.  A cascade never enters a segment another event owns.
+// until Phase A finds nothing.  Every repair keeps the arrays honest -- seg_start = the entry state the
+// segment's stored output and seg_final were computed from -- so the final all-clear Phase A IS the proof
+// (induction from the exactly-known first segment); an optimistic repair that started from a stale state
+// shows up as a mismatch in the next round.  The lowest event of a round is always repaired for good, so
+// the rounds terminate; in practice events are far apart (one per silent stretch) and two rounds do.
+constexpr int kFixThreads = 1024, kFixWaves = kFixThreads / 64;
 constexpr uint32_t kFixMaxSegs = 131072;   // LDS bitmap capacity (host picks S accordingly)
-__global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __restrict__ descs, uint32_t M) {
-    const BandSpecDesc& d = descs[blockIdx.x];
-    __shared__ uint32_t bitmap[kFixMaxSegs / 32];
-    __shared__ uint32_t found_s;
-    __shared__ float2 xs[kBandMaxS];
-    __shared__ __attribute__((aligned(16))) float ys[kBandMaxS * 4];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    const uint32_t nwords = (d.nseg + 31u) / 32u;
-    const uint4* S4 = reinterpret_cast<const uint4*>(d.seg_start);
+constexpr uint32_t kFixMaxEvents = 2048;   // events repaired per round (the rest wait for the next round)
+constexpr uint32_t kNoJob = 0xFFFFFFFFu;
+
+// One event: wave-wide.  Lanes 0..3 = the four chains on the TRUE trajectory, lanes 4..7 re-run the
+// speculative one from the entry state pass 1 used (as soon as the two are bit-identical the rest of the
+// segment -- output and exit state -- is already right; checked every 8 steps); the other lanes idle along
+// as copies of quad 0.  xs / ys: this wave's LDS staging for 64 frames of input / state.
+TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, uint32_t lo, uint32_t hi, const uint32_t* bitmap,
+                             float2* xs, float* ys, uint32_t& recomputed, uint32_t& parked_segs) {
+    const uint32_t lane = threadIdx.x & 63u, c = lane & 3u, ch = c & 1u;
+    const float gam = (c & 2u) ? d.hgamma : d.lgamma;
+    const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
+    uint32_t* Su = reinterpret_cast<uint32_t*>(d.seg_start);
+    uint32_t* Fu = reinterpret_cast<uint32_t*>(d.seg_final);
+    uint4* S4 = reinterpret_cast<uint4*>(d.seg_start);
     uint4* F4 = reinterpret_cast<uint4*>(d.seg_final);
-    if (tid == 0) found_s = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < d.nseg; base += kFixThreads) {
-        const uint32_t s = base + tid;
-        bool mis = false;
-        if (s > 0u && s < d.nseg) {
-            const uint4 a = S4[s], p = F4[s - 1u];
-            mis = a.x != p.x || a.y != p.y || a.z != p.z || a.w != p.w;
+    const uint2* X0 = reinterpret_cast<const uint2*>(d.seg_x0);
+    const float* xsf = reinterpret_cast<const float*>(xs);
+    auto flagged = [&](uint32_t s) { return ((bitmap[(s - lo) >> 5] >> ((s - lo) & 31u)) & 1u) != 0u; };   // lo <= s < hi
+    // exit state of the predecessor (lanes 0..3 own every store to seg_final this wave makes)
+    float y = __shfl(__uint_as_float(Fu[(seg - 1u) * 4u + c]), (int)c, 64);
+    bool first_round = true;
+    for (;;) {
+        const uint32_t start = seg * d.S, end = min(start + d.S, M), len = end - start;
+        // everything this round needs from global memory, issued together (one round trip)
+        const uint32_t flags = d.seg_flags[seg];
+        const uint2 x0 = X0[seg];
+        const uint32_t su = Su[seg * 4u + c];
+        const uint32_t fu_old = Fu[seg * 4u + c];
+        if (!first_round) {
+            if (flagged(seg)) break;   // another event's segment: its own cascade (this round or the next) takes over
+            if (__any((lane < 4u && su != __float_as_uint(y)) ? 1 : 0) == 0) break;   // entered with exactly the new state
         }
-        const unsigned long long m = __ballot(mis ? 1 : 0);
-        if (lane == 0u && (s >> 5) < nwords) {
-            bitmap[s >> 5] = (uint32_t)m;
-            if ((s >> 5) + 1u < kFixMaxSegs / 32) bitmap[(s >> 5) + 1u] = (uint32_t)(m >> 32);
-            if (m) atomicAdd(&found_s, (uint32_t)__popcll(m));
-        }
-    }
-    __syncthreads();
-    const uint32_t found = found_s;
-    uint32_t recomputed = 0, parked_segs = 0, njobs = 0;
-    if (tid < 64u) {
-        if (found) {
-            const uint32_t c = lane & 3u, ch = c & 1u;
-            const float gam = (c & 2u) ? d.hgamma : d.lgamma;
-            const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
-                        const uint32_t* Su = reinterpret_cast<const uint32_t*>(d.seg_start);
-            uint32_t* Fu = reinterpret_cast<uint32_t*>(d.seg_final);
-            const uint2* X0 = reinterpret_cast<const uint2*>(d.seg_x0);
-            uint32_t seg = 1;
-            while (seg < d.nseg) {
-                // next flagged segment at or after seg (wave-uniform scan of the bitmap)
-                uint32_t w = seg >> 5, bits = bitmap[w] & (0xFFFFFFFFu << (seg & 31u));
-                while (bits == 0u && ++w < nwords) bits = bitmap[w];
-                if (w >= nwords) break;
-                seg = w * 32u + (uint32_t)__ffs((int)bits) - 1u;
-                // exit state of the predecessor: lanes 0..3 own every store to seg_final made in this kernel
-                float y = __shfl(__uint_as_float(Fu[(seg - 1u) * 4u + c]), (int)c, 64);
-                // cascade: recompute from y until a recomputed exit state reproduces the stored one, or the
-                // next segment is found to have entered with exactly the new exit state
-                bool first_round = true;
-                for (;;) {
-                    const uint32_t start = seg * d.S, end = min(start + d.S, M), len = end - start;
-                    // everything this round needs from global memory, issued together (one round trip): the
-                    // segment's flags / first frame / speculative entry state / stored exit state and the first
-                    // 64 input frames.  The input is staged in LDS 64 frames at a time, only as far as the
-                    // stepping gets (most repairs park or coalesce within the first few frames).
-                    const uint32_t flags = d.seg_flags[seg];
-                    const uint2 x0 = X0[seg];
-                    const uint32_t su = Su[seg * 4u + c];
-                    const uint32_t fu_old = Fu[seg * 4u + c];
-                    if (lane < len) xs[lane] = gload2(d.x + start + lane);
-                    uint32_t staged = min(64u, len);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    if (!first_round && __any((lane < 4u && su != __float_as_uint(y)) ? 1 : 0) == 0) {
-                        ++seg;   // this segment entered with exactly the new state: its pass-1 result stands
-                        break;
-                    }
-                    first_round = false;
-                    uint32_t last = seg;   // last segment covered by this round
-                    const float* xsf = reinterpret_cast<const float*>(xs);
-                    // Quad 0 (lanes 0..3) follows the TRUE trajectory from y; quad 1 (lanes 4..7) re-runs the
-                    // speculative one from the entry state pass 1 used.  As soon as the two are bit-identical
-                    // the rest of the segment -- output and exit state -- is already right (checked every 8
-                    // steps).  The other lanes idle along as copies of quad 0.
-                    float yy = (lane >= 4u && lane < 8u) ? __uint_as_float(su) : y;
-                    uint32_t n = 0;
-                    bool parked = false, coalesced = false;
-                    while (n < len && !parked && !coalesced) {
-                        if (n >= staged) {
-                            if (staged + lane < len) xs[staged + lane] = gload2(d.x + start + staged + lane);
-                            staged = min(staged + 64u, len);
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                        }
-                        const uint32_t nb = min(8u, len - n);
-                        float xv[8];
+        first_round = false;
+        if (lane < 4u) Su[seg * 4u + c] = __float_as_uint(y);   // the entry state everything below is computed from
+        uint32_t last = seg;   // last segment covered by this round
+        uint32_t job = kNoJob;
+        float yy = (lane >= 4u && lane < 8u) ? __uint_as_float(su) : y;
+        uint32_t n = 0;
+        bool parked = false, coalesced = false;
+        while (n < len && !parked && !coalesced) {
+            // the next 64 frames of input (most repairs park or coalesce within the first few frames)
+            const uint32_t cl = min(64u, len - n);
+            if (lane < cl) xs[lane] = gload2(d.x + start + n + lane);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            uint32_t k = 0;
+            while (k < cl && !parked && !coalesced) {
+                const uint32_t nb = min(8u, cl - k);
+                float xv[8];
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) xv[u] = (uint32_t)u < nb ? xsf[2u * (n + u) + ch] : 0.0f;
+                for (int u = 0; u < 8; ++u) xv[u] = (uint32_t)u < nb ? xsf[2u * (k + u) + ch] : 0.0f;
 #pragma unroll
-                        for (int u = 0; u < 8; ++u) {
-                            if ((uint32_t)u >= nb || parked) continue;
-                            const float yn = yy + gam * (xv[u] - yy);
-                            const bool still = __float_as_uint(yn) == __float_as_uint(yy);
-                            yy = yn;
-                            if (lane < 4u) ys[(n + u) * 4u + c] = yy;
-                            if (!flags || !__all((lane >= 4u || still) ? 1 : 0)) continue;
-                            // All four chains sit on a fixed point of this frame's input.  It stays one while
-                            // the input is (A) bit-identical, or (B) any-signed zero with every moving chain
-                            // non-zero (x - y is then the same for +0 and -0).  The state is parked for the rest
-                            // of this segment and for every following segment of the same class.
-                            const bool zero_ok = (flags & 2u) && __all((lane >= 4u || gam == 0.0f || yy != 0.0f) ? 1 : 0);
-                            const bool const_ok = (flags & 1u) != 0u;
-                            if (!zero_ok && !const_ok) continue;
-                            uint32_t e = seg + 1u;
-                            for (;;) {   // extend over following segments, 64 at a time
-                                const uint32_t s2 = e + lane;
-                                bool ok = false;
-                                if (s2 < d.nseg) {
-                                    const uint32_t f2 = d.seg_flags[s2];
-                                    if (zero_ok) ok = (f2 & 2u) != 0u;
-                                    else { const uint2 x2 = X0[s2]; ok = (f2 & 1u) && x2.x == x0.x && x2.y == x0.y; }
-                                }
-                                const unsigned long long m = __ballot(ok ? 1 : 0);
-                                const uint32_t run = m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1u;
-                                e += run;
-                                if (run < 64u) break;
-                            }
-                            const float y0 = quad_bcast<0>(yy), y1 = quad_bcast<1>(yy), y2 = quad_bcast<2>(yy), y3 = quad_bcast<3>(yy);
-                            if (lane == 0u) {
-                                BandJob j;
-                                j.begin = start + n + (uint32_t)u + 1u;
-                                j.end = min(e * d.S, M);
-                                j.y[0] = y0; j.y[1] = y1; j.y[2] = y2; j.y[3] = y3;
-                                j.pad[0] = j.pad[1] = 0u;
-                                d.jobs[njobs] = j;
-                            }
-                            ++njobs;
-                            parked_segs += e - seg;
-                            last = e - 1u;
-                            parked = true;
-                            n += (uint32_t)u + 1u;
+                for (int u = 0; u < 8; ++u) {
+                    if ((uint32_t)u >= nb || parked) continue;
+                    const float yn = yy + gam * (xv[u] - yy);
+                    const bool still = __float_as_uint(yn) == __float_as_uint(yy);
+                    yy = yn;
+                    if (lane < 4u) ys[(k + u) * 4u + c] = yy;
+                    if (!flags || !__all((lane >= 4u || still) ? 1 : 0)) continue;
+                    // All four chains sit on a fixed point of this frame's input.  It stays one while the input
+                    // is (A) bit-identical, or (B) any-signed zero with every moving chain non-zero (x - y is
+                    // then the same for +0 and -0).  The state is parked for the rest of this segment and for
+                    // every following segment of the same class (up to the next event's segment).
+                    const bool zero_ok = (flags & 2u) && __all((lane >= 4u || gam == 0.0f || yy != 0.0f) ? 1 : 0);
+                    const bool const_ok = (flags & 1u) != 0u;
+                    if (!zero_ok && !const_ok) continue;
+                    uint32_t slot = 0;
+                    if (lane == 0u) slot = atomicAdd(&d.stats[3], 1u);
+                    slot = (uint32_t)__shfl((int)slot, 0, 64);
+                    if (slot >= d.nseg) {   // job table full (only after many superseded rounds): keep stepping
+                        if (lane == 0u) atomicSub(&d.stats[3], 1u);
+                        continue;
+                    }
+                    uint32_t e = seg + 1u;
+                    for (;;) {   // extend over following segments, 64 at a time
+                        const uint32_t s2 = e + lane;
+                        bool ok = false;
+                        if (s2 < hi && !flagged(s2)) {
+                            const uint32_t f2 = d.seg_flags[s2];
+                            if (zero_ok) ok = (f2 & 2u) != 0u;
+                            else { const uint2 x2 = X0[s2]; ok = (f2 & 1u) && x2.x == x0.x && x2.y == x0.y; }
                         }
-                        if (!parked) {
-                            n += nb;
-                            const float twin = __shfl_xor(yy, 4, 64);
-                            coalesced = __all((lane >= 8u || __float_as_uint(twin) == __float_as_uint(yy)) ? 1 : 0) != 0;
-                        }
+                        const unsigned long long m = __ballot(ok ? 1 : 0);
+                        const uint32_t run = m == ~0ull ? 64u : (uint32_t)__ffsll((long long)~m) - 1u;
+                        e += run;
+                        if (run < 64u) break;
                     }
-                    y = __shfl(yy, (int)c, 64);   // true state, every lane
-                    // outputs of the n frames stepped above, 64 at a time
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    for (uint32_t q = lane; q < n; q += 64u) {
-                        const float2 x = xs[q];
-                        const float4 s = reinterpret_cast<const float4*>(ys)[q];
-                        d.out[start + q] = epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), d.pg);
+                    const float y0 = quad_bcast<0>(yy), y1 = quad_bcast<1>(yy), y2 = quad_bcast<2>(yy), y3 = quad_bcast<3>(yy);
+                    if (lane == 0u) {
+                        BandJob j;
+                        j.begin = start + n + k + (uint32_t)u + 1u;
+                        j.end = min(e * d.S, M);
+                        j.y[0] = y0; j.y[1] = y1; j.y[2] = y2; j.y[3] = y3;
+                        j.pad[0] = j.pad[1] = 0u;
+                        d.jobs[slot] = j;
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    if (coalesced && !parked) {   // pass 1's exit state of this segment stands: cascade over
-                        ++recomputed;
-                        ++seg;
-                        break;
-                    }
-                    recomputed += last - seg + 1u;
-                    const uint32_t fu_cmp = last == seg ? fu_old : Fu[last * 4u + c];
-                    const bool changed = __any((lane < 4u && fu_cmp != __float_as_uint(y)) ? 1 : 0) != 0;
-                    if (lane < 4u) Fu[last * 4u + c] = __float_as_uint(y);
-                    seg = last + 1u;
-                    if (!changed || seg >= d.nseg) break;
+                    job = slot;
+                    parked_segs += e - seg;
+                    last = e - 1u;
+                    parked = true;
+                    k += (uint32_t)u + 1u;
+                }
+                if (!parked) {
+                    k += nb;
+                    const float twin = __shfl_xor(yy, 4, 64);
+                    coalesced = __all((lane >= 8u || __float_as_uint(twin) == __float_as_uint(yy)) ? 1 : 0) != 0;
                 }
             }
+            // outputs of the k frames stepped in this batch
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (lane < k) {
+                const float2 x = xs[lane];
+                const float4 s = reinterpret_cast<const float4*>(ys)[lane];
+                d.out[start + n + lane] = epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), d.pg);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            n += k;
         }
-        if (lane < 4u) reinterpret_cast<uint32_t*>(d.state)[lane] = reinterpret_cast<const uint32_t*>(d.seg_final)[(d.nseg - 1u) * 4u + lane];
-        if (lane == 0u) {
-            d.state->first = 0u;
-            d.stats[0] = found;
-            d.stats[1] = recomputed;
-            d.stats[2] = parked_segs;
-            d.stats[3] = njobs;
+        y = __shfl(yy, (int)c, 64);   // true state, every lane
+        if (coalesced && !parked) {   // pass 1's exit state of this segment stands: cascade over
+            ++recomputed;
+            if (lane == 0u) d.seg_job[seg] = kNoJob;
+            break;
         }
+        recomputed += last - seg + 1u;
+        const uint32_t fu_cmp = last == seg ? fu_old : Fu[last * 4u + c];
+        const bool changed = __any((lane < 4u && fu_cmp != __float_as_uint(y)) ? 1 : 0) != 0;
+        if (parked) {
+            // the parked state is the exit state of every covered segment and the entry state of all but the first
+            const uint4 yb = make_uint4(__float_as_uint(quad_bcast<0>(y)), __float_as_uint(quad_bcast<1>(y)),
+                                        __float_as_uint(quad_bcast<2>(y)), __float_as_uint(quad_bcast<3>(y)));
+            for (uint32_t s2 = seg + lane; s2 <= last; s2 += 64u) {
+                d.seg_job[s2] = job;
+                F4[s2] = yb;
+                if (s2 > seg) S4[s2] = yb;
+            }
+        } else {
+            if (lane < 4u) Fu[seg * 4u + c] = __float_as_uint(y);
+            if (lane == 0u) d.seg_job[seg] = kNoJob;
+        }
+        seg = last + 1u;
+        if (!changed || seg >= hi) break;   // (a change that reaches the end of the range is the next pass's event)
     }
 }
 
+// Rounds over the segments [lo, hi) (whole workgroup; hi - lo <= kFixMaxSegs).
+struct BandFixLds {
+    uint32_t bitmap[kFixMaxSegs / 32];
+    uint32_t events[kFixMaxEvents];
+    uint32_t wave_cnt[kFixWaves];
+    uint32_t n_events;
+    float2 xs[kFixWaves][64];
+    __attribute__((aligned(16))) float ys[kFixWaves][64 * 4];
+};
+// Returns whether anything had to be repaired (same value in every thread).
+TD_DEV bool band_fix_range(const BandSpecDesc& d, uint32_t M, uint32_t lo, uint32_t hi, BandFixLds& L) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nwords = (hi - lo + 31u) / 32u;
+    const uint4* S4 = reinterpret_cast<const uint4*>(d.seg_start);
+    const uint4* F4 = reinterpret_cast<const uint4*>(d.seg_final);
+    uint32_t cascades = 0, rec = 0, park = 0;
+    bool any = false;
+    for (;;) {
+        if (tid == 0) L.n_events = 0;
+        // ---- Phase A: mismatch bitmap (each wave owns two whole words per pass; four passes' loads in flight)
+        for (uint32_t base = lo; base < hi; base += 4u * kFixThreads) {
+            uint4 a[4], p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t s = base + (uint32_t)u * kFixThreads + tid;
+                if (s > 0u && s < hi) { a[u] = S4[s]; p[u] = F4[s - 1u]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t s = base + (uint32_t)u * kFixThreads + tid;
+                const bool mis = s > 0u && s < hi && (a[u].x != p[u].x || a[u].y != p[u].y || a[u].z != p[u].z || a[u].w != p[u].w);
+                const unsigned long long m = __ballot(mis ? 1 : 0);
+                if (lane == 0u && s < hi) {
+                    L.bitmap[(s - lo) >> 5] = (uint32_t)m;
+                    L.bitmap[((s - lo) >> 5) + 1u] = (uint32_t)(m >> 32);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- ... and the ordered event list: one bitmap word per lane, block-wide exclusive scan of the counts
+        for (uint32_t wbase = 0; wbase < nwords; wbase += kFixThreads) {
+            const uint32_t wi = wbase + tid;
+            uint32_t word = wi < nwords ? L.bitmap[wi] : 0u;
+            const uint32_t cnt = (uint32_t)__popc(word);
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t v = (uint32_t)__shfl_up((int)inc, off, 64);
+                if (lane >= (uint32_t)off) inc += v;
+            }
+            if (lane == 63u) L.wave_cnt[wave] = inc;
+            __syncthreads();
+            uint32_t slot = L.n_events + inc - cnt;
+            for (uint32_t w = 0; w < wave; ++w) slot += L.wave_cnt[w];
+            while (word) {
+                const uint32_t b = (uint32_t)__ffs((int)word) - 1u;
+                word &= word - 1u;
+                if (slot < kFixMaxEvents) L.events[slot] = lo + wi * 32u + b;
+                ++slot;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t t = 0;
+                for (int w = 0; w < kFixWaves; ++w) t += L.wave_cnt[w];
+                L.n_events += t;
+            }
+            __syncthreads();
+        }
+        const uint32_t nev_total = L.n_events;
+        if (nev_total == 0u) break;
+        any = true;
+        // ---- Phase B: independent cascades
+        const uint32_t nev = min(nev_total, kFixMaxEvents);
+        for (uint32_t i = wave; i < nev; i += kFixWaves) {
+            band_fix_cascade(d, M, L.events[i], lo, hi, L.bitmap, L.xs[wave], L.ys[wave], rec, park);
+            ++cascades;
+        }
+        __threadfence();   // the next Phase A reads what the other waves stored
+        __syncthreads();
+    }
+    if (lane == 0u && cascades) { atomicAdd(&d.stats[0], cascades); atomicAdd(&d.stats[1], rec); atomicAdd(&d.stats[2], park); }
+    return any;
+}
+
+// grid (G, vertices): workgroup g first settles its own slice of the segments (cascades stop at the slice
+// end, the slice's first event trusts whatever exit state its left neighbour shows at the time), then the
+// workgroup that finishes LAST (ticket in stats[4]; no spinning) repeats the rounds over all segments --
+// normally one Phase A that finds nothing, otherwise the few events at slice borders -- and its all-clear is the
+// proof for the whole vertex.  stats[] is zeroed by k_band_spec.
+__global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __restrict__ descs, uint32_t M) {
+    const BandSpecDesc& d = descs[blockIdx.y];
+    __shared__ BandFixLds L;
+    __shared__ uint32_t ticket_s;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t G = gridDim.x;
+    const uint32_t per = (((d.nseg + G - 1u) / G) + 63u) & ~63u;
+    const uint32_t lo = min(blockIdx.x * per, d.nseg), hi = min(lo + per, d.nseg);
+    for (uint32_t s = lo + tid; s < hi; s += kFixThreads) d.seg_job[s] = kNoJob;
+    if (G > 1u) {
+        const bool any = lo < hi && band_fix_range(d, M, lo, hi, L);
+        if (any) __threadfence();   // release what this slice's repairs stored
+        __syncthreads();
+        if (tid == 0) ticket_s = atomicAdd(&d.stats[4], any ? 0x10001u : 1u);
+        __syncthreads();
+        if ((ticket_s & 0xFFFFu) != G - 1u) return;
+        // Last workgroup.  If no slice had anything to repair, the slices' own all-clear checks -- together
+        // they compared every segment with its predecessor, and nothing was modified -- are the proof already.
+        if ((ticket_s >> 16) != 0u || any) {
+            __threadfence();   // acquire the other slices' repairs
+            band_fix_range(d, M, 0u, d.nseg, L);
+        }
+    } else {
+        band_fix_range(d, M, 0u, d.nseg, L);
+    }
+    __syncthreads();
+    if (tid < 4u) reinterpret_cast<uint32_t*>(d.state)[tid] = reinterpret_cast<const uint32_t*>(d.seg_final)[(d.nseg - 1u) * 4u + tid];
+    if (tid == 0u) d.state->first = 0u;
+}
+
 // Output of the parked stretches recorded by k_band_fix: the four states are constants, every frame's
-// output follows from its own input frame -- fully parallel.
+// output follows from its own input frame -- fully parallel.  seg_job maps a segment to the job covering it.
 __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __restrict__ descs, uint32_t M) {
     const BandSpecDesc& d = descs[blockIdx.y];
-    const uint32_t njobs = d.stats[3];
-    if (njobs == 0u) return;
+    if (d.stats[3] == 0u) return;
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
     const uint32_t tile0 = blockIdx.x * kTileFrames;
-    // jobs are sorted and disjoint: first job ending after the tile start
-    uint32_t lo = 0, hi = njobs;
-    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (d.jobs[mid].end > tile0) hi = mid; else lo = mid + 1u; }
-    if (lo >= njobs || d.jobs[lo].begin >= min(tile0 + (uint32_t)kTileFrames, M)) return;
     for (uint32_t f = threadIdx.x; f < (uint32_t)kTileFrames; f += kThreads) {
         const uint32_t m = tile0 + f;
         if (m >= M) break;
-        uint32_t j = lo;
-        while (j < njobs && d.jobs[j].end <= m) ++j;
-        if (j >= njobs) break;
+        const uint32_t j = d.seg_job[m / d.S];
+        if (j == kNoJob) continue;
         const BandJob jb = d.jobs[j];
-        if (m < jb.begin) continue;
+        if (m < jb.begin || m >= jb.end) continue;
         const float2 x = d.x[m];
         d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
     }
@@ -1350,9 +1447,10 @@ void launch_band_spec(const BandSpecDesc* d, int n, uint32_t frames, uint32_t ma
     if (!n || !frames) return;
     TD_BATCHED(k_band_spec, (max_nseg + kThreads / 4 - 1) / (kThreads / 4), kThreads, d, n, frames);
 }
-void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {    // vertex index in grid.x
-    if (!n || !frames) return;
-    hipLaunchKernelGGL(k_band_fix, dim3(n), dim3(kFixThreads), 0, s, d, frames);
+void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max_nseg, hipStream_t s) {    // (slice, vertex)
+    if (n <= 0) return;
+    const uint32_t G = std::max(1u, std::min(16u, max_nseg / 512u));
+    hipLaunchKernelGGL(k_band_fix, dim3(G, n), dim3(kFixThreads), 0, s, d, frames);
 }
 void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
