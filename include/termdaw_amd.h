@@ -68,7 +68,17 @@ void td_flowwbank_reset(td_flowwbank* fb);                                /* flo
 /* declare_floww floww.rs:32-38 with the events given directly (add_floww floww.rs:40-48 reads them
  * from MIDI through the un-vendored floww crate). Returns the floww index, or -1. */
 long td_flowwbank_add_events(td_flowwbank* fb, const char* name, const td_event* events, size_t n);
+/* add_floww floww.rs:40-48: a Standard MIDI File through this library's own reader (the floww crate's
+ * read_floww_from_midi is un-vendored; mapping fixed in csrc/midi.h).  Returns the floww index, or -1 with
+ * the reference's "Could not read midi file" message in td_last_error(). */
+long td_flowwbank_add_midi(td_flowwbank* fb, const char* name, const char* path);
 long td_flowwbank_declare_stream(td_flowwbank* fb, const char* name);     /* floww.rs:50-53 */
+/* append_streams floww.rs:55-57 with the packets already decoded (`unpacket` is the floww crate's): appends
+ * events to the named floww.  Returns its new length, or -1 if the name is unknown. */
+long td_flowwbank_append_stream(td_flowwbank* fb, const char* name, const td_event* events, size_t n);
+void td_flowwbank_trim_streams(td_flowwbank* fb);                         /* floww.rs:59-64 */
+/* copy of floww `index` (at most cap events are written); returns its length */
+size_t td_flowwbank_get_events(const td_flowwbank* fb, size_t index, td_event* out, size_t cap);
 long td_flowwbank_get_index(const td_flowwbank* fb, const char* name);    /* floww.rs:66-68 */
 void td_flowwbank_set_time(td_flowwbank* fb, size_t t);                   /* floww.rs:83-86 */
 void td_flowwbank_set_time_to_next_block(td_flowwbank* fb);               /* floww.rs:88-91 */

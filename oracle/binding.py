@@ -70,6 +70,10 @@ def lib():
     sig("orc_fb_free", None, vp)
     sig("orc_fb_add_events", lng, vp, cp, fp, sz)
     sig("orc_fb_get_index", lng, vp, cp)
+    sig("orc_fb_declare_stream", lng, vp, cp)
+    sig("orc_fb_append_stream", lng, vp, cp, fp, sz)
+    sig("orc_fb_trim_streams", None, vp)
+    sig("orc_fb_get_events", sz, vp, sz, fp, sz)
     sig("orc_fb_set_time", None, vp, sz)
     sig("orc_fb_set_time_to_next_block", None, vp)
     sig("orc_fb_start_block", None, vp, sz)
@@ -164,6 +168,22 @@ class FlowwBank:
     def get_index(self, name):
         i = lib().orc_fb_get_index(self.h, name.encode())
         return None if i < 0 else i
+
+    def declare_stream(self, name):
+        return lib().orc_fb_declare_stream(self.h, name.encode())
+
+    def append_stream(self, name, events):
+        a, p = _fa(np.asarray(events, dtype=np.float32).reshape(-1, 3))
+        return lib().orc_fb_append_stream(self.h, name.encode(), p, a.shape[0])
+
+    def trim_streams(self):
+        lib().orc_fb_trim_streams(self.h)
+
+    def get_events(self, index):
+        n = lib().orc_fb_get_events(self.h, index, None, 0)
+        buf = np.zeros((max(n, 1), 3), np.float32)
+        lib().orc_fb_get_events(self.h, index, buf.ctypes.data_as(C.POINTER(C.c_float)), n)
+        return buf[:n]
 
     def set_time(self, t):
         lib().orc_fb_set_time(self.h, t)

@@ -473,6 +473,26 @@ struct FlowwBank {  // floww.rs:6-16
         names[name] = index;
         return index;
     }
+    std::vector<size_t> stream_list;
+    size_t declare_stream(const std::string& name) {  // floww.rs:50-53
+        size_t index = declare_floww(name, {});
+        stream_list.push_back(index);
+        return index;
+    }
+    // floww.rs:55-57 hands FlowwPackets to the floww crate's `unpacket` (un-vendored); its visible effect on
+    // the bank -- events appended to the named floww -- is restated here with the events given directly.
+    long append_stream(const std::string& name, const std::vector<Event>& ev) {
+        long i = get_index(name);
+        if (i < 0) return -1;
+        flowws[(size_t)i].insert(flowws[(size_t)i].end(), ev.begin(), ev.end());
+        return (long)flowws[(size_t)i].size();
+    }
+    void trim_streams() {  // floww.rs:59-64: drain(..start_index); start_indices are NOT rewound here
+        for (size_t index : stream_list) {
+            size_t k = std::min(start_indices[index], flowws[index].size());
+            flowws[index].erase(flowws[index].begin(), flowws[index].begin() + (long)k);
+        }
+    }
     long get_index(const std::string& n) const {  // floww.rs:66-68
         auto it = names.find(n);
         return it == names.end() ? -1 : (long)it->second;
@@ -1177,6 +1197,20 @@ long orc_fb_add_events(void* fb, const char* name, const float* triples, size_t 
     return (long)((FlowwBank*)fb)->declare_floww(name, ev);
 }
 long orc_fb_get_index(void* fb, const char* name) { return ((FlowwBank*)fb)->get_index(name); }
+long orc_fb_declare_stream(void* fb, const char* name) { return (long)((FlowwBank*)fb)->declare_stream(name); }
+long orc_fb_append_stream(void* fb, const char* name, const float* triples, size_t n) {
+    std::vector<Event> ev(n);
+    for (size_t i = 0; i < n; ++i) ev[i] = {triples[3 * i], triples[3 * i + 1], triples[3 * i + 2]};
+    return ((FlowwBank*)fb)->append_stream(name, ev);
+}
+void orc_fb_trim_streams(void* fb) { ((FlowwBank*)fb)->trim_streams(); }
+size_t orc_fb_get_events(void* fb, size_t index, float* out, size_t cap) {
+    FlowwBank* b = (FlowwBank*)fb;
+    if (index >= b->flowws.size()) return 0;
+    const auto& f = b->flowws[index];
+    for (size_t i = 0; i < f.size() && i < cap; ++i) { out[3 * i] = f[i].t; out[3 * i + 1] = f[i].note; out[3 * i + 2] = f[i].vel; }
+    return f.size();
+}
 void orc_fb_set_time(void* fb, size_t t) { ((FlowwBank*)fb)->set_time(t); }
 void orc_fb_set_time_to_next_block(void* fb) { ((FlowwBank*)fb)->set_time_to_next_block(); }
 void orc_fb_start_block(void* fb, size_t index) { ((FlowwBank*)fb)->start_block(index); }

@@ -44,7 +44,11 @@ SIGNATURES = {
     "td_flowwbank_free": (None, [_vp]),
     "td_flowwbank_reset": (None, [_vp]),
     "td_flowwbank_add_events": (_lng, [_vp, _cp, C.POINTER(td_event), _sz]),
+    "td_flowwbank_add_midi": (_lng, [_vp, _cp, _cp]),
     "td_flowwbank_declare_stream": (_lng, [_vp, _cp]),
+    "td_flowwbank_append_stream": (_lng, [_vp, _cp, C.POINTER(td_event), _sz]),
+    "td_flowwbank_trim_streams": (None, [_vp]),
+    "td_flowwbank_get_events": (_sz, [_vp, _sz, C.POINTER(td_event), _sz]),
     "td_flowwbank_get_index": (_lng, [_vp, _cp]),
     "td_flowwbank_set_time": (None, [_vp, _sz]),
     "td_flowwbank_set_time_to_next_block": (None, [_vp]),
@@ -209,8 +213,28 @@ class FlowwBank:
         ev = np.ascontiguousarray(np.asarray(events, dtype=np.float32).reshape(-1, 3))
         return lib().td_flowwbank_add_events(self.h, name.encode(), ev.ctypes.data_as(C.POINTER(td_event)), ev.shape[0])
 
+    def add_midi(self, name, path):
+        """FlowwBank::add_floww (floww.rs:40-48); raises TermdawError like the reference's Err."""
+        i = lib().td_flowwbank_add_midi(self.h, name.encode(), str(path).encode())
+        if i < 0:
+            raise TermdawError(last_error())
+        return i
+
     def declare_stream(self, name):
         return lib().td_flowwbank_declare_stream(self.h, name.encode())
+
+    def append_stream(self, name, events):
+        ev = np.ascontiguousarray(np.asarray(events, dtype=np.float32).reshape(-1, 3))
+        return lib().td_flowwbank_append_stream(self.h, name.encode(), ev.ctypes.data_as(C.POINTER(td_event)), ev.shape[0])
+
+    def trim_streams(self):
+        lib().td_flowwbank_trim_streams(self.h)
+
+    def get_events(self, index):
+        n = lib().td_flowwbank_get_events(self.h, index, None, 0)
+        buf = np.zeros((max(n, 1), 3), np.float32)
+        lib().td_flowwbank_get_events(self.h, index, buf.ctypes.data_as(C.POINTER(td_event)), n)
+        return buf[:n]
 
     def get_index(self, name):
         i = lib().td_flowwbank_get_index(self.h, name.encode())

@@ -7,6 +7,7 @@
 // per-sample runs on the GPU (kernels.hip).  There is no CPU render fallback: every render entry
 // point fails when no HIP device is usable.
 #include "engine.h"
+#include "midi.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -1551,6 +1552,34 @@ long td_flowwbank_declare_stream(td_flowwbank* fb, const char* name) {
     long i = td_flowwbank_add_events(fb, name, nullptr, 0);
     fb->stream_list.push_back((size_t)i);
     return i;
+}
+long td_flowwbank_add_midi(td_flowwbank* fb, const char* name, const char* path) {
+    std::vector<td_event> ev;
+    std::string err;
+    if (!tde::read_midi_file(path, &ev, &err)) {
+        fail(std::string("Could not read midi file: \"") + path + "\" (" + err + ").");   // floww.rs:45-46
+        return -1;
+    }
+    return td_flowwbank_add_events(fb, name, ev.data(), ev.size());
+}
+long td_flowwbank_append_stream(td_flowwbank* fb, const char* name, const td_event* events, size_t n) {
+    auto it = fb->names.find(name);
+    if (it == fb->names.end()) return -1;
+    auto& f = fb->flowws[it->second];
+    f.insert(f.end(), events, events + n);
+    return (long)f.size();
+}
+void td_flowwbank_trim_streams(td_flowwbank* fb) {   // start_indices are not rewound (floww.rs:59-64)
+    for (size_t index : fb->stream_list) {
+        auto& f = fb->flowws[index];
+        f.erase(f.begin(), f.begin() + (long)std::min(fb->start_indices[index], f.size()));
+    }
+}
+size_t td_flowwbank_get_events(const td_flowwbank* fb, size_t index, td_event* out, size_t cap) {
+    if (index >= fb->flowws.size()) return 0;
+    const auto& f = fb->flowws[index];
+    for (size_t i = 0; i < f.size() && i < cap; ++i) out[i] = f[i];
+    return f.size();
 }
 long td_flowwbank_get_index(const td_flowwbank* fb, const char* name) {
     auto it = fb->names.find(name);

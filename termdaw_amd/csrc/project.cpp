@@ -15,6 +15,7 @@
 #include "engine.h"
 #include "lua_subset.h"
 #include "wav.h"
+#include "midi.h"
 
 using namespace tde;
 using tdl::LuaError;
@@ -134,17 +135,19 @@ void bank_remove(td_samplebank* sb, const std::string& name) {   // mark_dead + 
 }
 
 // Event lists for load_midi_floww: the reference reads MIDI through the un-vendored floww crate
-// (floww.rs:40-48).  This front-end reads a plain-text list instead: one event per line,
-// "<t_sec> <note> <vel>" (decimal or C99 hex floats), '#' comments.  Anything else fails loudly.
+// (floww.rs:40-48).  This front-end reads .mid / .midi files with its own SMF reader (midi.h) and, for any
+// other name, a plain-text list: one event per line, "<t_sec> <note> <vel>" (decimal or C99 hex floats),
+// '#' comments.  Anything else fails loudly.
 bool read_event_file(const std::string& path, std::vector<td_event>* out, std::string* err) {
     std::ifstream f(path);
     if (!f) { *err = "Could not read midi file: \"" + path + "\"."; return false; }
     if (path.size() >= 4) {
         std::string ext = path.substr(path.size() - 4);
         for (auto& c : ext) c = (char)tolower(c);
-        if (ext == ".mid" || ext == "midi") {
-            *err = "Could not read midi file: \"" + path + "\": MIDI parsing lives in the un-vendored floww crate "
-                   "(floww.rs:41); give a .flw text event list (t_sec note vel per line) instead.";
+        if (ext == ".mid" || ext == "midi") {   // Standard MIDI File: this library's own reader (midi.h)
+            std::string merr;
+            if (tde::read_midi_file(path, out, &merr)) return true;
+            *err = "Could not read midi file: \"" + path + "\" (" + merr + ").";
             return false;
         }
     }

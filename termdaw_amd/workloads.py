@@ -107,6 +107,40 @@ def write_wav_int16(path, pcm, sr):
 # ------------------------------------------------------------------------------------------------
 # project script recorder (Lua API surface, state.rs:103-157)
 # ------------------------------------------------------------------------------------------------
+
+def _vlq(v):
+    out = [v & 0x7F]
+    v >>= 7
+    while v:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    return bytes(reversed(out))
+
+
+def midi_bytes(events, ppq=480, us_per_quarter=500000, channel=0):
+    """A format-0 Standard MIDI File holding `events` = [(t_sec, note, vel)] (vel 0 -> note-off), times
+    quantised to ticks.  Returns (bytes, quantised_events) -- the second is what a reader following
+    csrc/midi.h must produce: (f32(tick * us_per_quarter / ppq * 1e-6), note, f32(int(vel*127+0.5)) / 127)."""
+    trk = bytearray()
+    trk += _vlq(0) + bytes([0xFF, 0x51, 0x03]) + int(us_per_quarter).to_bytes(3, "big")
+    last = 0
+    quant = []
+    rows = []
+    for t, note, vel in events:
+        tick = int(round(float(t) * 1e6 / us_per_quarter * ppq))
+        rows.append((tick, int(note) & 0x7F, int(float(vel) * 127.0 + 0.5)))
+    rows.sort(key=lambda r: r[0])
+    for tick, note, v in rows:
+        trk += _vlq(tick - last)
+        last = tick
+        trk += bytes([(0x90 if v > 0 else 0x80) | channel, note, v if v > 0 else 0x40])
+        sec = np.float32(np.float64(tick) * np.float64(us_per_quarter) / np.float64(ppq) * 1e-6)
+        quant.append((sec, np.float32(note), np.float32(v) / np.float32(127.0) if v > 0 else np.float32(0.0)))
+    trk += _vlq(0) + bytes([0xFF, 0x2F, 0x00])
+    data = b"MThd" + (6).to_bytes(4, "big") + (0).to_bytes(2, "big") + (1).to_bytes(2, "big") + int(ppq).to_bytes(2, "big")
+    data += b"MTrk" + len(trk).to_bytes(4, "big") + bytes(trk)
+    return data, np.array(quant, dtype=np.float32).reshape(-1, 3)
+
 class Asset:
     def __init__(self, pcm, sr=48000, bits=16):
         self.pcm = np.asarray(pcm)

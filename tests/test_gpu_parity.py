@@ -349,3 +349,64 @@ def test_packed_16bit_sample_form_is_value_identical(gpu_api, oracle, packed, le
     built[2].set_option("packed_samples", packed)
     for scan in (False, True):
         assert_bit_exact(p.render(gpu_api, built=built, scan=scan), p.render(oracle, scan=scan))
+
+
+def test_stream_workflow_block_pull(gpu_api, oracle):
+    """stream_workflow.rs:62-101 without the audio device: events arrive in packets between block pulls
+    (trim_streams, append, set_time(graph time)), blocks are pulled one at a time.  Drum-driven vertices
+    (sample_multi -> adsr vertex) stay bit-exact against the oracle doing the same."""
+    rng = np.random.default_rng(21)
+    banks = []
+    for be in (gpu_api, oracle):
+        sb = be.SampleBank(48000)
+        sb.add_decoded("kick", W.kick_int16(12, 9000).astype(np.float32).reshape(-1), 2, 48000, 16, "")
+        fb = be.FlowwBank(48000, 512)
+        fb.declare_stream("live")
+        g = be.Graph(512, 48000)
+        g.add_sample_multi("hits", 0.9, 10.0, sb.get_index("kick"), fb.get_index("live"), -1)
+        g.add_adsr("env", 1.0, 0.0, 1.0, fb.get_index("live"), False, True, -1, [0.01, 0.05, 0.7, 0.05, 0.2, 0.02])
+        g.add_sum("out", 1.0, 0.0)
+        assert g.connect("hits", "env") and g.connect("env", "out") and g.set_output("out") and g.check_graph()
+        banks.append((sb, fb, g))
+    (gsb, gfb, gg), (osb, ofb, og) = banks
+    clock = 0.0
+    for b in range(60):
+        if b % 3 == 0:   # a packet: a few hits scheduled a little ahead of the playhead
+            now = b * 512 / 48000.0
+            batch = []
+            clock = max(clock, now)
+            for _ in range(int(rng.integers(1, 4))):
+                clock += float(rng.uniform(0.001, 0.02))
+                batch.append((clock, 36.0, float(rng.uniform(0.3, 1.0))))
+            for fb, g in ((gfb, gg), (ofb, og)):
+                fb.trim_streams()
+                fb.append_stream("live", batch)
+                fb.set_time(g.get_time())
+        for fb, g in ((gfb, gg), (ofb, og)):
+            fb.set_time(g.get_time())   # stream_workflow.rs:91-92
+        gl, gr = gg.render(gsb, gfb)
+        ol, orr = og.render(osb, ofb)
+        assert np.array_equal(_bits(gl), _bits(ol)) and np.array_equal(_bits(gr), _bits(orr)), "block %d" % b
+        gfb.set_time_to_next_block()
+        ofb.set_time_to_next_block()
+    assert np.abs(gl).max() >= 0.0 and gg.get_time() == og.get_time() == 60 * 512
+
+
+def test_project_with_midi_file(gpu_api, oracle, tmp_path):
+    """load_midi_floww with a real .mid through the project front-end: the library parses the SMF itself;
+    the oracle is handed the event list the file stands for (W.midi_bytes' quantised times)."""
+    ev = [(0.1 * i + 0.003, 60 + (i % 5), 0.4 + 0.1 * (i % 4)) for i in range(12)]
+    data, quant = W.midi_bytes(ev, ppq=480, us_per_quarter=500000)
+    p = W.drum_project(seconds=1.5)
+    name = sorted(p.event_files)[0]
+    p.event_files[name] = quant
+    want = p.render(oracle)
+    d = tmp_path / "proj"
+    lua = p.to_lua(str(d))
+    old = [l for l in lua.splitlines() if l.startswith("load_midi_floww(\"%s\"" % name)][0]
+    (d / "song.mid").write_bytes(data)
+    lua = lua.replace(old, 'load_midi_floww("%s", "%s");' % (name, d / "song.mid"))
+    s = gpu_api.State("", p.psr, p.bl)
+    assert s.refresh(lua), gpu_api.last_error()
+    pcm = s.render_to_memory()
+    assert np.array_equal(pcm, want[0])
