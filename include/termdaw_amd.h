@@ -157,7 +157,8 @@ float td_graph_output_peak(const td_graph* g);
 size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits);
 int td_graph_sync(td_graph* g);
 /* HIP-event timing of the launches of the last render, per kernel family (ms).  names/ms are parallel
- * arrays of capacity cap; returns the number of entries. Enabled by td_graph_set_profiling(g, 1). */
+ * arrays of capacity cap; returns the number of entries. Enabled by td_graph_set_profiling(g, n): n = 1
+ * times every render, n > 1 every n-th render only (the events themselves cost a few us per launch), 0 off. */
 void td_graph_set_profiling(td_graph* g, int on);
 size_t td_graph_last_kernel_times(const td_graph* g, const char** names, float* ms, size_t* launches, size_t cap);
 /* HBM bytes allocated for edge buffers / tables by this graph handle. */

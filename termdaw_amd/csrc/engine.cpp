@@ -765,14 +765,14 @@ struct Prof {
     hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
     Prof(td_graph* g_, int fam_, hipStream_t s_) : g(g_), fam(fam_), s(s_) {
-        if (g->profiling) {
+        if (g->prof_now) {
             a = get_event(g);
             b = get_event(g);
             (void)hipEventRecord(a, s);
         }
     }
     ~Prof() {
-        if (g->profiling) {
+        if (g->prof_now) {
             (void)hipEventRecord(b, s);
             g->ev_pending.push_back({a, b, fam});
         }
@@ -840,6 +840,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     const size_t M = nb * bl;
     if (M == 0) return 1;
     if (M > 0xFFFFFFF0ull) return fail("termdaw_amd: chunk too long");
+    g->prof_now = g->prof_every && (g->prof_count++ % g->prof_every) == 0;
     const size_t nv = g->vertices.size();
 
     g->band_stats_off.clear();
@@ -1972,7 +1973,9 @@ float td_graph_output_peak(const td_graph* gc) {
     return v;
 }
 void td_graph_set_profiling(td_graph* g, int on) {
-    g->profiling = on != 0;
+    g->prof_every = on > 0 ? (unsigned)on : 0u;
+    g->prof_count = 0;
+    g->prof_now = false;
     for (auto& e : g->ev_pending) { g->ev_free.push_back(e.a); g->ev_free.push_back(e.b); }
     g->ev_pending.clear();
     g->last_times.clear();

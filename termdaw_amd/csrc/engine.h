@@ -161,7 +161,8 @@ struct td_graph {
     size_t band_stats_base = 0;
     size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)
     // profiling
-    bool profiling = false;
+    unsigned prof_every = 0, prof_count = 0;   // HIP events around the launches of every prof_every-th chunk
+    bool prof_now = false;
     struct EvPair { hipEvent_t a, b; int fam; };
     std::vector<EvPair> ev_pending;
     std::vector<hipEvent_t> ev_free;
