@@ -1040,6 +1040,9 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
         if (lane < 4u) Su[seg * 4u + c] = __float_as_uint(y);   // the entry state everything below is computed from
         uint32_t last = seg;   // last segment covered by this round
         uint32_t job = kNoJob;
+        // A segment that an earlier repair left (partly) to a pending job has stored output that is not all
+        // in memory yet: "the rest already stands" cannot be used there, it is stepped through (or parked anew).
+        const bool had_job = d.seg_job[seg] != kNoJob;
         float yy = (lane >= 4u && lane < 8u) ? __uint_as_float(su) : y;
         uint32_t n = 0;
         bool parked = false, coalesced = false;
@@ -1108,7 +1111,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
                 if (!parked) {
                     k += nb;
                     const float twin = __shfl_xor(yy, 4, 64);
-                    coalesced = __all((lane >= 8u || __float_as_uint(twin) == __float_as_uint(yy)) ? 1 : 0) != 0;
+                    coalesced = !had_job && __all((lane >= 8u || __float_as_uint(twin) == __float_as_uint(yy)) ? 1 : 0) != 0;
                 }
             }
             // outputs of the k frames stepped in this batch
@@ -1122,9 +1125,8 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
             n += k;
         }
         y = __shfl(yy, (int)c, 64);   // true state, every lane
-        if (coalesced && !parked) {   // pass 1's exit state of this segment stands: cascade over
+        if (coalesced && !parked) {   // the stored exit state (and output) of this segment stands: cascade over
             ++recomputed;
-            if (lane == 0u) d.seg_job[seg] = kNoJob;
             break;
         }
         recomputed += last - seg + 1u;
