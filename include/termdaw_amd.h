@@ -161,6 +161,10 @@ int td_graph_sync(td_graph* g);
  * times every render, n > 1 every n-th render only (the events themselves cost a few us per launch), 0 off. */
 void td_graph_set_profiling(td_graph* g, int on);
 size_t td_graph_last_kernel_times(const td_graph* g, const char** names, float* ms, size_t* launches, size_t cap);
+/* Host-side time spent inside the renders since the last reset, by phase (ms): [0] event compile (cursor /
+ * voice bookkeeping -> tables), [1] descriptor build, [2] table upload, [3] kernel launches.  Returns the
+ * number of chunks accumulated. */
+size_t td_graph_host_times(td_graph* g, double* ms4, int reset);
 /* HBM bytes allocated for edge buffers / tables by this graph handle. */
 size_t td_graph_device_bytes(const td_graph* g);
 /* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are

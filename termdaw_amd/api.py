@@ -86,6 +86,7 @@ SIGNATURES = {
     "td_graph_render_all_async": (_sz, [_vp, _vp, _vp, _sz, _i32]),
     "td_graph_sync": (_i32, [_vp]),
     "td_graph_set_profiling": (None, [_vp, _i32]),
+    "td_graph_host_times": (_sz, [_vp, C.POINTER(C.c_double), _i32]),
     "td_graph_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
     "td_graph_device_bytes": (_sz, [_vp]),
     "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
@@ -373,6 +374,12 @@ class Graph:
 
     def sync(self):
         _check(lib().td_graph_sync(self.h))
+
+    def host_times(self, reset=True):
+        """Host ms per phase since the last reset: compile, descriptors, upload, launches; and chunk count."""
+        out = (C.c_double * 4)()
+        n = lib().td_graph_host_times(self.h, out, int(reset))
+        return {"compile": out[0], "descriptors": out[1], "upload": out[2], "launch": out[3], "chunks": n}
 
     def set_profiling(self, on):
         lib().td_graph_set_profiling(self.h, int(on))

@@ -6,6 +6,8 @@
 // one-shot cursors) that the reference interleaves with its per-sample loops.  Everything that is
 // per-sample runs on the GPU (kernels.hip).  There is no CPU render fallback: every render entry
 // point fails when no HIP device is usable.
+#include <chrono>
+
 #include "engine.h"
 #include "midi.h"
 
@@ -337,16 +339,17 @@ static void simple_block(const std::vector<td_event>& ev, const td_flowwbank& fb
     if (any) offset_done(i);
 }
 
-struct BlockCursor {
-    size_t frame;
-    std::vector<size_t> start;
-};
 
 struct IntervalBuilder {
     std::vector<uint32_t> istart, ivoff;
     std::vector<float4> voices;
     uint32_t limit = 0;
     bool open = false;
+    void reserve(size_t blocks, size_t voices_per) {
+        istart.reserve(blocks + blocks / 4 + 16);
+        ivoff.reserve(blocks + blocks / 4 + 17);
+        voices.reserve((blocks + blocks / 4 + 16) * voices_per);
+    }
     bool begin(size_t m) {
         if (m >= limit) { open = false; return false; }
         if (!istart.empty() && istart.back() == (uint32_t)m) {
@@ -363,21 +366,6 @@ struct IntervalBuilder {
 };
 
 static inline float note_hz(float note) { return 440.0f * powf(2.0f, (note - 69.0f) / 12.0f); }   // extensions.rs:451,503
-
-struct Staging {
-    std::vector<uint8_t> b;
-    size_t alloc(size_t n) {
-        size_t o = (b.size() + 15) & ~(size_t)15;
-        b.resize(o + n);
-        return o;
-    }
-    template <class T>
-    size_t put(const std::vector<T>& v) {
-        size_t o = alloc(v.size() * sizeof(T) + 16);   // never zero-sized
-        if (!v.empty()) memcpy(&b[o], v.data(), v.size() * sizeof(T));
-        return o;
-    }
-};
 
 struct VTables {   // per-vertex compile result: offsets into the staging arena
     size_t hits_off = 0;
@@ -407,7 +395,7 @@ static const std::vector<td_event>& floww_of(const td_flowwbank* fb, size_t idx)
     static const std::vector<td_event> empty;
     return idx < fb->flowws.size() ? fb->flowws[idx] : empty;
 }
-static size_t start_of(const BlockCursor& c, size_t idx) { return idx < c.start.size() ? c.start[idx] : 0; }
+static size_t start_of(const BlockCursor& c, size_t idx) { return idx < c.n ? c.start[idx] : 0; }
 
 // ---- SampleMulti (extensions.rs:344-381) ----
 static void compile_multi(Vertex& v, size_t L, const td_flowwbank* fb, const std::vector<BlockCursor>& cur,
@@ -520,10 +508,11 @@ static int compile_synth(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
                          size_t sr, Staging& st, VTables& vt) {
     IntervalBuilder ib;
     ib.limit = (uint32_t)(cur.size() * bl);
+    ib.reserve(cur.size(), std::max<size_t>(v.notes.size(), 8));
     const float release_sec = v.kind == K_SAMPSYN ? v.conf.release_sec : synth_release_sec(v);
     auto emit = [&](size_t m) {
         if (!ib.begin(m)) return;
-        for (auto& n : v.notes) ib.push(note_hz(n.note), n.vel, n.env_t, n.rel_t);
+        for (auto& n : v.notes) ib.push(n.hz, n.vel, n.env_t, n.rel_t);
     };
     const auto& ev = floww_of(fb, v.floww_index);
     bool impossible = false;
@@ -533,7 +522,7 @@ static int compile_synth(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
             [&](size_t i, bool on, float note, float vel) {
                 const float off = (float)i / (float)sr;
                 if (on) {
-                    v.notes.push_back({note, vel, -off, 0.0f});
+                    v.notes.push_back({note, vel, -off, 0.0f, note_hz(note)});
                 } else {
                     v.notes.erase(std::remove_if(v.notes.begin(), v.notes.end(),
                                                  [&](const SynthNote& x) {
@@ -567,6 +556,7 @@ static void compile_adsr(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
                          size_t sr, Staging& st, VTables& vt) {
     IntervalBuilder ib;
     ib.limit = (uint32_t)(cur.size() * bl);
+    ib.reserve(cur.size(), 2);
     auto emit = [&](size_t m, float skip) {
         if (!ib.begin(m)) return;
         ib.push(v.ap.t, v.ap.vel, v.ap.rel, skip);
@@ -845,7 +835,9 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
 
     g->band_stats_off.clear();
     // ---- 1. host compile: sequential bookkeeping -> tables
-    Staging st;
+    const auto tp0 = std::chrono::steady_clock::now();
+    Staging& st = g->staging;   // capacity kept from render to render
+    st.b.clear();
     std::vector<VTables> vt(nv);
     for (size_t vi : g->order) {
         Vertex& v = g->vertices[vi];
@@ -877,6 +869,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     }
 
     // ---- 2. descriptors: walk levels, assign edge buffers
+    const auto tp1 = std::chrono::steady_clock::now();
     if (!ensure_buffers(g, M)) return 0;
     g->vbuf.assign(nv, nullptr);
     std::vector<int> last_use(nv, -1);
@@ -1290,6 +1283,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
 
     g->band_stats_base = 0;
     // ---- 3. upload
+    const auto tp2 = std::chrono::steady_clock::now();
     const size_t upload = (st.b.size() + 255) & ~(size_t)255;
     if (!ensure_arena(g, upload + scratch_bytes + 256)) return 0;
     for (auto& f : pfix) {
@@ -1315,6 +1309,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     for (size_t pk : peaks_to_zero) TD_HIP(hipMemsetAsync(g->darena + upload + pk, 0, nb * sizeof(float), g->stream));
 
     // ---- 4. launch, level by level
+    const auto tp3 = std::chrono::steady_clock::now();
     size_t li = 0;
     while (li < launches.size()) {
         size_t lj = li;
@@ -1364,6 +1359,15 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     }
     TD_HIP(hipGetLastError());
     g->state_dev_dirty = true;
+    const auto tp4 = std::chrono::steady_clock::now();
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    g->host_ms[0] += ms(tp0, tp1);   // event compile
+    g->host_ms[1] += ms(tp1, tp2);   // descriptors
+    g->host_ms[2] += ms(tp2, tp3);   // arena upload (or the compare that skips it)
+    g->host_ms[3] += ms(tp3, tp4);   // launches
+    g->host_chunks += 1;
     return 1;
 }
 
@@ -1414,10 +1418,14 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
     size_t done = 0;
     while (done < n_blocks) {
         const size_t nb = std::min(chunk_blocks, n_blocks - done);
-        std::vector<BlockCursor> cur(nb);
+        std::vector<BlockCursor>& cur = g->cursor;   // (capacity kept from render to render)
+        const size_t nfl = fb->start_indices.size();
+        cur.resize(nb);
+        g->cursor_starts.resize(nb * nfl + 1);
         for (size_t b = 0; b < nb; ++b) {
-            cur[b].frame = fb->frame;
-            cur[b].start = fb->start_indices;
+            size_t* s = g->cursor_starts.data() + b * nfl;
+            for (size_t i = 0; i < nfl; ++i) s[i] = fb->start_indices[i];
+            cur[b] = {fb->frame, s, nfl};
             fb->set_time_to_next_block();
         }
         const uint64_t t0 = advance_graph_time ? g->t : scan_t0 + done * bl;
@@ -1971,6 +1979,12 @@ float td_graph_output_peak(const td_graph* gc) {
     if (hipMemcpyAsync(&v, g->d_scalar, 4, hipMemcpyDeviceToHost, g->stream) != hipSuccess) return 0.0f;
     (void)hipStreamSynchronize(g->stream);
     return v;
+}
+size_t td_graph_host_times(td_graph* g, double* ms4, int reset) {
+    for (int i = 0; i < 4; ++i) ms4[i] = g->host_ms[i];
+    const size_t n = g->host_chunks;
+    if (reset) { for (double& v : g->host_ms) v = 0.0; g->host_chunks = 0; }
+    return n;
 }
 void td_graph_set_profiling(td_graph* g, int on) {
     g->prof_every = on > 0 ? (unsigned)on : 0u;

@@ -6,7 +6,11 @@
 // clocks) into small tables, and every per-sample operation runs in the HIP kernels of kernels.hip,
 // one batched launch per (topological level, vertex kind).
 #pragma once
+#include <string.h>
+
 #include <deque>
+#include <memory>
+#include <utility>
 #include <map>
 #include <string>
 #include <vector>
@@ -61,7 +65,7 @@ enum Kind { K_SUM, K_NORMALIZE, K_SAMPLE_LOOP, K_SAMPLE_MULTI, K_SAMPLE_LERP, K_
             K_SAMPSYN, K_ADSR, K_BAND_PASS, K_COUNT };
 
 struct SineNote { float note, vel; };
-struct SynthNote { float note, vel, env_t, rel_t; };
+struct SynthNote { float note, vel, env_t, rel_t, hz; };   // hz = 440 * 2^((note - 69) / 12), extensions.rs:503
 struct Voice3 { float t, vel, rel; };
 
 struct Vertex {
@@ -105,6 +109,46 @@ union StateSlot {
 
 struct KernelTime { std::string name; float ms = 0; size_t launches = 0; };
 
+}  // namespace tde
+
+namespace tde {
+// std::allocator whose value-less construct() default-initialises: resize() of a byte vector then costs no
+// zero fill (every staged byte is written right after being allocated; alignment gaps are never read).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    template <class U, class... A>
+    void construct(U* p, A&&... a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void*)p) U;
+        else ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+struct Staging {
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> b;
+    size_t alloc(size_t n) {
+        const size_t end = b.size();
+        const size_t o = (end + 15) & ~(size_t)15;
+        b.resize(o + n);
+        for (size_t i = end; i < o; ++i) b[i] = 0;   // (the upload-skip compares whole arenas)
+        return o;
+    }
+    template <class T>
+    size_t put(const std::vector<T>& v) {
+        size_t o = alloc(v.size() * sizeof(T) + 16);   // never zero-sized
+        if (!v.empty()) memcpy(&b[o], v.data(), v.size() * sizeof(T));
+        memset(&b[o + v.size() * sizeof(T)], 0, 16);
+        return o;
+    }
+};
+
+}  // namespace tde
+
+namespace tde {
+struct BlockCursor {   // FlowwBank state at the start of one block: frame + start index of every floww
+    size_t frame;
+    const size_t* start;   // [n], into the chunk's flat cursor table
+    size_t n;
+};
 }  // namespace tde
 
 struct td_graph {
@@ -163,6 +207,11 @@ struct td_graph {
     // profiling
     unsigned prof_every = 0, prof_count = 0;   // HIP events around the launches of every prof_every-th chunk
     bool prof_now = false;
+    tde::Staging staging;               // table / descriptor arena under construction (host)
+    std::vector<tde::BlockCursor> cursor;   // per-block FlowwBank cursors of the chunk being compiled
+    std::vector<size_t> cursor_starts;
+    double host_ms[4] = {0, 0, 0, 0};   // host time per run_chunk phase: compile, descriptors, upload, launches
+    size_t host_chunks = 0;
     struct EvPair { hipEvent_t a, b; int fam; };
     std::vector<EvPair> ev_pending;
     std::vector<hipEvent_t> ev_free;

@@ -10,10 +10,13 @@ for name, p in (("config2", W.config2()), ("config3", W.config3()), ("drum60", W
         g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0); g.render_all_async(sb, fb, p.cs, 16)
     g.sync()
     N = 10
+    g.host_times()
     t0 = time.perf_counter(); c = 0.0
     for _ in range(N):
         g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
         t = time.perf_counter(); g.render_all_async(sb, fb, p.cs, 16); c += time.perf_counter() - t
     g.sync()
     tt = time.perf_counter() - t0
-    print("%-8s host %.3f ms per render call, total %.3f ms per render" % (name, c / N * 1e3, tt / N * 1e3))
+    ht = g.host_times()
+    print("%-8s host %.3f ms per render call, total %.3f ms per render; phases per render (ms): " % (name, c / N * 1e3, tt / N * 1e3) +
+          ", ".join("%s %.3f" % (k, ht[k] / N) for k in ("compile", "descriptors", "upload", "launch")))
