@@ -955,6 +955,75 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     if (live) d.seg_start[seg * 4u + c] = y;
     // the segment itself: recurrence + output
     const float x_first = gload1(xf + 2u * start + ch);
+    // Fast form (every quad of the wave owns a whole segment): the wave alternates between
+    //   (a) 32 steps of the bare recurrence, like the warm-up, each lane dropping its state after every step
+    //       into LDS (one ds_write per step; quad slots padded to 528 B so a wave's 64 lanes hit 64 banks), and
+    //   (b) the output of those 32 frames x 16 segments with all 64 lanes: frame-parallel, coalesced 256-byte
+    //       runs of input and output instead of one 8-byte store per quad per step.
+    // The "input constant / all zero" flags of the segments fall out of (b) as ballots.
+    constexpr uint32_t kQStride = 132;   // floats per quad slot: 32 frames x 4 states + 4 pad
+    __shared__ __attribute__((aligned(16))) float ys_l[(kThreads / 4) * kQStride];
+    __shared__ float2 xf_l[kThreads / 4];
+    if (__all((start + d.S <= M) ? 1 : 0) != 0) {
+        const uint32_t quad = threadIdx.x >> 2, lane = threadIdx.x & 63u, wq0 = (threadIdx.x >> 6) * 16u;
+        float* myq = ys_l + quad * kQStride + c;
+        const float xr_first = quad_bcast<1>(x_first);
+        if (c == 0u) xf_l[quad] = make_float2(x_first, xr_first);
+        uint32_t same_mask = 0xFFFFu, zero_mask = 0xFFFFu;   // bit q: segment of the wave's quad q
+        const uint32_t wave_seg0 = blockIdx.x * (kThreads / 4) + wq0;
+#define TD_BAND_S1(X, PERM, J)                                                                                  \
+    asm volatile("v_sub_f32_dpp %1, %3, %0 quad_perm:" PERM " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"        \
+                 "v_mul_f32 %1, %2, %1\n"                                                                       \
+                 "v_add_f32 %0, %0, %1\n"                                                                       \
+                 : "+v"(y), "=&v"(t_) : "v"(gam), "v"(X));                                                      \
+    myq[(J) * 4] = y;
+#define TD_BAND_STEP8W(A, J0)                                                                                   \
+    {                                                                                                           \
+        const float4 a = A;                                                                                     \
+        float t_;                                                                                               \
+        asm volatile("s_nop 1" ::: "memory");                                                                   \
+        TD_BAND_S1(a.x, "[0,1,0,1]", (J0) + 0) TD_BAND_S1(a.y, "[0,1,0,1]", (J0) + 1)                           \
+        TD_BAND_S1(a.z, "[0,1,0,1]", (J0) + 2) TD_BAND_S1(a.w, "[0,1,0,1]", (J0) + 3)                           \
+        TD_BAND_S1(a.x, "[2,3,2,3]", (J0) + 4) TD_BAND_S1(a.y, "[2,3,2,3]", (J0) + 5)                           \
+        TD_BAND_S1(a.z, "[2,3,2,3]", (J0) + 6) TD_BAND_S1(a.w, "[2,3,2,3]", (J0) + 7)                           \
+    }
+        float4 a0 = fetchq(start), a1 = fetchq(start + 8u), a2 = fetchq(start + 16u), a3 = fetchq(start + 24u);
+        for (uint32_t p = 0; p < d.S; p += 32u) {
+            TD_BAND_STEP8W(a0, 0) TD_BAND_STEP8W(a1, 8) TD_BAND_STEP8W(a2, 16) TD_BAND_STEP8W(a3, 24)
+            if (p + 32u < d.S) {   // the next 32 frames' input flies during (b)
+                a0 = fetchq(start + p + 32u); a1 = fetchq(start + p + 40u);
+                a2 = fetchq(start + p + 48u); a3 = fetchq(start + p + 56u);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll 2
+            for (uint32_t i = 0; i < 8u; ++i) {
+                const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u;
+                const uint32_t sraw = wave_seg0 + sq;
+                const uint32_t m = min(sraw, d.nseg - 1u) * d.S + p + j;   // quads past the end mirror the last segment
+                const float2 x = gload2(d.x + m);
+                const float4 s = *reinterpret_cast<const float4*>(ys_l + (wq0 + sq) * kQStride + j * 4u);
+                const float2 x0 = xf_l[wq0 + sq];
+                const bool sm = __float_as_uint(x.x) == __float_as_uint(x0.x) && __float_as_uint(x.y) == __float_as_uint(x0.y);
+                const bool zr = x.x == 0.0f && x.y == 0.0f;
+                const unsigned long long bs = __ballot(sm ? 1 : 0), bz = __ballot(zr ? 1 : 0);
+                if ((uint32_t)bs != 0xFFFFFFFFu) same_mask &= ~(1u << (2u * i));
+                if ((uint32_t)(bs >> 32) != 0xFFFFFFFFu) same_mask &= ~(2u << (2u * i));
+                if ((uint32_t)bz != 0xFFFFFFFFu) zero_mask &= ~(1u << (2u * i));
+                if ((uint32_t)(bz >> 32) != 0xFFFFFFFFu) zero_mask &= ~(2u << (2u * i));
+                if (sraw < d.nseg) gstore2(d.out + m, epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), d.pg));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        }
+#undef TD_BAND_STEP8W
+#undef TD_BAND_S1
+        if (live) d.seg_final[seg * 4u + c] = y;
+        if (c == 0u && live) {
+            const uint32_t q = quad & 15u;
+            d.seg_flags[seg] = ((same_mask >> q) & 1u) | (((zero_mask >> q) & 1u) << 1);
+            d.seg_x0[seg] = make_float2(x_first, xr_first);
+        }
+        return;
+    }
     bool same = true, zero = true;
     auto step = [&](uint32_t m, float l, float r) {
         if (m >= end) return;

@@ -114,8 +114,10 @@ def test_random_projects_bit_exact(gpu_api, oracle, seed):
     for scan in (False, True, False):    # plain, scanned, and a continuation render on the carried state
         gp, gf = p.render(gpu_api, built=gb, scan=scan)
         op, of = p.render(oracle, built=ob, scan=scan)
+        # NaNs must sit in the same places; which NaN (sign, payload) an operation with two NaN operands
+        # returns is outside IEEE 754 and outside Rust's guarantees, so NaN bits are not compared
         assert np.array_equal(np.isnan(gf), np.isnan(of))
-        bad = np.nonzero(_bits(gf) != _bits(of))[0]
+        bad = np.nonzero((_bits(gf) != _bits(of)) & ~np.isnan(of))[0]
         assert bad.size == 0, "seed %d scan %s: first bad frame %d got %s want %s" % (seed, scan, bad[0], gf[bad[0]], of[bad[0]])
         assert np.array_equal(gp, op)
 
