@@ -20,7 +20,8 @@ def assert_bit_exact(got, ref):
     gp, gf = got
     rp, rf = ref
     assert gp.shape == rp.shape
-    bad = np.nonzero(_bits(gf) != _bits(rf))
+    assert np.array_equal(np.isnan(gf), np.isnan(rf))   # same NaN positions; NaN payloads are not compared
+    bad = np.nonzero((_bits(gf) != _bits(rf)) & ~np.isnan(rf))
     assert bad[0].size == 0, "f32 mismatch at frames %s: got %s ref %s" % (bad[0][:5], gf[bad][:5], rf[bad][:5])
     assert np.array_equal(gp, rp)
 
