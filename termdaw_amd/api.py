@@ -116,9 +116,19 @@ def build(force=False):
     import subprocess
     srcs = glob.glob(os.path.join(_HERE, "csrc", "*")) + [os.path.join(_HERE, "..", "include", "termdaw_amd.h"),
                                                          os.path.join(_HERE, "Makefile")]
-    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
-    if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-j8", "-s"])
+    def stale():
+        return (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH)
+                                                     for s in srcs if os.path.exists(s))
+    if force or stale():
+        # one builder at a time: the ranks of a multi-GPU launch all come through here at once
+        import fcntl
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            try:
+                if force or stale():
+                    subprocess.check_call(["make", "-C", _HERE, "-j8", "-s"])
+            finally:
+                fcntl.flock(lk, fcntl.LOCK_UN)
     return LIB_PATH
 
 
