@@ -805,7 +805,7 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     if (v.hgamma != 0.0f) gmin = fminf(gmin, fabsf(v.hgamma));
     // 150 / gamma: ~103 / gamma frames take a full-scale tail down to the denormal floor (so a warm-up that
     // starts in the sound before a silence reproduces the decay into it), the rest is coalescence margin
-    const double w = 150.0 / (double)gmin + 64.0;
+    const double w = (double)g->band_warmup / (double)gmin + 64.0;
     if (!(w <= 262144.0)) return p;   // cut-offs below ~5 Hz: the serial kernel is the better plan
     p.W = ((uint32_t)w + 31u) & ~31u;
     p.Ws = std::min(p.W, ((uint32_t)(40.0 / (double)gmin + 64.0) + 31u) & ~31u);   // coalescence only
@@ -1224,7 +1224,16 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         x.S = bp.S;
                         x.W = bp.W;
                         x.Ws = bp.Ws;
-                        x.live_thr = 1e-6f;
+                        x.live_thr = g->band_live_thr;
+                        {
+                            float gmin = 1.0f;
+                            if (v.lgamma != 0.0f) gmin = fminf(gmin, fabsf(v.lgamma));
+                            if (v.hgamma != 0.0f) gmin = fminf(gmin, fabsf(v.hgamma));
+                            x.gmin = gmin;
+                            x.decay1 = (float)exp(-(double)gmin * 256.0);
+                            x.decay4 = (float)exp(-(double)gmin * 1024.0);
+                            x.post_blocks = (uint32_t)(20.0 / (double)gmin / 256.0) + 1u;
+                        }
                         x.pass = v.pass;
                         x.lgamma = v.lgamma;
                         x.hgamma = v.hgamma;
@@ -2045,6 +2054,8 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
+    if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
+    if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }
     if (k == "max_chunk_frames") {

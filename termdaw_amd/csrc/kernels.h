@@ -242,7 +242,10 @@ struct BandSpecDesc {
     uint32_t* stats;        // [8]: cascades repaired, segments recomputed, segments parked, jobs, ticket (zeroed by k_band_spec)
     uint32_t nseg, S, W;
     uint32_t Ws;            // short warm-up (k_band_spec picks W or Ws per segment from blk_peaks)
-    float live_thr;         // quietest / loudest block peak ratio above which a window counts as live (1e-6)
+    float live_thr;         // (energy left from before the short window) / (energy fed in inside it) below which Ws is enough
+    float gmin;             // the smaller non-zero gamma of the two smoothers
+    float decay1, decay4;   // e^(-gamma_min * 256), and its 4th power: decay of a state over one / four 256-frame blocks
+    uint32_t post_blocks;   // blocks right before the segment that must not be held constants (~20 / gamma frames)
     uint32_t pass;
     float lgamma, hgamma;
     PanGain pg;

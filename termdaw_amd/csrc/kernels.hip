@@ -874,8 +874,8 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     // n and start are multiples of 32 (S and W are), so the loop runs in batches of 32 frames: four fetches
     // issued one whole batch ahead -- ~32 steps of dependent VALU cover an Infinity Cache / L2 round trip.
     const float4* __restrict__ q4 = reinterpret_cast<const float4*>(d.xq4);
-    auto fetchq = [&](uint32_t frame) -> float4 {            // frame is a multiple of 8 and below start
-        return gload4(q4 + (frame >> 1) + c);
+    auto fetchq = [&](uint32_t frame) -> float4 {            // frame is a multiple of 8
+        return gload4(q4 + min((frame >> 1) + c, M2 - 1u));  // (prefetches may run past the last stepped frame)
     };
     // The eight steps are written as one instruction block: the compiler's DPP hazard rule also pads a DPP
     // instruction whose NON-DPP operand (y, just written by the previous add) is fresh -- 3.3 ns of s_nop per
@@ -898,60 +898,94 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
                      : "v"(gam), "v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w));                           \
     }
     // Warm-up length.  The long warm-up W covers a full-scale tail decaying to the denormal floor (needed when
-    // the segment sits in or after a silence or a held constant); when the whole short window Ws is live
-    // signal the state is driven by it and Ws (coalescence only) does.  A wrong pick only costs a repair in
-    // k_band_fix, never exactness.
+    // the segment sits in or right after a silence or a held constant, where trajectories park instead of
+    // meeting).  Otherwise the short window Ws = 40 / gamma is enough if the energy the input feeds in INSIDE
+    // the window dominates, at the segment start, what is left of everything before it: a state is an
+    // exponentially weighted memory of the input, so with E(blocks) = max_b peak_b * e^(-gamma * distance of
+    // block b to the segment start), the wrong part of the guess is at most A = E(blocks of the Ws frames before
+    // the window) and the state itself about B = E(blocks of the window).  A <= live_thr * B (1e-9: below half an
+    // ulp with a margin for states much smaller than the input peak) means the guess error ends far below the
+    // state's last bit.  (A window that merely decays does NOT qualify -- error and state shrink together -- a
+    // window in which the next sound starts does, however many decades the level swings in between.)  Block
+    // values come for free from the k_sum launch that materialised the input; held-constant blocks (-1) count as
+    // no energy and must not lie in the last 20 / gamma frames.  A wrong pick only costs a repair in k_band_fix,
+    // never exactness.
     uint32_t my_w = d.W;
+    // (the workgroup's 64 segments are neighbours, their block ranges overlap almost entirely: staged in LDS once)
+    __shared__ float pk_l[1024];
+    const uint32_t nw_ = d.Ws / 256u, s256 = d.S / 256u;
+    const uint32_t seg_first = blockIdx.x * (kThreads / 4), seg_last = min(seg_first + kThreads / 4 - 1u, d.nseg - 1u);
+    const uint32_t pk_base = seg_first * s256 > 2u * nw_ ? seg_first * s256 - 2u * nw_ : 0u;
+    const uint32_t pk_cnt = seg_last * s256 - pk_base;
+    const bool pk_lds = pk_cnt <= 1024u && d.Ws < d.W;
+    if (pk_lds)
+        for (uint32_t i = threadIdx.x; i < pk_cnt; i += kThreads) pk_l[i] = d.blk_peaks[pk_base + i];
+    __syncthreads();
+    auto blk_peak = [&](uint32_t b) -> float { return pk_lds ? pk_l[b - pk_base] : d.blk_peaks[b]; };
     if (d.Ws < d.W && start > d.Ws) {
-        // The short window is live when none of its 256-frame blocks is a held constant (-1) and their peaks
-        // stay within 120 dB of each other (the guess error scales with the loudest block, the state at the
-        // segment start with the quietest) and clear of the denormal range.  Block values come for free from
-        // the k_sum launch that materialised the input.
-        float lo = 3.0e38f, hi = 0.0f;
-        for (uint32_t b = (start - d.Ws) / 256u + c; b < start / 256u; b += 4u) {
-            const float v = d.blk_peaks[b];
-            lo = fminf(lo, v);
-            hi = fmaxf(hi, v);
+        const uint32_t nw = d.Ws / 256u, b1 = start / 256u, b0 = b1 - nw, bA = b0 > nw ? b0 - nw : 0u;
+        // (near the chunk start the history before the window is the carried state itself, decayed to here)
+        const float A0 = bA == 0u ? fabsf(y_true0) * __expf(-d.gmin * (float)start) : 0.0f;
+        float A = 0.0f, B = 0.0f, tail_min = 1.0f;
+        uint32_t b = bA + c;
+        for (; b < b0; b += 4u) A = fmaxf(A * d.decay4, blk_peak(b));
+        // lane-local reference point: block b - 4; bring A forward as the window is walked
+        for (; b < b1; b += 4u) {
+            const float pk = blk_peak(b);
+            A *= d.decay4;
+            B = fmaxf(B * d.decay4, pk);
+            if (b + d.post_blocks >= b1) tail_min = fminf(tail_min, pk);
         }
-        lo = fminf(fminf(quad_bcast<0>(lo), quad_bcast<1>(lo)), fminf(quad_bcast<2>(lo), quad_bcast<3>(lo)));
-        hi = fmaxf(fmaxf(quad_bcast<0>(hi), quad_bcast<1>(hi)), fmaxf(quad_bcast<2>(hi), quad_bcast<3>(hi)));
-        if (lo >= 1e-30f && lo >= hi * d.live_thr) my_w = d.Ws;
+        // the block maxima are now referred to block b - 4 (this lane's last); refer them to the segment start
+        float tail = 1.0f;
+        for (uint32_t r = b - 4u + 1u; r < b1; ++r) tail *= d.decay1;
+        B *= tail;
+        A = fmaxf(A * tail, A0);
+        A = fmaxf(fmaxf(quad_bcast<0>(A), quad_bcast<1>(A)), fmaxf(quad_bcast<2>(A), quad_bcast<3>(A)));
+        B = fmaxf(fmaxf(quad_bcast<0>(B), quad_bcast<1>(B)), fmaxf(quad_bcast<2>(B), quad_bcast<3>(B)));
+        tail_min = fminf(fminf(quad_bcast<0>(tail_min), quad_bcast<1>(tail_min)), fminf(quad_bcast<2>(tail_min), quad_bcast<3>(tail_min)));
+        if (tail_min >= 0.0f && B >= 1e-30f && A <= B * d.live_thr) my_w = d.Ws;
     }
-    const uint32_t my_begin = start > my_w ? start - my_w : 0u;
-    uint32_t wave_begin = my_begin;   // the wave walks from its earliest lane; later lanes (re)seed on arrival
+    // Every lane of the wave walks the same number of steps -- the longest warm-up any of its quads picked (a
+    // longer warm-up than needed never hurts) -- over its OWN window [start - w, start).  Quads whose window is
+    // cut short by the chunk start begin at frame 0 with the exact state and simply finish earlier.
+    uint32_t w_wave = my_w;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) wave_begin = min(wave_begin, (uint32_t)__shfl_xor((int)wave_begin, off, 64));
-    uint32_t n = wave_begin;
-    float y = y_true0;
-    // at this lane's own warm-up start: exact state at frame 0, constant chain, or the guess (loaded up front
-    // so that the loop body contains no other memory operation than the batched prefetches)
-    const float seed_val = (my_begin == 0u || gam == 0.0f) ? y_true0 : gload1(xf + 2u * my_begin + ch);
-    auto seed = [&]() { if (n == my_begin) y = seed_val; };
+    for (int off = 32; off > 0; off >>= 1) w_wave = max(w_wave, (uint32_t)__shfl_xor((int)w_wave, off, 64));
+    const uint32_t my_begin = start > w_wave ? start - w_wave : 0u;
+    uint32_t n = my_begin;
+    // exact state at frame 0, constant chain, or the guess
+    float y = (my_begin == 0u || gam == 0.0f) ? y_true0 : gload1(xf + 2u * my_begin + ch);
     if (n + 32u <= start && (n & 31u) == 0u) {
-        // ping-pong register sets A / B (no copies): while A's 32 steps retire, B's four loads stay in flight
+        // three register sets in rotation (no copies): each batch of 32 steps runs on loads issued two batches
+        // (~0.5 us) earlier -- every quad streams its own window, mostly out of L2
         float4 a0 = fetchq(n), a1 = fetchq(n + 8u), a2 = fetchq(n + 16u), a3 = fetchq(n + 24u);
-        while (n + 64u <= start) {
-            const float4 b0 = fetchq(n + 32u), b1 = fetchq(n + 40u), b2 = fetchq(n + 48u), b3 = fetchq(n + 56u);
-            seed();
+        float4 b0 = fetchq(n + 32u), b1 = fetchq(n + 40u), b2 = fetchq(n + 48u), b3 = fetchq(n + 56u);
+        while (n + 96u <= start) {
+            const float4 c0 = fetchq(n + 64u), c1 = fetchq(n + 72u), c2 = fetchq(n + 80u), c3 = fetchq(n + 88u);
             TD_BAND_STEP8(a0) TD_BAND_STEP8(a1) TD_BAND_STEP8(a2) TD_BAND_STEP8(a3)
             n += 32u;
-            a0 = fetchq(n + 32u); a1 = fetchq(n + 40u); a2 = fetchq(n + 48u); a3 = fetchq(n + 56u);
-            seed();
+            a0 = fetchq(n + 64u); a1 = fetchq(n + 72u); a2 = fetchq(n + 80u); a3 = fetchq(n + 88u);
             TD_BAND_STEP8(b0) TD_BAND_STEP8(b1) TD_BAND_STEP8(b2) TD_BAND_STEP8(b3)
+            n += 32u;
+            b0 = fetchq(n + 64u); b1 = fetchq(n + 72u); b2 = fetchq(n + 80u); b3 = fetchq(n + 88u);
+            TD_BAND_STEP8(c0) TD_BAND_STEP8(c1) TD_BAND_STEP8(c2) TD_BAND_STEP8(c3)
             n += 32u;
         }
         if (n + 32u <= start) {
-            seed();
             TD_BAND_STEP8(a0) TD_BAND_STEP8(a1) TD_BAND_STEP8(a2) TD_BAND_STEP8(a3)
+            n += 32u;
+        }
+        if (n + 32u <= start) {
+            TD_BAND_STEP8(b0) TD_BAND_STEP8(b1) TD_BAND_STEP8(b2) TD_BAND_STEP8(b3)
             n += 32u;
         }
     }
     if ((n & 7u) == 0u)
-        for (; n + 8u <= start; n += 8u) { seed(); TD_BAND_STEP8(fetchq(n)) }
+        for (; n + 8u <= start; n += 8u) { TD_BAND_STEP8(fetchq(n)) }
 #undef TD_BAND_STEP8
 #undef TD_BAND_S
-    for (; n < start; ++n) { seed(); y = y + gam * (gload1(xf + 2u * n + ch) - y); }
-    seed();   // n == start == my_begin: segment 0 / no warm-up
+    for (; n < start; ++n) y = y + gam * (gload1(xf + 2u * n + ch) - y);
     if (live) d.seg_start[seg * 4u + c] = y;
     // the segment itself: recurrence + output
     const float x_first = gload1(xf + 2u * start + ch);
