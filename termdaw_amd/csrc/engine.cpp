@@ -882,6 +882,16 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     if (g->fuse_sources)
         for (size_t vi : g->order)
             inlined[vi] = g->vertices[vi].kind == K_SAMPLE_LOOP && (long)vi != g->output_vertex;
+    // ... and so is a Sum vertex with exactly one (materialised) input -- a gain / pan stage: its consumers read
+    // the input's buffer and apply `0.0 + x`, pan, gain themselves (term kind 4); one launch and one buffer less
+    if (g->fuse_sources)
+        for (size_t vi : g->order) {   // topological order: the input's own flag is final here
+            const Vertex& v = g->vertices[vi];
+            if (v.kind != K_SUM || (long)vi == g->output_vertex || g->edges[vi].size() != 1 || inlined[g->edges[vi][0]]) continue;
+            inlined[vi] = 2;
+            const size_t u = g->edges[vi][0];
+            last_use[u] = std::max(last_use[u], last_use[vi]);   // the input must outlive the stage's consumers
+        }
 
     struct Launch { int fam; size_t off; int n; uint32_t aux; int level; };
     std::vector<Launch> launches;
@@ -952,7 +962,11 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
             std::vector<InTerm> ins;
             for (size_t u : g->edges[vi]) {
                 InTerm t{};
-                if (inlined[u]) {
+                if (inlined[u] == 2) {   // single-input Sum stage, read through
+                    t.p = g->vbuf[g->edges[u][0]];
+                    t.kind = 4u;
+                    t.pg = make_pg(g->vertices[u].gain, g->vertices[u].angle);
+                } else if (inlined[u]) {
                     const Vertex& src = g->vertices[u];
                     const SampleEntry& s = sb->samples[src.sample_index];
                     t.p = s.d;

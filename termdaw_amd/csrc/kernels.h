@@ -36,6 +36,9 @@ struct PanGain {
 //           so that any four consecutive loop frames are one aligned 16-byte load; the f32 frame is rebuilt as (float)l * scale_l, (float)r * scale_r -- the very
 //           expression the load pipeline used to produce the f32 bank entry (sample.rs:270-273 `as f32`,
 //           sample.rs:121-129 `* (1.0 / max)`), so the values are bit-identical at half the gather bytes.
+//   kind 4: an edge buffer read THROUGH a Sum vertex that has this one input only (a gain / pan stage): the
+//           consumer computes `0.0 + x`, pan, gain itself (extensions.rs:310-319, sample.rs:97-114) and the
+//           stage is never materialised.
 struct InTerm {
     const float2* p;   // edge buffer (kind 0) or sample frames (kind 1, 2)
     uint64_t len;      // sample length

@@ -152,6 +152,10 @@ TD_DEV float4 term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     const float2* p = t[j].p;
     const uint32_t kind = t[j].kind;
     if (kind == 0) return load_pair(p, m, M);
+    if (kind == 4) {   // a single-input Sum vertex read through: zero, += input (-0 becomes +0), pan, gain
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        return epilogue4(add4(z, load_pair(p, m, M)), term_pg(t, j));
+    }
     const uint64_t len = t[j].len, t0 = t[j].t0;
     float4 v;
     if (kind == 3) {   // packed 16-bit form, two frames
@@ -1330,7 +1334,9 @@ TD_DEV bool band_fix_range(const BandSpecDesc& d, uint32_t M, uint32_t lo, uint3
             band_fix_cascade(d, M, L.events[i], lo, hi, L.bitmap, L.xs[wave], L.ys[wave], rec, park);
             ++cascades;
         }
-        __threadfence();   // the next Phase A reads what the other waves stored
+        // the next Phase A reads what the other waves of THIS workgroup stored: same CU, same L1 -- a
+        // workgroup-scope fence (an agent-scope one would write the whole dirty L2 back every round)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __syncthreads();
     }
     if (lane == 0u && cascades) { atomicAdd(&d.stats[0], cascades); atomicAdd(&d.stats[1], rec); atomicAdd(&d.stats[2], park); }
