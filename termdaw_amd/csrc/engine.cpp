@@ -1080,6 +1080,13 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                                     v.topflat.volume * adsr_max_vel(v.topflat.adsr) +
                                     v.triangle.volume * adsr_max_vel(v.triangle.adsr));
                         x.pg = make_pg(v.gain, v.angle);
+                        {
+                            auto same = [](const AdsrConfD& a, const AdsrConfD& b) { return memcmp(&a, &b, sizeof(AdsrConfD)) == 0; };
+                            const bool sq = v.square.volume > 0.0f, tf = v.topflat.volume > 0.0f;
+                            x.tf_env_src = (sq && same(v.topflat.adsr, v.square.adsr)) ? 1u : 0u;
+                            x.tr_env_src = (sq && same(v.triangle.adsr, v.square.adsr)) ? 1u
+                                         : (tf && same(v.triangle.adsr, v.topflat.adsr)) ? 2u : 0u;
+                        }
                         d.push_back(x);
                     }
                     off = st.put(d);

@@ -168,6 +168,9 @@ struct SynthDesc {
     uint32_t sr, bl;
     OscConfD square, topflat, triangle;
     float osc_amp_multiplier;
+    // envelope sharing: 1 / 2 = this oscillator's AdsrConf is bit-identical to the square's / topflat's (and that
+    // one is enabled), so its envelope value -- a pure function of the conf and the voice's clocks -- is reused
+    uint32_t tf_env_src, tr_env_src;
     PanGain pg;
 };
 

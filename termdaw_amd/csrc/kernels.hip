@@ -613,23 +613,26 @@ TD_DEV float synth_frame(const SynthDesc& d, uint32_t m) {
         const float env_time = n.z + off;
         float s = 0.0f;
         float sn = 0.0f;
+        float env_sq = 0.0f, env_tf = 0.0f;
         if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sinf(time * hz * 2.0f * kPi);
         if (d.square.volume > 0.0f) {
             const float z = d.square.param;
             const float osc = fminf(fmaxf(sn, -z), z) * (1.0f / z);
-            const float env = rel_t == 0.0f ? apply_ads(d.square.adsr, env_time) : apply_r_rt(d.square.adsr, env_time, rel_t);
-            s += osc * vel * env * d.square.volume;
+            env_sq = rel_t == 0.0f ? apply_ads(d.square.adsr, env_time) : apply_r_rt(d.square.adsr, env_time, rel_t);
+            s += osc * vel * env_sq * d.square.volume;
         }
         if (d.topflat.volume > 0.0f) {
             const float z = d.topflat.param;
             const float osc = (fminf(sn, z) + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
-            const float env = rel_t == 0.0f ? apply_ads(d.topflat.adsr, env_time) : apply_r_rt(d.topflat.adsr, env_time, rel_t);
-            s += osc * vel * env * d.topflat.volume;
+            env_tf = d.tf_env_src == 1u ? env_sq
+                   : rel_t == 0.0f ? apply_ads(d.topflat.adsr, env_time) : apply_r_rt(d.topflat.adsr, env_time, rel_t);
+            s += osc * vel * env_tf * d.topflat.volume;
         }
         if (d.triangle.volume > 0.0f) {
             const float th = time * hz;
             const float osc = 4.0f * fabsf(th - floorf(th + 0.5f)) - 1.0f;
-            const float env = rel_t == 0.0f ? apply_ads(d.triangle.adsr, env_time) : apply_r_rt(d.triangle.adsr, env_time, rel_t);
+            const float env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf
+                            : rel_t == 0.0f ? apply_ads(d.triangle.adsr, env_time) : apply_r_rt(d.triangle.adsr, env_time, rel_t);
             s += osc * vel * env * d.triangle.volume;
         }
         s *= d.osc_amp_multiplier;
