@@ -1348,9 +1348,9 @@ TD_DEV bool band_fix_range(const BandSpecDesc& d, uint32_t M, uint32_t lo, uint3
 
 // grid (G, vertices): workgroup g first settles its own slice of the segments (cascades stop at the slice
 // end, the slice's first event trusts whatever exit state its left neighbour shows at the time), then the
-// workgroup that finishes LAST (ticket in stats[4]; no spinning) repeats the rounds over all segments --
-// normally one Phase A that finds nothing, otherwise the few events at slice borders -- and its all-clear is the
-// proof for the whole vertex.  stats[] is zeroed by k_band_spec.
+// workgroup that finishes LAST (ticket in stats[4]; no spinning) checks the slice borders and, if one fails,
+// repeats the rounds over all segments; the slices' all-clears plus the border check (or that global all-clear)
+// are the proof for the whole vertex.  stats[] is zeroed by k_band_spec.
 __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __restrict__ descs, uint32_t M) {
     const BandSpecDesc& d = descs[blockIdx.y];
     __shared__ BandFixLds L;
@@ -1371,7 +1371,20 @@ __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __
         // they compared every segment with its predecessor, and nothing was modified -- are the proof already.
         if ((ticket_s >> 16) != 0u || any) {
             __threadfence();   // acquire the other slices' repairs
-            band_fix_range(d, M, 0u, d.nseg, L);
+            // Inside a slice nothing changed after its own all-clear (no other slice writes there), so what is
+            // left to prove is the 15 slice borders: each slice's first segment against its left neighbour's exit
+            // state as it stands NOW.  Only if one of them fails do the rounds run again, over all segments.
+            if (tid == 0) ticket_s = 0u;
+            __syncthreads();
+            if (tid > 0u && tid < G) {
+                const uint32_t s = tid * per;
+                if (s < d.nseg) {
+                    const uint4 a = reinterpret_cast<const uint4*>(d.seg_start)[s], p = reinterpret_cast<const uint4*>(d.seg_final)[s - 1u];
+                    if (a.x != p.x || a.y != p.y || a.z != p.z || a.w != p.w) atomicOr(&ticket_s, 1u);
+                }
+            }
+            __syncthreads();
+            if (ticket_s != 0u) band_fix_range(d, M, 0u, d.nseg, L);
         }
     } else {
         band_fix_range(d, M, 0u, d.nseg, L);
