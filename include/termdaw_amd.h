@@ -196,6 +196,9 @@ int td_state_scan_exact(td_state* s);                                     /* sta
 int td_state_render(td_state* s, const char* path_override);
 /* Same render, PCM left in memory: copies frames*2 words to out (may be NULL to query the size). */
 size_t td_state_render_to_memory(td_state* s, void* out, size_t bytes);
+/* The same render, returned as a view of the library's own page-locked read-back buffer (interleaved PCM,
+ * *bytes long; valid until the next render or td_state_free): no second copy.  NULL on failure. */
+const void* td_state_render_view(td_state* s, size_t* bytes);
 size_t td_state_chunk_count(const td_state* s);                            /* cs, state.rs:104 */
 size_t td_state_render_samplerate(const td_state* s);
 size_t td_state_bitdepth(const td_state* s);

@@ -99,6 +99,7 @@ SIGNATURES = {
     "td_state_scan_exact": (_i32, [_vp]),
     "td_state_render": (_i32, [_vp, _cp]),
     "td_state_render_to_memory": (_sz, [_vp, _vp, _sz]),
+    "td_state_render_view": (_vp, [_vp, C.POINTER(_sz)]),
     "td_state_chunk_count": (_sz, [_vp]),
     "td_state_render_samplerate": (_sz, [_vp]),
     "td_state_bitdepth": (_sz, [_vp]),
@@ -451,6 +452,21 @@ class State:
             if not lib().td_state_render_to_memory(self.h, out.ctypes.data_as(_vp), out.nbytes):
                 raise TermdawError(last_error())
         return out.reshape(-1, 2)
+
+    def render_view(self):
+        """Render and return the PCM as a read-only numpy view of the library's page-locked read-back buffer
+        (frames x 2; valid until the next render of this State)."""
+        n = _sz(0)
+        p = lib().td_state_render_view(self.h, C.byref(n))
+        if not p:
+            raise TermdawError(last_error())
+        dt = np.int32 if self.bd > 16 else np.int16
+        if n.value == 0:
+            return np.zeros((0, 2), dt)
+        buf = (C.c_uint8 * n.value).from_address(p)
+        out = np.frombuffer(buf, dtype=dt).reshape(-1, 2)
+        out.flags.writeable = False
+        return out
 
     @property
     def cs(self):

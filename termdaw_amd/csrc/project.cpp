@@ -12,6 +12,8 @@
 #include <fstream>
 #include <sstream>
 
+#include <hip/hip_runtime.h>
+
 #include "engine.h"
 #include "lua_subset.h"
 #include "wav.h"
@@ -114,7 +116,26 @@ struct td_state {
     std::string output_vertex, output_file = "outp.wav";   // main.rs:91-92
     std::vector<Triple> cur_samples;
     std::string dump;
-    std::vector<uint8_t> host_pcm;
+    // read-back buffer of the last render: page-locked, so the device-to-host copy runs at PCIe speed
+    struct Pinned {
+        uint8_t* p = nullptr;
+        size_t n = 0, cap = 0;
+        uint8_t* data() { return p; }
+        size_t size() const { return n; }
+        void clear() { n = 0; }
+        bool resize(size_t want) {
+            if (want > cap) {
+                if (p) (void)hipHostFree(p);
+                p = nullptr;
+                cap = 0;
+                if (hipHostMalloc((void**)&p, want + want / 4 + 4096, hipHostMallocDefault) != hipSuccess) return false;
+                cap = want + want / 4 + 4096;
+            }
+            n = want;
+            return true;
+        }
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+    } host_pcm;
     size_t out_frames = 0;
 };
 
@@ -545,7 +566,7 @@ static int state_render_device(td_state* s) {
         return 0;
     }
     s->out_frames = frames;
-    s->host_pcm.resize(frames * 2 * word);
+    if (!s->host_pcm.resize(frames * 2 * word)) return fail("termdaw_amd: out of page-locked host memory for the PCM read-back");
     return td_graph_read_pcm(s->g, s->host_pcm.data(), s->host_pcm.size());
 }
 
@@ -571,6 +592,13 @@ size_t td_state_render_to_memory(td_state* s, void* out, size_t bytes) {
     }
     memcpy(out, s->host_pcm.data(), s->host_pcm.size());
     return s->host_pcm.size();
+}
+
+const void* td_state_render_view(td_state* s, size_t* bytes) {
+    if (bytes) *bytes = 0;
+    if (!state_render_device(s)) return nullptr;
+    if (bytes) *bytes = s->host_pcm.size();
+    return s->host_pcm.size() ? (const void*)s->host_pcm.data() : (const void*)"";
 }
 
 size_t td_state_chunk_count(const td_state* s) { return s->cs; }

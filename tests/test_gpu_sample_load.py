@@ -118,3 +118,18 @@ def test_headless_driver(gpu_api, oracle, tmp_path):
     got = np.frombuffer(open(out, "rb").read()[44:], "<i2").reshape(-1, 2)
     want, _ = p.render(oracle, scan=True)
     assert np.array_equal(got, want)
+
+
+def test_state_render_view_matches_render_to_memory(gpu_api, tmp_path):
+    p = W.config1(seconds=0.25)
+    lua = p.to_lua(str(tmp_path / "a"))
+    s = gpu_api.State("", 48000, 1024)
+    assert s.refresh(lua), gpu_api.last_error()
+    a = s.render_to_memory()
+    v = s.render_view()
+    # (two renders of one State: the second continues carried state exactly like the reference would)
+    b = s.render_to_memory()
+    s2 = gpu_api.State("", 48000, 1024)
+    assert s2.refresh(lua)
+    assert np.array_equal(s2.render_view(), a)
+    assert v.shape == a.shape == b.shape and v.dtype == a.dtype and not v.flags.writeable

@@ -9,7 +9,8 @@ s = api.State("", 48000, 1024)
 t0 = time.perf_counter(); assert s.refresh(lua), api.last_error(); t_load = time.perf_counter() - t0
 out = os.path.join(d, "o.wav")
 s.render(out)
-for label, fn in (("render+D2H+WAV write", lambda: s.render(out)), ("render+D2H (memory)", lambda: s.render_to_memory())):
+for label, fn in (("render+D2H+WAV write", lambda: s.render(out)), ("render+D2H (memory)", lambda: s.render_to_memory()),
+                  ("render+D2H (pinned view)", lambda: s.render_view())):
     ts = []
     for _ in range(5):
         t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
