@@ -173,20 +173,21 @@ bool write_wav_int(const char* path, const void* words, size_t frames, int chann
         return false;
     }
     bool ok = fwrite(h.data(), 1, h.size(), f) == h.size();
-    std::vector<uint8_t> body;
-    body.reserve(data_bytes + 1);
-    if (bits == 16 || bits == 32) {   // little-endian host: the words are the file bytes
-        body.resize(data_bytes);
-        memcpy(body.data(), words, data_bytes);
-    } else if (bits == 8) {
-        const int16_t* w = (const int16_t*)words;
-        for (size_t i = 0; i < n; ++i) body.push_back((uint8_t)(w[i] + 128));
+    if (bits == 16 || bits == 32) {   // little-endian host: the words are the file bytes, written in place
+        ok = ok && fwrite(words, 1, data_bytes, f) == data_bytes;
     } else {
-        const int32_t* w = (const int32_t*)words;
-        for (size_t i = 0; i < n; ++i) { body.push_back(w[i] & 0xFF); body.push_back((w[i] >> 8) & 0xFF); body.push_back((w[i] >> 16) & 0xFF); }
+        std::vector<uint8_t> body;
+        body.reserve(data_bytes + 1);
+        if (bits == 8) {
+            const int16_t* w = (const int16_t*)words;
+            for (size_t i = 0; i < n; ++i) body.push_back((uint8_t)(w[i] + 128));
+        } else {
+            const int32_t* w = (const int32_t*)words;
+            for (size_t i = 0; i < n; ++i) { body.push_back(w[i] & 0xFF); body.push_back((w[i] >> 8) & 0xFF); body.push_back((w[i] >> 16) & 0xFF); }
+        }
+        ok = ok && fwrite(body.data(), 1, body.size(), f) == body.size();
     }
-    if (data_bytes & 1) body.push_back(0);
-    ok = ok && fwrite(body.data(), 1, body.size(), f) == body.size();
+    if (data_bytes & 1) ok = ok && fputc(0, f) != EOF;
     ok = (fclose(f) == 0) && ok;
     if (!ok) *err = std::string("short write to \"") + path + "\"";
     return ok;
