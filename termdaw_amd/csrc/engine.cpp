@@ -995,7 +995,8 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
             }
             // (the band-pass pre-sum keeps the pair mapping: its block-liveness reduction is written for it)
             if (all_loop16 && g->vertices[vi].kind == K_BAND_PASS) all_loop16 = false;
-            term_mode[vi] = all_edge ? TERMS_ALL_EDGE : (all_loop16 ? TERMS_ALL_LOOP16 : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED));
+            term_mode[vi] = all_edge ? (ins.size() < 8 ? TERMS_EDGE_FEW : TERMS_ALL_EDGE)
+                                     : (all_loop16 ? TERMS_ALL_LOOP16 : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED));
             ins_off[vi] = st.put(ins);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
@@ -1184,6 +1185,10 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     }
                 } break;
                 case F_ADSR: {
+                    // (k_adsr is instantiated per term mode like k_sum; its pair mapping has no packed-loop form)
+                    for (size_t vi : vs)
+                        if (term_mode[vi] == TERMS_ALL_LOOP16) term_mode[vi] = TERMS_MIXED;
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[a] < term_mode[b]; });
                     std::vector<AdsrVDesc> d;
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
@@ -1283,12 +1288,13 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_BAND_FILL: off = band_desc_off; break;   // reuse the k_band_spec descriptors
                 default: continue;
             }
-            if (fam == F_SUM) {   // split at term-mode boundaries (vs is sorted by it)
+            if (fam == F_SUM || fam == F_ADSR) {   // split at term-mode boundaries (vs is sorted by it)
+                const size_t dsz = fam == F_SUM ? sizeof(SumDesc) : sizeof(AdsrVDesc);
                 size_t b = 0;
                 while (b < vs.size()) {
                     size_t e2 = b;
                     while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) ++e2;
-                    launches.push_back({F_SUM, off + b * sizeof(SumDesc), (int)(e2 - b), term_mode[vs[b]], lv});
+                    launches.push_back({fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]], lv});
                     b = e2;
                 }
                 continue;
@@ -1370,7 +1376,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, L.aux, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, s); break;
-                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
                 case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
                 case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;

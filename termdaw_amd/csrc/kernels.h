@@ -48,7 +48,8 @@ struct InTerm {
     uint32_t magic;
     float scale_l, scale_r;   // kind 3
 };
-enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2, TERMS_ALL_LOOP16 = 3 };
+enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2, TERMS_ALL_LOOP16 = 3,
+                           TERMS_EDGE_FEW = 4 };   // all edge buffers, fewer than 8: no deep prefetch pipeline (and its registers)
 
 // Running-peak bookkeeping of normalize_gen (extensions.rs:321-329), carried across chunks / passes.
 struct NormState { float max, scan_max; };
@@ -298,7 +299,7 @@ void launch_sample_lerp(const LerpDesc* d, int n_desc, uint32_t frames, hipStrea
 void launch_debug_sine(const SineDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
 void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sampsyn(const SampsynDesc* d, int n_desc, uint32_t frames, hipStream_t s);
-void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 
 }  // namespace tdk

@@ -207,7 +207,7 @@ TD_DEV void sum_terms(TermTab ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_
         float4 x0[4], x1[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (MODE == TERMS_ALL_EDGE) { const float2* p = ins[j + u].p; x0[u] = load_pair(p, m0, M); x1[u] = load_pair(p, m1, M); }
+            if (MODE == TERMS_ALL_EDGE || MODE == TERMS_EDGE_FEW) { const float2* p = ins[j + u].p; x0[u] = load_pair(p, m0, M); x1[u] = load_pair(p, m1, M); }
             else if (MODE == TERMS_ALL_LOOP32) { x0[u] = loop_term_pair(ins, j + u, m0, M); x1[u] = loop_term_pair(ins, j + u, m1, M); }
             else { x0[u] = term_pair(ins, j + u, m0, M); x1[u] = term_pair(ins, j + u, m1, M); }
         }
@@ -729,12 +729,13 @@ TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
     const float vel = lerpf(1.0f, adsr_vel, d.wet);
     return make_float2(x.x * vel, x.y * vel);
 }
+template <int TMODE>
 __global__ __launch_bounds__(kThreads) void k_adsr(const AdsrVDesc* __restrict__ descs, uint32_t M) {
     const AdsrVDesc& d = descs[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
-    float4 a0, a1;
-    sum_inputs_pairs(d.ins, d.k, d.term_mode, m0, m1, M, a0, a1);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+    sum_terms<TMODE>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
     if (m0 < M) {
         float2 a = adsr_frame(d, m0, make_float2(a0.x, a0.y));
         float2 b = (m0 + 1 < M) ? adsr_frame(d, m0 + 1, make_float2(a0.z, a0.w)) : make_float2(0.f, 0.f);
@@ -1526,6 +1527,7 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
         case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         case TERMS_ALL_LOOP32: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         case TERMS_ALL_LOOP16: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_EDGE_FEW>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         default: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_MIXED>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
     }
 }
@@ -1562,9 +1564,14 @@ void launch_sampsyn(const SampsynDesc* d, int n, uint32_t frames, hipStream_t s)
     if (!n || !frames) return;
     TD_BATCHED(k_sampsyn, tiles(frames), kThreads, d, n, frames);
 }
-void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t s) {
+void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {
     if (!n || !frames) return;
-    TD_BATCHED(k_adsr, tiles(frames), kThreads, d, n, frames);
+    switch (term_mode) {
+        case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_adsr<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames); break;
+        case TERMS_ALL_LOOP32: TD_BATCHED(HIP_KERNEL_NAME(k_adsr<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames); break;
+        case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_adsr<TERMS_EDGE_FEW>), tiles(frames), kThreads, d, n, frames); break;
+        default: TD_BATCHED(HIP_KERNEL_NAME(k_adsr<TERMS_MIXED>), tiles(frames), kThreads, d, n, frames); break;
+    }
 }
 void launch_band_pass(const BandDesc* d, int n, uint32_t frames, hipStream_t s) {   // vertex index in grid.x
     if (!n || !frames) return;
