@@ -808,7 +808,7 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     const double w = (double)g->band_warmup / (double)gmin + 64.0;
     if (!(w <= 262144.0)) return p;   // cut-offs below ~5 Hz: the serial kernel is the better plan
     p.W = ((uint32_t)w + 31u) & ~31u;
-    p.Ws = std::min(p.W, ((uint32_t)(40.0 / (double)gmin + 64.0) + 31u) & ~31u);   // coalescence only
+    p.Ws = std::min(p.W, ((uint32_t)((double)g->band_short / (double)gmin + 64.0) + 31u) & ~31u);   // coalescence only
     p.Ws = (p.Ws + 255u) & ~255u;                                                   // whole 256-frame liveness blocks
     p.W = std::max(p.W, p.Ws);
     p.S = 256;
@@ -2082,6 +2082,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
     if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
+    if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }

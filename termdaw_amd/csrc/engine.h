@@ -201,6 +201,7 @@ struct td_graph {
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
+    unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
     std::vector<size_t> band_stats_off;        // scratch offsets of the last chunk's k_band_fix counters
