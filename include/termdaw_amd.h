@@ -173,12 +173,16 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "packed_samples" 0|1 (default 1: inlined sources gather the packed 16-bit form of samples that came from
  * <= 16-bit integer PCM -- (float)int * scale is how the f32 bank entry was made, so values are identical);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
+ * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
+ * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed
+ * only, the bit-wise check and repair keep every result exact);
  * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
  * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */
 int td_graph_set_option(td_graph* g, const char* key, long value);
 /* Counters of the exact parallel band-pass for the last rendered chunk, summed over its band-pass
- * vertices: out[0] segments whose speculative entry state failed the bit-wise check, out[1] segments
- * recomputed sequentially, out[2] of those cut short by a fixed point under constant input. */
+ * vertices: out[0] repair cascades started (segments whose entry state failed the bit-wise check, incl.
+ * re-checks after optimistic repairs), out[1] segments recomputed, out[2] of those cut short by a fixed point
+ * under constant input. */
 int td_graph_band_stats(const td_graph* g, uint32_t out[3]);
 
 /* ---- Project front-end: State (state.rs:27-578) -------------------------------------------- */
