@@ -415,6 +415,15 @@ static void compile_multi(Vertex& v, size_t L, const td_flowwbank* fb, const std
         if (h.origin + (int64_t)L > (int64_t)M) v.ts.push_back({(int64_t)M - h.origin, h.vel});
     vt.n_hits = (uint32_t)hits.size();
     vt.hits_off = st.put(hits);
+    // per tile: first hit whose voice can still sound at the tile's first frame
+    std::vector<uint32_t> tf((M + kTileFrames - 1) / kTileFrames + 1);
+    uint32_t j = 0;
+    for (size_t t = 0; t < tf.size(); ++t) {
+        const int64_t lo_key = (int64_t)(t * kTileFrames) - (int64_t)L;
+        while (j < hits.size() && hits[j].origin <= lo_key) ++j;
+        tf[t] = j;
+    }
+    vt.tile_first_off = st.put(tf);
 }
 
 // ---- SampleLerp (extensions.rs:384-421) ----
@@ -445,6 +454,14 @@ static void compile_lerp(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
     v.g_vel = g.vel;
     vt.n_hits = (uint32_t)hits.size();
     vt.hits_off = st.put(hits);
+    // per tile: number of entries whose key is <= the tile's first frame
+    std::vector<uint32_t> tf((size_t)(M + kTileFrames - 1) / kTileFrames + 1);
+    uint32_t j = 0;
+    for (size_t t = 0; t < tf.size(); ++t) {
+        while (j < hits.size() && hits[j].key <= (int64_t)(t * kTileFrames)) ++j;
+        tf[t] = j;
+    }
+    vt.tile_first_off = st.put(tf);
 }
 
 static void put_intervals(IntervalBuilder& ib, Staging& st, VTables& vt) {
@@ -1024,11 +1041,13 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
                         const SampleEntry& s = sb->samples[v.sample_index];
-                        d.push_back({s.d, g->vbuf[vi], nullptr, s.len, vt[vi].n_hits, 0, make_pg(v.gain, v.angle)});
+                        d.push_back({s.d, g->vbuf[vi], nullptr, s.len, vt[vi].n_hits, 0, make_pg(v.gain, v.angle), nullptr});
                     }
                     off = st.put(d);
-                    for (size_t i = 0; i < vs.size(); ++i)
+                    for (size_t i = 0; i < vs.size(); ++i) {
                         ptr_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, hits), vt[vs[i]].hits_off);
+                        ptr_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, tile_first), vt[vs[i]].tile_first_off);
+                    }
                 } break;
                 case F_LERP: {
                     std::vector<LerpDesc> d;
@@ -1036,11 +1055,13 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         const Vertex& v = g->vertices[vi];
                         const SampleEntry& s = sb->samples[v.sample_index];
                         d.push_back({s.d, g->vbuf[vi], nullptr, s.len, vt[vi].n_hits, (uint32_t)v.lerp_len,
-                                     make_pg(v.gain, v.angle)});
+                                     make_pg(v.gain, v.angle), nullptr});
                     }
                     off = st.put(d);
-                    for (size_t i = 0; i < vs.size(); ++i)
+                    for (size_t i = 0; i < vs.size(); ++i) {
                         ptr_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, hits), vt[vs[i]].hits_off);
+                        ptr_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, tile_first), vt[vs[i]].tile_first_off);
+                    }
                 } break;
                 case F_SINE: {
                     std::vector<SineDesc> d;

@@ -122,6 +122,7 @@ struct MultiDesc {
     uint32_t n_hits;
     uint32_t pad;
     PanGain pg;
+    const uint32_t* tile_first;   // [tiles]: first hit that can still sound at the tile's first frame (origin > frame - len)
 };
 
 // sample_lerp_gen (extensions.rs:384-421).  key = frame from which the entry is `primary` (INT64_MIN for
@@ -136,6 +137,7 @@ struct LerpDesc {
     uint32_t n_hits;
     uint32_t lerp_len;
     PanGain pg;
+    const uint32_t* tile_first;   // [tiles]: number of entries with key <= the tile's first frame
 };
 
 // Interval tables for the voice-list vertices: the chunk is cut at block starts and event frames into

@@ -481,14 +481,13 @@ __global__ __launch_bounds__(kThreads) void k_sample_loop(const LoopDesc* __rest
 // k_sample_multi (extensions.rs:344-381)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float2 multi_frame(const MultiDesc& d, int64_t m) {
-    // live voices: origin in (m - len, m]; hits are sorted by origin (onset order = deque order)
+    // live voices: origin in (m - len, m]; hits are sorted by origin (onset order = deque order).  The per-tile
+    // table gives the first candidate for the tile's first frame; from there it is a short walk, no search.
     const int64_t lo_key = m - (int64_t)d.len;
-    uint32_t lo = 0, hi = d.n_hits;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.hits[mid].origin > lo_key) hi = mid; else lo = mid + 1; }
-    const uint32_t first = lo;
-    hi = d.n_hits;
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.hits[mid].origin > m) hi = mid; else lo = mid + 1; }
-    const uint32_t last = lo;
+    uint32_t first = d.tile_first[(uint32_t)m / kTileFrames];
+    while (first < d.n_hits && d.hits[first].origin <= lo_key) ++first;
+    uint32_t last = first;
+    while (last < d.n_hits && d.hits[last].origin <= m) ++last;
     float2 acc = make_float2(0.0f, 0.0f);
     for (uint32_t j = first; j < last; ++j) {
         const MultiHit h = d.hits[j];
@@ -518,8 +517,8 @@ __global__ __launch_bounds__(kThreads) void k_sample_multi(const MultiDesc* __re
 // k_sample_lerp (extensions.rs:384-421)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float2 lerp_frame(const LerpDesc& d, int64_t m) {
-    uint32_t lo = 0, hi = d.n_hits;   // number of entries with key <= m (>= 2: the carried pair)
-    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (d.hits[mid].key > m) hi = mid; else lo = mid + 1; }
+    uint32_t lo = d.tile_first[(uint32_t)m / kTileFrames];   // number of entries with key <= m (>= 2: the carried pair)
+    while (lo < d.n_hits && d.hits[lo].key <= m) ++lo;
     const LerpHit p = d.hits[lo - 1];
     const int64_t last = (int64_t)d.len - 1;
     int64_t ppos = m - p.origin;
