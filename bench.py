@@ -213,7 +213,22 @@ def main():
             "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % PROF_EVERY,
             "peak_table": [round(float(x), 6) for x in peaks],
             "device_bytes": g.device_bytes(),
+            # vertex-frames/s = frames x vertices reached from the output
+            "vertex_frames_per_s": round(value * 1e6 * (N_SRC + 1), 0),
         }
+        if world == 1:
+            # outside the timed region, for reference only (never `value`): one render plus the copy of its
+            # 16-bit PCM to host memory (pageable numpy array), median of 5
+            ts = []
+            for _ in range(5):
+                step_t0 = time.perf_counter()
+                g.reset_normalize_vertices()
+                fb.set_time(0)
+                g.render_all(sb, fb, cs, 16, want_f32=False, want_pcm=True)
+                ts.append(time.perf_counter() - step_t0)
+            ts.sort()
+            out["pcie_inclusive"] = {"ms_per_render": round(ts[2] * 1e3, 4), "Msamples_per_s": round(frames / ts[2] / 1e6, 1),
+                                     "note": "render + D2H of the PCM into pageable host memory; not part of `value`"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(project, frames)
             out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
