@@ -73,8 +73,46 @@ def cpu_baseline(project, frames, runs=5):
     }
 
 
+def cpu_worker(seed_offset, seconds):
+    """One config-5 project (config 2, seeds offset) on this process' core; prints its render time."""
+    from termdaw_amd import workloads
+    from oracle import binding as oracle
+    p = workloads.config2(seconds=seconds, n_src=N_SRC, seed_offset=seed_offset)
+    built = p.build(oracle)
+    p.render(oracle, built=built, want_f32=False)        # warm
+    built = p.build(oracle)
+    t0 = time.perf_counter()
+    p.render(oracle, built=built, want_f32=False)
+    print("CPU_WORKER %.6f %d" % (time.perf_counter() - t0, p.cs * p.bl), flush=True)
+
+
+def cpu_all_cores(seconds, workers):
+    """Context for config 5: one project per host core, all at once, each through the single-threaded
+    oracle in its own process (started before anything here touches the GPU runtime in THAT process)."""
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(64 * i), "--seconds", str(seconds)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(workers)]
+    rate = 0.0
+    done = 0
+    slowest = 0.0
+    for p in procs:
+        out, _ = p.communicate(timeout=600)
+        for line in out.splitlines():
+            if line.startswith("CPU_WORKER"):
+                _, sec, fr = line.split()
+                rate += float(fr) / float(sec)
+                slowest = max(slowest, float(sec))
+                done += 1
+    if not done:
+        return None
+    return {"value": round(rate / 1e6, 2), "unit": "Msamples/s", "cores": done, "kind": "port",
+            "sample": "%d processes x 1 project each (config 2, seeds offset by 64 per process), all concurrently; sum of the "
+                      "per-process rates; slowest render %.3f s" % (done, slowest)}
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
@@ -83,6 +121,9 @@ def main():
     ap.add_argument("--no-fuse", action="store_true", help="edge-buffer model: one HBM buffer per source vertex (no source inlining)")
     ap.add_argument("--no-pack", action="store_true", help="inlined sources gather the f32 sample form (8 B/frame) instead of the packed 16-bit one")
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        cpu_worker(args.cpu_worker, args.seconds)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -232,6 +273,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(project, frames)
             out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+            allc = cpu_all_cores(args.seconds, min(os.cpu_count() or 1, 256))
+            if allc:
+                out["cpu_baseline_all_cores"] = allc
+                out["gpu_over_cpu_all_cores"] = round(out["value"] / allc["value"], 1)
         result_line = json.dumps(out)
     else:
         result_line = None
