@@ -99,11 +99,13 @@ int resample_device(const float2* in, size_t len, size_t from, size_t to, float2
     float* d_T = nullptr;
     float2* d_out = nullptr;
     TD_HIP(hipMalloc(&d_T, T.size() * sizeof(float)));
-    TD_HIP(hipMalloc(&d_out, (nout + (nout & 1) + 1) * sizeof(float2)));
+    TD_HIP(hipMalloc(&d_out, (nout + (nout & 1) + 3) * sizeof(float2)));
     TD_HIP(hipMemcpyAsync(d_T, T.data(), T.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    TD_HIP(hipMemsetAsync(d_out + nout - (nout ? 1 : 0), 0, 2 * sizeof(float2), st));
+    TD_HIP(hipMemsetAsync(d_out + nout - (nout ? 1 : 0), 0, 4 * sizeof(float2), st));
     ResampleDesc d{in, d_out, d_T, len, nout, from, to};
     launch_resample(d, st);
+    if (nout)   // frame nout = frame 0 again (wrap frame, as in every bank entry)
+        TD_HIP(hipMemcpyAsync(d_out + nout, d_out, sizeof(float2), hipMemcpyDeviceToDevice, st));
     TD_HIP(hipStreamSynchronize(st));
     TD_HIP(hipGetLastError());
     (void)hipFree(d_T);
@@ -220,14 +222,15 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     if (n == 0) { cleanup(); return fail("TermDaw: Sample::from: l and r have length 0."); }
     SampleEntry e;
     e.len = n;
-    TD_HIP(hipMalloc(&e.d, (n + (n & 1)) * sizeof(float2)));
-    TD_HIP(hipMemsetAsync(e.d + (n - 1 + (n & 1)), 0, sizeof(float2), st));   // pad frame of an odd length
+    // n frames, then frame 0 again (wrap frame for looping readers), padded to an even count
+    TD_HIP(hipMalloc(&e.d, (n + 2 + (n & 1)) * sizeof(float2)));
+    TD_HIP(hipMemsetAsync(e.d + n, 0, (2 + (n & 1)) * sizeof(float2), st));
     launch_sample_pack(d_l, d_r, p_max_l, p_max_r, e.d, (uint32_t)n, st);
     // packed 16-bit twin: only when l / r are still the raw integer PCM values times one scale per channel
     // (every mode but mix-down) and no resample follows
     bool want16 = method != LM_MIX && sr == sb->sample_rate && n >= 1 && n < 0x3FFFFFF0u;
     if (want16) {
-        TD_HIP(hipMalloc(&e.d16, 4 * ((n + 3) & ~(size_t)3) * sizeof(uint32_t)));   // four phase-shifted copies
+        TD_HIP(hipMalloc(&e.d16, ((n + 6) & ~(size_t)3) * sizeof(uint32_t)));   // the loop + its first three frames again
         TD_HIP(hipMemsetAsync(d_s + 8, 0, sizeof(uint32_t), st));
         launch_sample_pack16(d_l, d_r, e.d16, (uint32_t)n, reinterpret_cast<uint32_t*>(d_s + 8), st);
     }
