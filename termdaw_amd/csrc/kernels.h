@@ -31,10 +31,10 @@ struct PanGain {
 //           "source inlining").  32-bit form: t0 + m < 2^32, modulo by Barrett reduction with
 //           magic = floor(2^32 / len).
 //   kind 2: the same with 64-bit cursor / length (generic modulo).
-//   kind 3: kind 1 over the sample's packed 16-bit form: one 32-bit word per frame (int16 l | int16 r << 16),
-//           stored as four phase-shifted copies (copy c, word p = frame (p + c) % len, stride roundup(len, 4))
-//           so that any four consecutive loop frames are one aligned 16-byte load; the f32 frame is rebuilt as (float)l * scale_l, (float)r * scale_r -- the very
-//           expression the load pipeline used to produce the f32 bank entry (sample.rs:270-273 `as f32`,
+//   kind 3: kind 1 over the sample's packed 16-bit form: one 32-bit word per frame (int16 l | int16 r << 16), the
+//           loop followed by its own first three frames, so that any four consecutive loop frames are one
+//           dword-aligned 16-byte load; the f32 frame is rebuilt as (float)l * scale_l, (float)r * scale_r -- the
+//           very expression the load pipeline used to produce the f32 bank entry (sample.rs:270-273 `as f32`,
 //           sample.rs:121-129 `* (1.0 / max)`), so the values are bit-identical at half the gather bytes.
 //   kind 4: an edge buffer read THROUGH a Sum vertex that has this one input only (a gain / pan stage): the
 //           consumer computes `0.0 + x`, pan, gain itself (extensions.rs:310-319, sample.rs:97-114) and the
