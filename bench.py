@@ -247,12 +247,19 @@ def main():
                         ("source inlining: k_sum's algorithmic bytes are its own gathers, (%dk+8) B/frame -- k looping "
                          "samples read in place (%s) + one raw-sum write; the k source edge buffers of SURVEY 8(d)'s "
                          "(8k+8) model never exist.  The gathers re-read the %s sample set ~37x per launch, so they are "
-                         "served by the 256 MB Infinity Cache, not HBM (`traffic` = PMC L2-miss-side bytes per launch, "
-                         "profiles/traffic.json): the bound that applies is the Infinity Cache gather rate "
-                         "(MI355X_MICROARCH.md: 8.6 TB/s for a 38 MB table), frac_of_mall_gather below; "
+                         "served by L2 (hit rate 25-40%%) and the 256 MB Infinity Cache, not HBM -- which is why `frac` can "
+                         "exceed 1 (`traffic` = PMC L2-miss-side bytes per launch, profiles/traffic.json; `beyond_l2` "
+                         "prices those against the 8 TB/s peak): the bound that applies is the cache hierarchy's gather "
+                         "rate (MI355X_MICROARCH.md: 8.6 TB/s for a 38 MB table from the Infinity Cache), "
+                         "frac_of_mall_gather below; "
                          "`survey_model` restates the same launch time against SURVEY's (8k+8) figure; --no-fuse runs "
                          "the edge-buffer model itself" % ((4, "packed 16-bit, 4 B", "20 MB") if packed else (8, "f32, 8 B", "40 MB"))),
                 "frac_of_mall_gather_8.6TBs": None if not fused else round(dom["achieved_GBs"] / 8600.0, 4),
+                # what actually crosses the L2 -> fabric boundary (Infinity Cache + HBM), from the PMC pass
+                "beyond_l2": None if not traffic else {
+                    "bytes_per_launch": traffic,
+                    "GBs": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9, 1),
+                    "frac_of_8TBs": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
                 "survey_model": None if not fused else {
                     "bytes_per_frame": survey_abf[dom["kernel"]] if dom["kernel"] in survey_abf else None,
                     "achieved": round(survey_abf.get(dom["kernel"], 0.0) * frames / (dom["avg_ms"] * 1e-3) / 1e9, 1),
