@@ -230,7 +230,7 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     // (every mode but mix-down) and no resample follows
     bool want16 = method != LM_MIX && sr == sb->sample_rate && n >= 1 && n < 0x3FFFFFF0u;
     if (want16) {
-        TD_HIP(hipMalloc(&e.d16, ((n + 6) & ~(size_t)3) * sizeof(uint32_t)));   // the loop + its first three frames again
+        TD_HIP(hipMalloc(&e.d16, ((n + 18) & ~(size_t)3) * sizeof(uint32_t)));   // the loop + its first 15 frames again
         TD_HIP(hipMemsetAsync(d_s + 8, 0, sizeof(uint32_t), st));
         launch_sample_pack16(d_l, d_r, e.d16, (uint32_t)n, reinterpret_cast<uint32_t*>(d_s + 8), st);
     }
@@ -1317,8 +1317,12 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 size_t b = 0;
                 while (b < vs.size()) {
                     size_t e2 = b;
-                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) ++e2;
-                    launches.push_back({fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]], lv});
+                    bool wide_ok = true;   // (k_sum16w: plain sums, or normalize pass A with the tile as reference block)
+                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) {
+                        wide_ok = wide_ok && (g->vertices[vs[e2]].kind != K_NORMALIZE || bl == (size_t)kTileFrames);
+                        ++e2;
+                    }
+                    launches.push_back({fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u), lv});
                     b = e2;
                 }
                 continue;
@@ -1398,9 +1402,9 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                 case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, L.aux, s); break;
+                case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, s); break;
-                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
+                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, L.aux & 0xFFu, s); break;
                 case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, s); break;
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
                 case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;

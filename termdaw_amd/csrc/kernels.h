@@ -32,8 +32,8 @@ struct PanGain {
 //           magic = floor(2^32 / len).
 //   kind 2: the same with 64-bit cursor / length (generic modulo).
 //   kind 3: kind 1 over the sample's packed 16-bit form: one 32-bit word per frame (int16 l | int16 r << 16), the
-//           loop followed by its own first three frames, so that any four consecutive loop frames are one
-//           dword-aligned 16-byte load; the f32 frame is rebuilt as (float)l * scale_l, (float)r * scale_r -- the
+//           loop followed by its own first 15 frames, so that up to 16 consecutive loop frames are dword-aligned
+//           16-byte loads behind ONE modulo; the f32 frame is rebuilt as (float)l * scale_l, (float)r * scale_r -- the
 //           very expression the load pipeline used to produce the f32 bank entry (sample.rs:270-273 `as f32`,
 //           sample.rs:121-129 `* (1.0 / max)`), so the values are bit-identical at half the gather bytes.
 //   kind 4: an edge buffer read THROUGH a Sum vertex that has this one input only (a gain / pan stage): the
@@ -292,7 +292,7 @@ void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
-void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, hipStream_t s);
+void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStream_t s);

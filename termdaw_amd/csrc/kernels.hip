@@ -280,6 +280,48 @@ TD_DEV void sum_terms16(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4&
     acc1 = zero_tail(make_float4(c[2].x, c[2].y, c[3].x, c[3].y), m + 2u, M);
 }
 
+// all terms kind 3, 4 * NQ consecutive frames per lane (NQ 16-byte gathers per source).  More frames per lane =
+// more of the timeline resident per XCD at any moment = more of the concurrently running tiles touch the same
+// lines of a looping source while they are still in L2.  The packed form carries 15 wrap frames, so one modulo
+// per source and lane is enough.
+template <int NQ>
+TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4 acc[2 * NQ]) {
+    f2v c[4 * NQ];
+#pragma unroll
+    for (int f = 0; f < 4 * NQ; ++f) { c[f].x = 0.f; c[f].y = 0.f; }
+    auto add_term = [&](uint32_t j, const uint32_t w[4 * NQ]) {
+        f2v sc, am, gn;   // (the host leaves l_amp / r_amp / gain at 1.0f when their flag is clear)
+        sc.x = ins[j].scale_l; sc.y = ins[j].scale_r;
+        am.x = ins[j].pg.l_amp; am.y = ins[j].pg.r_amp;
+        gn.x = gn.y = ins[j].pg.gain;
+#pragma unroll
+        for (int f = 0; f < 4 * NQ; ++f) {
+            f2v v = cvt16(w[f]) * sc;
+            v = v * am;
+            v = v * gn;
+            c[f] = c[f] + v;
+        }
+    };
+    auto gather = [&](uint32_t j, uint32_t w[4 * NQ]) {
+        const uint32_t len = (uint32_t)ins[j].len;
+        const uint32_t idx = barrett_mod((uint32_t)ins[j].t0 + m, len, ins[j].magic);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) loop16_quad(reinterpret_cast<const uint32_t*>(ins[j].p), len, idx + 4u * q, w + 4 * q);
+    };
+    uint32_t j = 0;
+    constexpr int B = NQ >= 4 ? 1 : (NQ == 2 ? 2 : 4);   // sources per batch: 16 x 16-byte loads in flight per lane... 4 x NQ
+    for (; j + B <= k; j += B) {
+        uint32_t w[B][4 * NQ];
+#pragma unroll
+        for (int u = 0; u < B; ++u) gather(j + u, w[u]);
+#pragma unroll
+        for (int u = 0; u < B; ++u) add_term(j + u, w[u]);
+    }
+    for (; j < k; ++j) { uint32_t w[4 * NQ]; gather(j, w); add_term(j, w); }
+#pragma unroll
+    for (int q = 0; q < 2 * NQ; ++q) acc[q] = zero_tail(make_float4(c[2 * q].x, c[2 * q].y, c[2 * q + 1].x, c[2 * q + 1].y), m + 2u * q, M);
+}
+
 TD_DEV void sum_inputs_pairs(const InTerm* ins_generic, uint32_t k, uint32_t term_mode, uint32_t m0, uint32_t m1, uint32_t M,
                              float4& a0, float4& a1) {
     const TermTab ins = term_tab(ins_generic);
@@ -400,6 +442,42 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
                 atomicMax(reinterpret_cast<unsigned int*>(d.peaks + m / bl), __float_as_uint(pk));
             }
         }
+    }
+}
+
+// k_sum for all-packed-loop terms with 4 * NQ frames per lane: Sum vertices, and Normalize pass A when the
+// reference block is the 1024-frame tile (a workgroup then covers NQ whole blocks, a block 4 / NQ waves).
+template <int NQ>
+__global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__ descs, uint32_t M) {
+    const SumDesc& d = descs[blockIdx.y];
+    const uint32_t m = blockIdx.x * (kTileFrames * NQ) + 4u * NQ * threadIdx.x;
+    float4 a[2 * NQ];
+    sum_terms16w<NQ>(term_tab(d.ins), d.k, m, M, a);
+    if (d.mode == 0) {
+#pragma unroll
+        for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, epilogue4(a[q], d.pg));
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        d.init_copy[0] = d.use_init ? d.init_max : d.state->max;
+        d.init_copy[1] = d.state->scan_max;
+    }
+    float pk = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 2 * NQ; ++q) if (m + 2u * q < M) pk = absmax4(pk, a[q]);
+    pk = wave_max(pk);
+    __shared__ float wm[kThreads / 64];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = pk;
+    __syncthreads();
+    // wave w covers frames [256 NQ w, 256 NQ (w + 1)) of the tile: block (of 1024) = w * NQ / 4
+    if (threadIdx.x < (uint32_t)NQ) {
+        constexpr uint32_t wpb = 4 / NQ;   // waves per block (NQ = 1, 2, 4)
+        float p = wm[threadIdx.x * wpb];
+        for (uint32_t u = 1; u < wpb; ++u) p = fmaxf(p, wm[threadIdx.x * wpb + u]);
+        const uint32_t b = blockIdx.x * NQ + threadIdx.x;
+        if (b * kTileFrames < M) d.peaks[b] = p;
     }
 }
 
@@ -1524,13 +1602,23 @@ constexpr int kMaxGridY = 65535;
     for (int o_ = 0; o_ < (N); o_ += kMaxGridY)                                                             \
         hipLaunchKernelGGL(KERNEL, dim3((GRID_X), std::min((N) - o_, kMaxGridY)), dim3(BLOCK), 0, s, (D) + o_, __VA_ARGS__)
 
-void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, hipStream_t s) {
+void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
     switch (term_mode) {
         case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         case TERMS_ALL_LOOP32: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
-        case TERMS_ALL_LOOP16: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        case TERMS_ALL_LOOP16:
+            // wide_ok: every descriptor is a plain Sum or a Normalize whose reference block is the 1024-frame tile.
+            // Long timelines take more frames per lane (more of the timeline resident per XCD -> more L2 hits among
+            // concurrently running tiles); short ones keep the workgroup count up.
+            if (wide_ok && frames >= 2048u * kTileFrames)
+                TD_BATCHED(HIP_KERNEL_NAME(k_sum16w<4>), (frames + kTileFrames * 4 - 1) / (kTileFrames * 4), kThreads, d, n, frames);
+            else if (wide_ok && frames >= 512u * kTileFrames)
+                TD_BATCHED(HIP_KERNEL_NAME(k_sum16w<2>), (frames + kTileFrames * 2 - 1) / (kTileFrames * 2), kThreads, d, n, frames);
+            else
+                TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb);
+            break;
         case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_EDGE_FEW>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         default: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_MIXED>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
     }
@@ -1623,7 +1711,7 @@ __global__ __launch_bounds__(kThreads) void k_sample_pack16(const float* __restr
                                                             uint32_t* __restrict__ packed, uint32_t n, uint32_t* not_int16) {
     // word i = frame i % n for i < roundup(n + 3, 4): the loop plus its first frames again, so that any four
     // consecutive loop frames (wrap included) are four consecutive words
-    const uint32_t total = (n + 3u + 3u) & ~3u;
+    const uint32_t total = (n + 15u + 3u) & ~3u;
     bool bad = false;
     for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < total; i += gridDim.x * kThreads) {
         const uint32_t f = i % n;
@@ -1635,7 +1723,7 @@ __global__ __launch_bounds__(kThreads) void k_sample_pack16(const float* __restr
     if (__any(bad ? 1 : 0) && (threadIdx.x & 63) == 0) atomicOr(not_int16, 1u);
 }
 void launch_sample_pack16(const float* l, const float* r, uint32_t* packed, uint32_t n, uint32_t* not_int16, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_sample_pack16, dim3(grid_for((n + 6u) & ~3u)), dim3(kThreads), 0, s, l, r, packed, n, not_int16);
+    if (n) hipLaunchKernelGGL(k_sample_pack16, dim3(grid_for((n + 18u) & ~3u)), dim3(kThreads), 0, s, l, r, packed, n, not_int16);
 }
 void launch_sample_pack(const float* l, const float* r, const float* max_l, const float* max_r, float2* frames, uint32_t n,
                         hipStream_t s) {
