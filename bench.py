@@ -247,7 +247,7 @@ def main():
                         ("source inlining: k_sum's algorithmic bytes are its own gathers, (%dk+8) B/frame -- k looping "
                          "samples read in place (%s) + one raw-sum write; the k source edge buffers of SURVEY 8(d)'s "
                          "(8k+8) model never exist.  The gathers re-read the %s sample set ~37x per launch, so they are "
-                         "served by L2 (hit rate 25-40%%) and the 256 MB Infinity Cache, not HBM -- which is why `frac` can "
+                         "served by L2 (hit rate 25-76%%) and the 256 MB Infinity Cache, not HBM -- which is why `frac` can "
                          "exceed 1 (`traffic` = PMC L2-miss-side bytes per launch, profiles/traffic.json; `beyond_l2` "
                          "prices those against the 8 TB/s peak): the bound that applies is the cache hierarchy's gather "
                          "rate (MI355X_MICROARCH.md: 8.6 TB/s for a 38 MB table from the Infinity Cache), "
