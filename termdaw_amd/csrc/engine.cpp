@@ -99,13 +99,17 @@ int resample_device(const float2* in, size_t len, size_t from, size_t to, float2
     float* d_T = nullptr;
     float2* d_out = nullptr;
     TD_HIP(hipMalloc(&d_T, T.size() * sizeof(float)));
-    TD_HIP(hipMalloc(&d_out, (nout + (nout & 1) + 3) * sizeof(float2)));
+    TD_HIP(hipMalloc(&d_out, (nout + (nout & 1) + 17) * sizeof(float2)));
     TD_HIP(hipMemcpyAsync(d_T, T.data(), T.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    TD_HIP(hipMemsetAsync(d_out + nout - (nout ? 1 : 0), 0, 4 * sizeof(float2), st));
+    TD_HIP(hipMemsetAsync(d_out + nout - (nout ? 1 : 0), 0, 18 * sizeof(float2), st));
     ResampleDesc d{in, d_out, d_T, len, nout, from, to};
     launch_resample(d, st);
-    if (nout)   // frame nout = frame 0 again (wrap frame, as in every bank entry)
-        TD_HIP(hipMemcpyAsync(d_out + nout, d_out, sizeof(float2), hipMemcpyDeviceToDevice, st));
+    // frames nout .. nout + 14 = the first frames again (wrap frames, as in every bank entry)
+    for (size_t i = 0; nout && i < 15;) {
+        const size_t src = i % nout, cnt = std::min<size_t>(15 - i, nout - src);
+        TD_HIP(hipMemcpyAsync(d_out + nout + i, d_out + src, cnt * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        i += cnt;
+    }
     TD_HIP(hipStreamSynchronize(st));
     TD_HIP(hipGetLastError());
     (void)hipFree(d_T);
@@ -222,9 +226,9 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     if (n == 0) { cleanup(); return fail("TermDaw: Sample::from: l and r have length 0."); }
     SampleEntry e;
     e.len = n;
-    // n frames, then frame 0 again (wrap frame for looping readers), padded to an even count
-    TD_HIP(hipMalloc(&e.d, (n + 2 + (n & 1)) * sizeof(float2)));
-    TD_HIP(hipMemsetAsync(e.d + n, 0, (2 + (n & 1)) * sizeof(float2), st));
+    // n frames, then the first 15 again (wrap frames for looping readers), padded to an even count
+    TD_HIP(hipMalloc(&e.d, (n + 16 + (n & 1)) * sizeof(float2)));
+    TD_HIP(hipMemsetAsync(e.d + n, 0, (16 + (n & 1)) * sizeof(float2), st));
     launch_sample_pack(d_l, d_r, p_max_l, p_max_r, e.d, (uint32_t)n, st);
     // packed 16-bit twin: only when l / r are still the raw integer PCM values times one scale per channel
     // (every mode but mix-down) and no resample follows
