@@ -547,6 +547,9 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
     __syncthreads();
     const float before = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
     const float r_stale = 1.0f / init;
+    // the common shape -- the tile IS the reference block -- has one scale for the whole workgroup
+    const bool one_block = bl == (uint32_t)kTileFrames;
+    const float r_tile = one_block ? (is_scan ? r_stale : 1.0f / fmaxf(d.peaks[b_lo], b_lo ? fmaxf(before, init) : init)) : 0.0f;
     // 1.0 / max for the block holding frame m:  max_b = peak_b.max(max_{b-1}),  max_{-1} = init
     auto rscale_of = [&](uint32_t m) -> float {
         if (is_scan) return r_stale;
@@ -560,8 +563,8 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
         const uint32_t m = h ? m1 : m0;
         if (m < M) {
             float4 v = h ? in1 : in0;
-            const float r0 = rscale_of(m);
-            const float r1 = (m + 1 < M) ? rscale_of(m + 1) : r0;
+            const float r0 = one_block ? r_tile : rscale_of(m);
+            const float r1 = one_block ? r_tile : ((m + 1 < M) ? rscale_of(m + 1) : r0);
             v = epilogue4(make_float4(v.x * r0, v.y * r0, v.z * r1, v.w * r1), d.pg);
             store_pair(d.buf, m, M, v);
             if (d.qmode) store_quant_pair(d.pcm, d.qmode, m, M, v, d.amplitude);
