@@ -541,7 +541,13 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
     // max of the peaks of all blocks before this tile's first block (identity 0: peaks are >= 0, never NaN)
     __shared__ float wmax[kThreads / 64];
     float p = 0.0f;
-    for (uint32_t b = threadIdx.x; b < b_lo; b += kThreads) p = fmaxf(d.peaks[b], p);
+    for (uint32_t b = threadIdx.x; b < b_lo; b += 4u * kThreads) {   // four independent loads in flight per lane
+        const float p0 = d.peaks[b];
+        const float p1 = b + kThreads < b_lo ? d.peaks[b + kThreads] : 0.0f;
+        const float p2 = b + 2u * kThreads < b_lo ? d.peaks[b + 2u * kThreads] : 0.0f;
+        const float p3 = b + 3u * kThreads < b_lo ? d.peaks[b + 3u * kThreads] : 0.0f;
+        p = fmaxf(fmaxf(fmaxf(p0, p1), fmaxf(p2, p3)), p);
+    }
     p = wave_max(p);
     if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = p;
     __syncthreads();
