@@ -463,3 +463,34 @@ def test_band_pass_repair_storm(gpu_api, oracle, seconds, spacing, lo, hi):
     assert st["mismatched"] > 100, st
     # second render of the same handles (carried lerp / band state, quirk Q4): same answer again
     assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
+
+
+@pytest.mark.parametrize("bits,seconds,bl", [(16, 12.0, 1000), (24, 12.0, 1000), (16, 45.0, 1024), (24, 45.0, 1024)])
+def test_wide_loop_sums_on_long_timelines(gpu_api, oracle, bits, seconds, bl):
+    """Timelines of >= 512 / >= 2048 tiles switch the all-loop sums to 8 / 16 consecutive frames per lane
+    (k_sum16w): plain Sum vertices (any block length, partial last tile) and Normalize pass A (bl = 1024), packed
+    16-bit sources and f32 ones (24-bit assets have no packed form)."""
+    p = W.ProjectScript(48000, bl)
+    p.set_length(seconds)
+    for k in range(5):
+        pcm = W.noise_int16(700 + k, 3001 + 517 * k)
+        if bits == 24:
+            pcm = pcm.astype(np.int32) * 256 + (k + 1)
+        p.assets["s%d" % k] = W.Asset(pcm, bits=bits)
+        p.load_sample("s%d" % k, "s%d" % k, "")
+        p.add_sampleloop("v%d" % k, 0.3 + 0.2 * k, -60.0 + 30.0 * k, "s%d" % k)
+    p.add_sum("mix", 0.9, 12.0)            # mode 0 over loop sources
+    p.add_normalize("out", 1.0, 0.0)       # pass A over two loop sources + (edge) mix -> mixed mode ...
+    p.add_normalize("loops", 1.0, 0.0)     # ... and one over loop sources only
+    for k in range(5):
+        p.connect("v%d" % k, "mix")
+    for k in range(3):
+        p.connect("v%d" % k, "loops")
+    p.add_sum("final", 1.0, 0.0)
+    p.connect("mix", "out")
+    p.connect("out", "final")
+    p.connect("loops", "final")
+    p.set_output("final")
+    gb, ob = p.build(gpu_api), p.build(oracle)
+    for scan in (False, True):
+        assert_bit_exact(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
