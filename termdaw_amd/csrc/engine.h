@@ -27,12 +27,12 @@ int fail(const std::string& msg);   // sets g_error, returns 0
 size_t f32_as_usize(float x);
 
 struct SampleEntry {
-    float2* d = nullptr;   // interleaved frames in HBM
+    float2* d = nullptr;   // interleaved frames in HBM: len frames + the first 15 again (wrap frames for looping readers)
     size_t len = 0;
     // Optional packed form for samples that came from <= 16-bit integer PCM through a per-channel-scale load
-    // mode: one word per frame (int16 l | int16 r << 16), four phase-shifted copies (kernels.h, InTerm kind 3),
-    // + the two normalisation scales.  (float)int * scale
-    // rebuilds the f32 frame bit for bit (it IS how the f32 frame was made) at half the bytes.
+    // mode: one word per frame (int16 l | int16 r << 16), the loop + its first 15 frames again (kernels.h, InTerm
+    // kind 3), + the two normalisation scales.  (float)int * scale rebuilds the f32 frame bit for bit (it IS how the
+    // f32 frame was made) at half the bytes.
     uint32_t* d16 = nullptr;
     float scale_l = 0.0f, scale_r = 0.0f;
 };

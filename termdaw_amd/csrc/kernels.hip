@@ -225,7 +225,8 @@ TD_DEV float2 unpack16(uint32_t w, float sl, float sr) {
     return make_float2((float)(int16_t)(w & 0xFFFFu) * sl, (float)(int16_t)(w >> 16) * sr);
 }
 // Frames idx .. idx+3 of a looping sample in ONE 16-byte load: the packed form is the loop followed by its own
-// first three frames, and global_load_dwordx4 only needs dword alignment.  (A first version kept four
+// first 15 frames (the wide kernels read up to 16 consecutive frames behind one modulo), and global_load_dwordx4
+// only needs dword alignment.  (A first version kept four
 // phase-shifted copies to make the load 16-byte aligned: four times the footprint in L2 / Infinity Cache for
 // nothing -- 0.101 ms against 0.086 ms for the 64-source sum.)
 typedef unsigned int u4v_u __attribute__((ext_vector_type(4), aligned(4)));
