@@ -1661,12 +1661,13 @@ static const auto k_sum32w_2 = &k_sum16w<2, false>;   // (names without a comma 
 void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
+    static const int forced_nq = getenv("TD_FORCE_NQ") ? atoi(getenv("TD_FORCE_NQ")) : 0;   // tuning aid: 1 | 2 | 4
     switch (term_mode) {
         case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         case TERMS_ALL_LOOP32:
             // (8 frames per lane: 0.183 -> 0.152 ms on config 2 with f32 samples; 16 per lane: 0.211 ms -- twice the
             // bytes per frame of the packed form, the whole grid's working set no longer sits in L2)
-            if (wide_ok && frames >= 512u * kTileFrames)
+            if (wide_ok && frames >= 1800u * kTileFrames)
                 TD_BATCHED(k_sum32w_2, (frames + kTileFrames * 2 - 1) / (kTileFrames * 2), kThreads, d, n, frames);
             else
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames, bl, tpb);
@@ -1675,9 +1676,12 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
             // wide_ok: every descriptor is a plain Sum or a Normalize whose reference block is the 1024-frame tile.
             // Long timelines take more frames per lane (more of the timeline resident per XCD -> more L2 hits among
             // concurrently running tiles); short ones keep the workgroup count up.
-            if (wide_ok && frames >= 2048u * kTileFrames)
+            // (measured on config-2-like renders of 3 .. 300 s, tools/nq_sweep.py: below ~1 800 tiles the narrow form wins --
+            // a wide workgroup's own serial walk over the sources, ~55 us for 64 of them at 16 frames per lane, is then
+            // the whole launch; 8 per lane pays from ~1 800 tiles, 16 per lane from ~2 600)
+            if (wide_ok && (forced_nq ? forced_nq == 4 : frames >= 2600u * kTileFrames))
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum16w<4>), (frames + kTileFrames * 4 - 1) / (kTileFrames * 4), kThreads, d, n, frames);
-            else if (wide_ok && frames >= 512u * kTileFrames)
+            else if (wide_ok && (forced_nq ? forced_nq == 2 : frames >= 1800u * kTileFrames))
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum16w<2>), (frames + kTileFrames * 2 - 1) / (kTileFrames * 2), kThreads, d, n, frames);
             else
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb);

@@ -465,9 +465,9 @@ def test_band_pass_repair_storm(gpu_api, oracle, seconds, spacing, lo, hi):
     assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
 
 
-@pytest.mark.parametrize("bits,seconds,bl", [(16, 12.0, 1000), (24, 12.0, 1000), (16, 45.0, 1024), (24, 45.0, 1024)])
+@pytest.mark.parametrize("bits,seconds,bl", [(16, 40.0, 1000), (24, 40.0, 1000), (16, 58.0, 1024), (24, 58.0, 1024)])
 def test_wide_loop_sums_on_long_timelines(gpu_api, oracle, bits, seconds, bl):
-    """Timelines of >= 512 / >= 2048 tiles switch the all-loop sums to 8 / 16 consecutive frames per lane
+    """Timelines of >= 1800 / >= 2600 tiles switch the all-loop sums to 8 / 16 consecutive frames per lane
     (k_sum16w): plain Sum vertices (any block length, partial last tile) and Normalize pass A (bl = 1024), packed
     16-bit sources and f32 ones (24-bit assets have no packed form)."""
     p = W.ProjectScript(48000, bl)
