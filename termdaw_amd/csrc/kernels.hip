@@ -161,8 +161,9 @@ TD_DEV float4 term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     if (kind == 3) {   // packed 16-bit form, two frames
         const uint32_t TD_GLOBAL* g = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)p);
         const uint32_t l32 = (uint32_t)len, i0 = barrett_mod((uint32_t)t0 + m, l32, t[j].magic);
-        const uint32_t i1 = i0 + 1u == l32 ? 0u : i0 + 1u;
-        const float2 a = unpack16(g[i0], t[j].scale_l, t[j].scale_r), b = unpack16(g[i1], t[j].scale_l, t[j].scale_r);
+        typedef unsigned int u2v_u __attribute__((ext_vector_type(2), aligned(4)));
+        const u2v_u w = *reinterpret_cast<const u2v_u TD_GLOBAL*>(g + i0);   // frame i0 and its successor (wrap frames follow the loop)
+        const float2 a = unpack16(w.x, t[j].scale_l, t[j].scale_r), b = unpack16(w.y, t[j].scale_l, t[j].scale_r);
         v = make_float4(a.x, a.y, b.x, b.y);
     } else {
         v = kind == 1 ? loop_pair32(p, (uint32_t)len, t[j].magic, (uint32_t)t0 + m) : loop_pair<uint64_t>(p, len, (t0 + m) % len);
