@@ -204,6 +204,8 @@ size_t td_state_render_to_memory(td_state* s, void* out, size_t bytes);
  * *bytes long; valid until the next render or td_state_free): no second copy.  NULL on failure. */
 const void* td_state_render_view(td_state* s, size_t* bytes);
 size_t td_state_chunk_count(const td_state* s);                            /* cs, state.rs:104 */
+size_t td_state_buffer_length(const td_state* s);                          /* config.rs:58-60 */
+size_t td_state_project_samplerate(const td_state* s);                     /* config.rs:62-64 */
 size_t td_state_render_samplerate(const td_state* s);
 size_t td_state_bitdepth(const td_state* s);
 const char* td_state_output_file(const td_state* s);

@@ -104,6 +104,8 @@ SIGNATURES = {
     "td_state_render_samplerate": (_sz, [_vp]),
     "td_state_bitdepth": (_sz, [_vp]),
     "td_state_output_file": (_cp, [_vp]),
+    "td_state_buffer_length": (_sz, [_vp]),
+    "td_state_project_samplerate": (_sz, [_vp]),
     "td_state_graph": (_vp, [_vp]),
     "td_state_samplebank": (_vp, [_vp]),
     "td_state_flowwbank": (_vp, [_vp]),
@@ -489,12 +491,14 @@ class State:
 
     @property
     def g(self):
-        return Graph(0, 0, _handle=lib().td_state_graph(self.h))
+        return Graph(lib().td_state_buffer_length(self.h), lib().td_state_project_samplerate(self.h),
+                     _handle=lib().td_state_graph(self.h))
 
     @property
     def sb(self):
-        return SampleBank(0, _handle=lib().td_state_samplebank(self.h))
+        return SampleBank(lib().td_state_project_samplerate(self.h), _handle=lib().td_state_samplebank(self.h))
 
     @property
     def fb(self):
-        return FlowwBank(0, 0, _handle=lib().td_state_flowwbank(self.h))
+        return FlowwBank(lib().td_state_project_samplerate(self.h), lib().td_state_buffer_length(self.h),
+                         _handle=lib().td_state_flowwbank(self.h))

@@ -602,6 +602,8 @@ const void* td_state_render_view(td_state* s, size_t* bytes) {
 }
 
 size_t td_state_chunk_count(const td_state* s) { return s->cs; }
+size_t td_state_buffer_length(const td_state* s) { return s->bl; }
+size_t td_state_project_samplerate(const td_state* s) { return s->psr; }
 size_t td_state_render_samplerate(const td_state* s) { return s->render_sr; }
 size_t td_state_bitdepth(const td_state* s) { return s->bd; }
 const char* td_state_output_file(const td_state* s) { return s->output_file.c_str(); }

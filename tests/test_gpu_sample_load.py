@@ -133,3 +133,64 @@ def test_state_render_view_matches_render_to_memory(gpu_api, tmp_path):
     assert s2.refresh(lua)
     assert np.array_equal(s2.render_view(), a)
     assert v.shape == a.shape == b.shape and v.dtype == a.dtype and not v.flags.writeable
+
+
+def test_headless_stream_mode(gpu_api, oracle, tmp_path):
+    """python -m termdaw_amd <dir> --stream: text events on stdin -> declared streams -> block pulls -> WAV, against
+    the oracle driven through the same stream_workflow.rs sequence."""
+    import struct
+    import types
+    from termdaw_amd import __main__ as cli
+    d = tmp_path / "proj"
+    d.mkdir()
+    W.write_wav_int16(str(d / "kick.wav"), W.kick_int16(12, 9000), 48000)
+    (d / "project.toml").write_text('[settings]\nmain = "project.lua"\nbuffer_length = 512\nproject_samplerate = 48000\n')
+    (d / "project.lua").write_text(
+        'set_length(1.0); set_render_samplerate(48000); set_render_bitdepth(16); set_output_file("%s");\n'
+        'load_sample("kick", "%s", "");\n'
+        'declare_stream("live");\n'
+        'add_sample_multi("hits", 0.9, 10.0, "kick", "live", -1);\n'
+        'add_adsr("env", 1.0, 0.0, 1.0, "live", false, true, -1, { 0.01, 0.05, 0.7, 0.05, 0.2, 0.02 });\n'
+        'add_sum("out", 1.0, 0.0);\n'
+        'connect("hits", "env"); connect("env", "out"); set_output("out");\n' % (d / "stream.wav", d / "kick.wav"))
+    packets = [[(0.010, 36.0, 0.9), (0.120, 36.0, 0.5)], [(0.260, 36.0, 0.8)], [(0.300, 40.0, 0.4), (0.410, 36.0, 1.0)]]
+    lines = []
+    for pk in packets:
+        lines += ["live %r %r %r" % e for e in pk] + [""]
+    lines.append("end 0.6")
+    s = gpu_api.State(open_dir=str(d))
+    rc = cli.stream(s, types.SimpleNamespace(realtime=False, output=None), lines=lines)
+    assert rc == 0
+    raw = (d / "stream.wav").read_bytes()
+    assert struct.unpack("<I", raw[24:28])[0] == 48000
+    got = np.frombuffer(raw[44:], np.int16).reshape(-1, 2)
+    # the same sequence on the oracle
+    sb = oracle.SampleBank(48000)
+    sb.add_decoded("kick", W.kick_int16(12, 9000).astype(np.float32).reshape(-1), 2, 48000, 16, "")
+    fb = oracle.FlowwBank(48000, 512)
+    fb.declare_stream("live")
+    g = oracle.Graph(512, 48000)
+    g.add_sample_multi("hits", 0.9, 10.0, sb.get_index("kick"), fb.get_index("live"), -1)
+    g.add_adsr("env", 1.0, 0.0, 1.0, fb.get_index("live"), False, True, -1, [0.01, 0.05, 0.7, 0.05, 0.2, 0.02])
+    g.add_sum("out", 1.0, 0.0)
+    assert g.connect("hits", "env") and g.connect("env", "out") and g.set_output("out")
+    blocks = []
+
+    def pull_until(t):
+        while g.get_time() < int(t * 48000):
+            fb.set_time(g.get_time())
+            l, r = g.render(sb, fb)
+            blocks.append(np.stack([l, r], axis=1))
+            fb.set_time_to_next_block()
+    latest = 0.0
+    for pk in packets:
+        fb.trim_streams()
+        fb.append_stream("live", pk)
+        fb.set_time(g.get_time())
+        latest = max(latest, max(e[0] for e in pk))
+        pull_until(latest)
+    pull_until(max(latest, 0.6) + 512 / 48000.0)
+    f = np.concatenate(blocks).astype(np.float32) * np.float32(32767.0)
+    want = np.clip(np.trunc(f), -32768, 32767).astype(np.int16)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.abs(got).max() > 1000
