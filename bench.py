@@ -176,7 +176,8 @@ def main():
         step()
     g.sync()
     # warm the exchange path too (first CUDA tensor / first collective initialise lazily: not render work)
-    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda")
+    peak_buf = torch.empty(world, dtype=torch.float32, device="cuda") if use_dist else None
+    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda", peak_buf)
     barrier()
     # HIP events around every launch of every PROF_EVERY-th render, on the engine's stream (the events cost a
     # few microseconds per launch -- a tenth of this step if every render carried them)
@@ -187,7 +188,7 @@ def main():
         step()
     g.sync()
     # the path's only exchange: per-project (pre-normalisation) peak table, one all-reduce(max) over RCCL
-    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda")
+    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda", peak_buf)
     barrier()
     dt = time.perf_counter() - t0
     ktimes = g.kernel_times()
