@@ -199,6 +199,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    # the >= 40 % target is against a device-copy rate measured on this box, not the guide's number
+    copy_gbs = HBM_COPY_GBS
+    if rank == 0:
+        try:
+            n = 256 << 20   # 1 GiB of float32 each way
+            src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
+            dst = torch.empty_like(src)
+            for _ in range(3):
+                dst.copy_(src)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dst.copy_(src)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbs = 10 * 2 * n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9   # read + write bytes
+            del src, dst
+        except Exception:   # noqa: BLE001
+            copy_gbs = HBM_COPY_GBS
     if rank == 0:
         total_frames = frames * args.steps * world
         value = total_frames / dt / 1e6
@@ -212,7 +231,7 @@ def main():
             gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
             kernels.append({"kernel": name, "avg_ms": round(avg_ms, 5), "launches": int(launches),
                             "algorithmic_bytes_per_launch": int(bytes_per_launch), "achieved_GBs": round(gbs, 1),
-                            "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / HBM_COPY_GBS, 4)})
+                            "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_gbs, 4)})
         dom = kernels[0] if kernels else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -241,7 +260,8 @@ def main():
                        "parallelism": "projects sharded 1 per GPU; RCCL all-reduce(max) of the peak table only"},
             "roofline": None if not dom else {
                 "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac_of_8TBs"], "frac_of_measured_copy_6.29TBs": dom["frac_of_measured_copy"], "traffic": traffic,
+                "frac": dom["frac_of_8TBs"], "measured_copy_GBs": round(copy_gbs, 1),
+                "frac_of_measured_copy": dom["frac_of_measured_copy"], "traffic": traffic,
                 "bytes_per_frame": abf.get(dom["kernel"]),
                 "note": ("edge-buffer model (SURVEY 8d): every algorithmic byte is an HBM byte (PMC traffic == algorithmic "
                          "bytes)") if not fused else
