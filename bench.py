@@ -145,13 +145,19 @@ def main():
 
     if api.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP render path has no CPU fallback")
+    if os.environ.get("TD_BENCH_ONE_DEVICE") == "1":   # self-test on a 1-GPU box: every rank on device 0 (use with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     api.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("TD_BENCH_BACKEND", "nccl")   # "gloo" only for the 1-GPU self-test above
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # ---- build this rank's project: config 2 with seed offset 64 * rank (config 5 sharding) ----
     project = workloads.config2(seconds=args.seconds, n_src=N_SRC, seed_offset=64 * rank)
@@ -176,8 +182,9 @@ def main():
         step()
     g.sync()
     # warm the exchange path too (first CUDA tensor / first collective initialise lazily: not render work)
-    peak_buf = torch.empty(world, dtype=torch.float32, device="cuda") if use_dist else None
-    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda", peak_buf)
+    coll_dev = "cuda" if os.environ.get("TD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
+    peak_buf = torch.empty(world, dtype=torch.float32, device=coll_dev) if use_dist else None
+    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, coll_dev, peak_buf)
     barrier()
     # HIP events around every launch of every PROF_EVERY-th render, on the engine's stream (the events cost a
     # few microseconds per launch -- a tenth of this step if every render carried them)
@@ -188,13 +195,13 @@ def main():
         step()
     g.sync()
     # the path's only exchange: per-project (pre-normalisation) peak table, one all-reduce(max) over RCCL
-    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, "cuda", peak_buf)
+    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, coll_dev, peak_buf)
     barrier()
     dt = time.perf_counter() - t0
     ktimes = g.kernel_times()
     g.set_profiling(False)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
