@@ -47,7 +47,14 @@ bool read_wav(const char* path, WavData* out, std::string* err) {
             }
             size_t end = pos + 8 + (size_t)sz;
             if (end > buf.size()) end = buf.size();
-            const size_t bps = align ? align / ch : bits / 8;
+            const bool enc_ok = (fmt == 3 && bits == 32) || (fmt == 1 && (bits == 8 || bits == 16 || bits == 24 || bits == 32));
+            if (!enc_ok) {
+                *err = "TermDaw: SampleBank: unsupported WAV encoding.";
+                return false;
+            }
+            // sample stride: the container size from block_align when it is sane, never less than the sample itself
+            size_t bps = bits / 8;
+            if (align && align / ch > bps && align / ch <= 8) bps = align / ch;
             out->linear.clear();
             for (size_t o = pos + 8; o + bps <= end; o += bps) {
                 const uint8_t* p = &buf[o];
@@ -59,7 +66,7 @@ bool read_wav(const char* path, WavData* out, std::string* err) {
                     out->linear.push_back((float)((int)p[0] - 128));
                 } else if (fmt == 1 && bits == 16) {
                     out->linear.push_back((float)(int16_t)rd16(p));
-                } else if (fmt == 1 && bits == 24 && bps == 3) {
+                } else if (fmt == 1 && bits == 24) {
                     int32_t v = (int32_t)(rd16(p) | ((uint32_t)p[2] << 16));
                     if (v & 0x800000) v |= ~0xFFFFFF;
                     out->linear.push_back((float)v);
