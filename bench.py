@@ -270,6 +270,11 @@ def main():
                 "frac": dom["frac_of_8TBs"], "measured_copy_GBs": round(copy_gbs, 1),
                 "frac_of_measured_copy": dom["frac_of_measured_copy"], "traffic": traffic,
                 "bytes_per_frame": abf.get(dom["kernel"]),
+                # the engine times launch FAMILIES; which instantiation ran (= the name in the rocprofv3 summary):
+                "rocprof_kernel": (("tdk::k_sum16w<4, true>" if frames >= 2600 * 1024 else "tdk::k_sum16w<2, true>" if frames >= 1800 * 1024
+                                    else "tdk::k_sum<3>") if packed else
+                                   ("tdk::k_sum16w<2, false>" if frames >= 1800 * 1024 else "tdk::k_sum<2>")) if fused and dom["kernel"] == "k_sum"
+                                  else ("tdk::k_sum<1>" if dom["kernel"] == "k_sum" else "tdk::" + dom["kernel"]),
                 "note": ("edge-buffer model (SURVEY 8d): every algorithmic byte is an HBM byte (PMC traffic == algorithmic "
                          "bytes)") if not fused else
                         ("source inlining: k_sum's algorithmic bytes are its own gathers, (%dk+8) B/frame -- k looping "
