@@ -167,18 +167,32 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     const size_t nmax = std::max(nl, nr);
     float *d_lin = nullptr, *d_l = nullptr, *d_r = nullptr, *d_s = nullptr;
     uint8_t* d_raw = nullptr;
-    auto cleanup = [&]() {
-        (void)hipFree(d_lin); (void)hipFree(d_l); (void)hipFree(d_r); (void)hipFree(d_s); (void)hipFree(d_raw);
-    };
-    TD_HIP(hipMalloc(&d_lin, std::max<size_t>(n_values, 1) * sizeof(float)));
-    TD_HIP(hipMalloc(&d_l, std::max<size_t>(nmax, 1) * sizeof(float)));
-    TD_HIP(hipMalloc(&d_r, std::max<size_t>(nmax, 1) * sizeof(float)));
-    TD_HIP(hipMalloc(&d_s, 64));
+    auto cleanup = [&]() {};   // (the scratch belongs to the bank)
+    {
+        auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t bps_raw = linear ? 0 : (raw_format == PCM_U8 ? 1 : raw_format == PCM_S16 ? 2 : raw_format == PCM_S24 ? 3 : 4);
+        const size_t b_lin = up(std::max<size_t>(n_values, 1) * sizeof(float)), b_ch = up(std::max<size_t>(nmax, 1) * sizeof(float));
+        const size_t b_raw = up(std::max<size_t>(n_values * bps_raw, 1));
+        const size_t need = b_lin + 2 * b_ch + 256 + b_raw;
+        if (need > sb->tmp_cap) {
+            TD_HIP(hipDeviceSynchronize());
+            if (sb->tmp) (void)hipFree(sb->tmp);
+            sb->tmp = nullptr;
+            sb->tmp_cap = 0;
+            TD_HIP(hipMalloc(&sb->tmp, need + need / 2));
+            sb->tmp_cap = need + need / 2;
+        }
+        unsigned char* p = sb->tmp;
+        d_lin = reinterpret_cast<float*>(p); p += b_lin;
+        d_l = reinterpret_cast<float*>(p); p += b_ch;
+        d_r = reinterpret_cast<float*>(p); p += b_ch;
+        d_s = reinterpret_cast<float*>(p); p += 256;
+        d_raw = p;
+    }
     if (linear) {
         TD_HIP(hipMemcpyAsync(d_lin, linear, n_values * sizeof(float), hipMemcpyHostToDevice, st));
     } else {
         const size_t bps = raw_format == PCM_U8 ? 1 : raw_format == PCM_S16 ? 2 : raw_format == PCM_S24 ? 3 : 4;
-        TD_HIP(hipMalloc(&d_raw, std::max<size_t>(n_values * bps, 1)));
         TD_HIP(hipMemcpyAsync(d_raw, raw, n_values * bps, hipMemcpyHostToDevice, st));
         launch_pcm_decode(d_raw, d_lin, (uint32_t)n_values, raw_format, st);
     }
@@ -1564,6 +1578,7 @@ void td_samplebank_free(td_samplebank* sb) {
     if (!sb) return;
     if (!sb->samples.empty() && hipSetDevice(sb->device) == hipSuccess)
         for (auto& e : sb->samples) { (void)hipFree(e.d); if (e.d16) (void)hipFree(e.d16); }
+    if (sb->tmp && hipSetDevice(sb->device) == hipSuccess) (void)hipFree(sb->tmp);
     delete sb;
 }
 int td_samplebank_add_decoded(td_samplebank* sb, const char* name, const float* linear, size_t n, int channels,

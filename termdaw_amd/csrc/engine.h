@@ -45,6 +45,10 @@ struct td_samplebank {
     std::map<std::string, size_t> names;
     size_t max_sr = 0, max_bd = 0;
     int device = 0;
+    // load-pipeline scratch (decoded stream, planar l / r, scalars, raw PCM), kept from add to add: a hipMalloc /
+    // hipFree pair per temporary and sample was most of what loading a project cost
+    unsigned char* tmp = nullptr;
+    size_t tmp_cap = 0;
 };
 
 struct td_flowwbank {
