@@ -22,8 +22,11 @@ from termdaw_amd import workloads as W   # noqa: E402
 
 CASES = {
     "config1_3s": lambda: (W.config1(), False),
-    "config1_3s_scanned": lambda: (W.config1(), True),
+    # (config 1's first block already holds the global peak, so its scanned render equals the un-scanned one
+    # byte for byte and would pin nothing: the scanned cases are projects whose peak comes later)
     "config2_2s": lambda: (W.config2(seconds=2.0), False),
+    "config2_2s_scanned": lambda: (W.config2(seconds=2.0), True),
+    "config4_1s": lambda: (W.config4(seconds=1.0), False),
     "drum_project_4s": lambda: (W.drum_project(), False),
     "drum_project_4s_scanned": lambda: (W.drum_project(), True),
 }
@@ -42,5 +45,8 @@ if __name__ == "__main__":
         proj, scan = mk()
         pcm, _ = proj.render(oracle, scan=scan)
         out[name] = {"frames": int(pcm.shape[0]), "sha256": digest(pcm)}
+    for name in out:   # a scanned fixture must differ from its un-scanned twin, or it pins nothing
+        if name.endswith("_scanned"):
+            assert out[name]["sha256"] != out[name[:-len("_scanned")]]["sha256"], name
     json.dump(out, open(os.path.join(HERE, "digests.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps(out, indent=1))
