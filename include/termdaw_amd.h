@@ -29,6 +29,7 @@ typedef struct td_samplebank td_samplebank;
 typedef struct td_flowwbank td_flowwbank;
 typedef struct td_graph td_graph;
 typedef struct td_state td_state;
+typedef struct td_batch td_batch;
 
 /* One event of a floww: the (_, t, note, vel) tuple of the floww crate as used at floww.rs:74-75,
  * 105-116, 131-135 (field 0 is never read on the render path). vel <= 0.001 means note-off. */
@@ -124,8 +125,8 @@ size_t td_graph_vertex_count(const td_graph* g);
 
 /* Graph::render graph.rs:182-193: renders ONE block at the current playhead, advances the playhead by
  * max_buffer_len, copies the output vertex' block to l / r (max_buffer_len floats each, either may be
- * NULL).  Returns 0 when there is no output vertex (the reference's None).  Like the reference it
- * does not advance the FlowwBank -- the caller does (state.rs:572). */
+ * NULL).  Returns 1 = Some(block), 0 = no output vertex (the reference's None), -1 = failure (td_last_error).
+ * Like the reference it does not advance the FlowwBank -- the caller does (state.rs:572). */
 int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, float* l, float* r);
 
 /* Graph::true_normalize_scan graph.rs:222-237 over `chunks` blocks (whole timeline on the GPU). */
@@ -184,6 +185,40 @@ int td_graph_set_option(td_graph* g, const char* key, long value);
  * re-checks after optimistic repairs), out[1] segments recomputed, out[2] of those cut short by a fixed point
  * under constant input. */
 int td_graph_band_stats(const td_graph* g, uint32_t out[3]);
+
+/* ---- Batch of independent projects (BASELINE config 5) ---------------------------------------
+ * The reference renders one project per process: State::render's loop `for _ in 0..cs { g.render(..); write;
+ * fb.set_time_to_next_block() }` (state.rs:563-575).  A batch runs that loop for many independent projects at
+ * once on one GPU: every project keeps its own Graph / SampleBank / FlowwBank handles (added with td_batch_add,
+ * still usable on their own afterwards), the batch compiles all of them into one table arena and merges
+ * same-kind launches of different projects into one grid.  Results are exactly those of td_graph_render_all per
+ * project.  Projects shard across GPUs as one batch per process; the only cross-GPU exchange is the per-project
+ * peak table below (one all-reduce(max), RCCL). */
+td_batch* td_batch_new(void);                              /* on the device selected by td_set_device */
+void td_batch_free(td_batch* b);                           /* the projects' handles stay valid */
+/* Adds one project; returns its index in the batch or -1.  The graph's device work moves to the batch's stream. */
+long td_batch_add(td_batch* b, td_graph* g, const td_samplebank* sb, td_flowwbank* fb);
+size_t td_batch_size(const td_batch* b);
+/* For every project: Graph::reset_normalize_vertices (state.rs:467) + FlowwBank::set_time(0) -- the state
+ * right after State::refresh, from which a fresh render starts. */
+void td_batch_rewind(td_batch* b);
+/* td_graph_render_all[_async] for every project (each project's PCM / f32 stays readable through its own
+ * td_graph_read_pcm / td_graph_output_pcm_device).  Returns frames per project, 0 on failure. */
+size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits);
+size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits);
+int td_batch_sync(td_batch* b);
+int td_batch_normalize_scan(td_batch* b, size_t chunks);    /* State::scan_exact (state.rs:473-475) per project */
+/* Per-project peak after the last render: the output Normalize vertex' running peak (`max`, extensions.rs:323,
+ * i.e. the project's pre-normalisation peak) or, for other output kinds, the absolute peak of the output.
+ * td_batch_peaks: host copy, one float per project in td_batch_add order.  td_batch_peak_table_device: fills a
+ * table of n_total floats in DEVICE memory (caller-owned, e.g. the tensor handed to the all-reduce): project i
+ * goes to entry first + i * stride, all other entries are zeroed. */
+int td_batch_peaks(td_batch* b, float* out);
+int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size_t first, size_t stride);
+/* bench hooks, as for a graph */
+void td_batch_set_profiling(td_batch* b, int on);
+size_t td_batch_last_kernel_times(td_batch* b, const char** names, float* ms, size_t* launches, size_t cap);
+size_t td_batch_host_times(td_batch* b, double* ms4, int reset);
 
 /* ---- Project front-end: State (state.rs:27-578) -------------------------------------------- */
 /* State{..} as constructed at main.rs:75-98 (render_sr 48000, bd 16, output "outp.wav"). */

@@ -91,6 +91,20 @@ SIGNATURES = {
     "td_graph_device_bytes": (_sz, [_vp]),
     "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
     "td_graph_band_stats": (_i32, [_vp, C.POINTER(C.c_uint32)]),
+    "td_batch_new": (_vp, []),
+    "td_batch_free": (None, [_vp]),
+    "td_batch_add": (_lng, [_vp, _vp, _vp, _vp]),
+    "td_batch_size": (_sz, [_vp]),
+    "td_batch_rewind": (None, [_vp]),
+    "td_batch_render_all": (_sz, [_vp, _sz, _i32]),
+    "td_batch_render_all_async": (_sz, [_vp, _sz, _i32]),
+    "td_batch_sync": (_i32, [_vp]),
+    "td_batch_normalize_scan": (_i32, [_vp, _sz]),
+    "td_batch_peaks": (_i32, [_vp, _fp]),
+    "td_batch_peak_table_device": (_i32, [_vp, _vp, _sz, _sz, _sz]),
+    "td_batch_set_profiling": (None, [_vp, _i32]),
+    "td_batch_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
+    "td_batch_host_times": (_sz, [_vp, C.POINTER(C.c_double), _i32]),
     "td_state_new": (_vp, [_cp, _sz, _sz]),
     "td_state_open": (_vp, [_cp]),
     "td_state_free": (None, [_vp]),
@@ -140,12 +154,18 @@ def lib():
     There is no CPU fallback: if hipcc cannot build it, this raises."""
     global _lib
     if _lib is None:
-        try:
-            build()
-        except Exception as e:   # noqa: BLE001
-            if not os.path.exists(LIB_PATH):
-                raise TermdawError("%s is missing and `make -C termdaw_amd` failed (%s); there is no CPU fallback"
-                                   % (LIB_PATH, e))
+        # A stale or missing library whose rebuild fails is an error: tests and bench must never run a binary
+        # that is older than the sources they claim to measure.  Only an explicit opt-in skips the build:
+        # TD_LIB=<path> (A/B experiments) or TD_NO_BUILD=1 (a box without hipcc, prebuilt .so shipped along).
+        if not (_LIB_OVERRIDE or os.environ.get("TD_NO_BUILD") == "1"):
+            try:
+                build()
+            except Exception as e:   # noqa: BLE001
+                raise TermdawError("`make -C termdaw_amd` failed (%s) and %s is missing or older than its sources; "
+                                   "there is no CPU fallback (TD_NO_BUILD=1 loads a prebuilt library as it is)"
+                                   % (e, LIB_PATH))
+        if not os.path.exists(_LIB_OVERRIDE or LIB_PATH):
+            raise TermdawError("%s is missing; there is no CPU fallback" % (_LIB_OVERRIDE or LIB_PATH))
         L = C.CDLL(_LIB_OVERRIDE or LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
@@ -340,9 +360,9 @@ class Graph:
         l = np.empty(self.bl, np.float32)
         r = np.empty(self.bl, np.float32)
         ok = lib().td_graph_render_block(self.h, sb.h, fb.h, l.ctypes.data_as(_fp), r.ctypes.data_as(_fp))
+        if ok < 0:
+            raise TermdawError(last_error())
         if not ok:
-            if last_error() and "output vertex" not in last_error():
-                raise TermdawError(last_error())
             return None
         return l, r
 
@@ -418,6 +438,83 @@ class Graph:
 
     def set_option(self, key, value):
         _check(lib().td_graph_set_option(self.h, key.encode(), int(value)))
+
+
+class Batch:
+    """Many independent projects rendered together on one GPU (BASELINE config 5): State::render's loop
+    (state.rs:563-575) for every project, same-kind launches of different projects merged into one grid."""
+
+    def __init__(self):
+        self.h = lib().td_batch_new()
+        self.projects = []   # (sb, fb, g) kept alive: the batch only borrows the handles
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().td_batch_free(self.h)
+            self.h = None
+
+    def add(self, sb, fb, g):
+        i = lib().td_batch_add(self.h, g.h, sb.h, fb.h)
+        if i < 0:
+            raise TermdawError(last_error())
+        self.projects.append((sb, fb, g))
+        return i
+
+    def __len__(self):
+        return lib().td_batch_size(self.h)
+
+    def rewind(self):
+        lib().td_batch_rewind(self.h)
+
+    def render_all(self, cs, bd=16):
+        n = lib().td_batch_render_all(self.h, cs, bd)
+        if cs and len(self) and not n:
+            raise TermdawError(last_error())
+        return n
+
+    def render_all_async(self, cs, bd=16):
+        n = lib().td_batch_render_all_async(self.h, cs, bd)
+        if cs and len(self) and not n:
+            raise TermdawError(last_error())
+        return n
+
+    def sync(self):
+        _check(lib().td_batch_sync(self.h))
+
+    def normalize_scan(self, chunks):
+        _check(lib().td_batch_normalize_scan(self.h, chunks))
+
+    def peaks(self):
+        out = np.zeros(max(len(self), 1), np.float32)
+        _check(lib().td_batch_peaks(self.h, out.ctypes.data_as(_fp)))
+        return out[:len(self)]
+
+    def peak_table_device(self, device_ptr, n_total, first=0, stride=1):
+        """Fills n_total floats at `device_ptr` (e.g. torch_tensor.data_ptr()): own entries at first + i*stride, 0 elsewhere."""
+        _check(lib().td_batch_peak_table_device(self.h, C.c_void_p(device_ptr), n_total, first, stride))
+
+    def read_pcm(self, i, cs, bd=16):
+        sb, fb, g = self.projects[i]
+        pcm = np.zeros((cs * g.bl, 2), np.int32 if bd > 16 else np.int16)
+        if pcm.size:
+            _check(lib().td_graph_read_pcm(g.h, pcm.ctypes.data_as(_vp), pcm.nbytes))
+        return pcm
+
+    def set_profiling(self, on):
+        lib().td_batch_set_profiling(self.h, int(on))
+
+    def kernel_times(self):
+        cap = 32
+        names = (_cp * cap)()
+        ms = (C.c_float * cap)()
+        cnt = (_sz * cap)()
+        n = lib().td_batch_last_kernel_times(self.h, names, ms, cnt, cap)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+    def host_times(self, reset=True):
+        out = (C.c_double * 4)()
+        n = lib().td_batch_host_times(self.h, out, int(reset))
+        return {"compile": out[0], "descriptors": out[1], "upload": out[2], "launch": out[3], "steps": n}
 
 
 class State:

@@ -678,15 +678,19 @@ static void build_plan(td_graph* g) {
 
 static int ensure_graph_device(td_graph* g) {
     if (!ensure_device(g->device)) return 0;
-    if (!g->stream) {
-        TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-        TD_HIP(hipEventCreateWithFlags(&g->arena_copied, hipEventDisableTiming));
+    if (!g->ev_fork) {
+        if (!g->stream) {
+            TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+            g->owns_stream = true;
+        }
         TD_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
+        TD_HIP(hipMalloc(&g->d_scalar, 256));
+    }
+    if (g->branch_streams && !g->aux[0]) {   // branch streams are made on first use (a batch of 64 graphs never needs them)
         for (int a = 0; a < td_graph::kAuxStreams; ++a) {
             TD_HIP(hipStreamCreateWithFlags(&g->aux[a], hipStreamNonBlocking));
             TD_HIP(hipEventCreateWithFlags(&g->ev_join[a], hipEventDisableTiming));
         }
-        TD_HIP(hipMalloc(&g->d_scalar, 256));
     }
     return 1;
 }
@@ -751,24 +755,30 @@ static float2* take_buffer(td_graph* g) {
     return p;
 }
 
-static int ensure_arena(td_graph* g, size_t bytes) {
-    if (bytes <= g->arena_cap) return 1;
+static int ensure_arena(Arena& ar, size_t bytes, hipStream_t stream) {
+    if (bytes <= ar.cap) return 1;
     const size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
-    TD_HIP(hipStreamSynchronize(g->stream));
-    if (g->harena) (void)hipHostFree(g->harena);
-    if (g->darena) {
-        (void)hipFree(g->darena);
-        g->device_bytes -= g->arena_cap;
-    }
-    g->harena = nullptr;
-    g->darena = nullptr;
-    TD_HIP(hipHostMalloc(&g->harena, cap, hipHostMallocDefault));
-    TD_HIP(hipMalloc(&g->darena, cap));
-    g->arena_cap = cap;
-    g->device_bytes += cap;
-    g->arena_inflight = false;
-    g->arena_valid = 0;
+    if (stream) TD_HIP(hipStreamSynchronize(stream));
+    if (ar.h) (void)hipHostFree(ar.h);
+    if (ar.d) (void)hipFree(ar.d);
+    ar.h = nullptr;
+    ar.d = nullptr;
+    ar.cap = 0;
+    ar.device_bytes = 0;
+    TD_HIP(hipHostMalloc(&ar.h, cap, hipHostMallocDefault));
+    TD_HIP(hipMalloc(&ar.d, cap));
+    if (!ar.copied) TD_HIP(hipEventCreateWithFlags(&ar.copied, hipEventDisableTiming));
+    ar.cap = cap;
+    ar.device_bytes = cap;
+    ar.inflight = false;
+    ar.valid = 0;
     return 1;
+}
+static void free_arena(Arena& ar) {
+    if (ar.h) (void)hipHostFree(ar.h);
+    if (ar.d) (void)hipFree(ar.d);
+    if (ar.copied) (void)hipEventDestroy(ar.copied);
+    ar = Arena{};
 }
 
 enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
@@ -776,10 +786,10 @@ static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k
                                            "k_synth",       "k_sampsyn", "k_sum",          "k_scale",
                                            "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_quantise"};
 
-static hipEvent_t get_event(td_graph* g) {
-    if (!g->ev_free.empty()) {
-        hipEvent_t e = g->ev_free.back();
-        g->ev_free.pop_back();
+static hipEvent_t get_event(ProfCtx& pc) {
+    if (!pc.free_ev.empty()) {
+        hipEvent_t e = pc.free_ev.back();
+        pc.free_ev.pop_back();
         return e;
     }
     hipEvent_t e = nullptr;
@@ -788,21 +798,21 @@ static hipEvent_t get_event(td_graph* g) {
 }
 
 struct Prof {
-    td_graph* g;
+    ProfCtx& pc;
     int fam;
     hipStream_t s;
     hipEvent_t a = nullptr, b = nullptr;
-    Prof(td_graph* g_, int fam_, hipStream_t s_) : g(g_), fam(fam_), s(s_) {
-        if (g->prof_now) {
-            a = get_event(g);
-            b = get_event(g);
+    Prof(ProfCtx& pc_, int fam_, hipStream_t s_) : pc(pc_), fam(fam_), s(s_) {
+        if (pc.now) {
+            a = get_event(pc);
+            b = get_event(pc);
             (void)hipEventRecord(a, s);
         }
     }
     ~Prof() {
-        if (g->prof_now) {
+        if (pc.now) {
             (void)hipEventRecord(b, s);
-            g->ev_pending.push_back({a, b, fam});
+            pc.pending.push_back({a, b, fam});
         }
     }
 };
@@ -858,24 +868,29 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// one chunk: compile tables, upload, launch level by level
+// one chunk: compile tables + descriptors (compile_chunk), then upload and launch level by level (submit_chunk)
 // ------------------------------------------------------------------------------------------------
-static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
-                     const std::vector<BlockCursor>& cur, uint64_t t0, bool is_scan, void* pcm_dst, int qmode,
-                     float amplitude) {
+static double ms_between(std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+    return std::chrono::duration<double, std::milli>(b - a).count();
+}
+
+// Steps 1 and 2 for ONE graph, appended to `cb` (which several graphs of a batch may share).
+static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
+                         const std::vector<BlockCursor>& cur, uint64_t t0, bool is_scan, void* pcm_dst, int qmode,
+                         float amplitude, ChunkBuild& cb) {
     const size_t bl = g->bl, sr = g->sr;
     const size_t nb = cur.size();
     const size_t M = nb * bl;
     if (M == 0) return 1;
     if (M > 0xFFFFFFF0ull) return fail("termdaw_amd: chunk too long");
-    g->prof_now = g->prof_every && (g->prof_count++ % g->prof_every) == 0;
     const size_t nv = g->vertices.size();
 
     g->band_stats_off.clear();
+    g->band_stats_base = nullptr;
     // ---- 1. host compile: sequential bookkeeping -> tables
     const auto tp0 = std::chrono::steady_clock::now();
-    Staging& st = g->staging;   // capacity kept from render to render
-    st.b.clear();
+    Staging& st = *cb.st;   // capacity kept from render to render
+    cb.n_graphs += 1;
     std::vector<VTables> vt(nv);
     for (size_t vi : g->order) {
         Vertex& v = g->vertices[vi];
@@ -931,25 +946,19 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
             last_use[u] = std::max(last_use[u], last_use[vi]);   // the input must outlive the stage's consumers
         }
 
-    struct Launch { int fam; size_t off; int n; uint32_t aux; int level; };
-    std::vector<Launch> launches;
     std::vector<std::vector<size_t>> by_level(g->n_levels);
     for (size_t vi : g->order) by_level[g->level[vi]].push_back(vi);
+    auto add_launch = [&](int fam, size_t off, int n, uint32_t aux, int level) {
+        cb.launches.push_back({fam, off, n, aux, level, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0});
+    };
 
     // scratch (device-only) region is laid out after the uploaded region
-    size_t scratch_bytes = 0;
-    auto scratch = [&](size_t n) { size_t o = scratch_bytes; scratch_bytes += (n + 255) & ~(size_t)255; return o; };
-    struct Fix { size_t at; size_t scratch_off; };   // pointer fields patched once the upload size is known
-    std::vector<Fix> fixes;
-    struct PtrFix { size_t at; size_t staging_off; };   // pointers into the uploaded region
-    std::vector<PtrFix> pfix;
-
+    auto scratch = [&](size_t n) { size_t o = cb.scratch_bytes; cb.scratch_bytes += (n + 255) & ~(size_t)255; return o; };
     auto ptr_field = [&](size_t desc_off, size_t field_off, size_t staging_off) {
-        pfix.push_back({desc_off + field_off, staging_off});
+        cb.table_fix.push_back({desc_off + field_off, staging_off});
     };
-    auto scratch_field = [&](size_t desc_off, size_t field_off, size_t s_off) { fixes.push_back({desc_off + field_off, s_off}); };
+    auto scratch_field = [&](size_t desc_off, size_t field_off, size_t s_off) { cb.scratch_fix.push_back({desc_off + field_off, s_off}); };
 
-    std::vector<size_t> peaks_to_zero;   // scratch offsets needing a memset
     const bool peaks_need_zero = !(bl == (size_t)kTileFrames);
 
     for (int lv = 0; lv < g->n_levels; ++lv) {
@@ -1197,7 +1206,7 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                             norm_scratch[vs[i]] = {pk, ic};
                             scratch_field(o, offsetof(SumDesc, peaks), pk);
                             scratch_field(o, offsetof(SumDesc, init_copy), ic);
-                            if (peaks_need_zero) peaks_to_zero.push_back(pk);
+                            if (peaks_need_zero) cb.zero.push_back({pk, nb * sizeof(float)});
                             g->vertices[vs[i]].has_init_override = false;
                         } else if (band_plan.count(vs[i])) {
                             const size_t bpk = scratch(((M + 255) / 256) * sizeof(float));
@@ -1340,12 +1349,12 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
                         wide_ok = wide_ok && (g->vertices[vs[e2]].kind != K_NORMALIZE || bl == (size_t)kTileFrames);
                         ++e2;
                     }
-                    launches.push_back({fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u), lv});
+                    add_launch(fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u), lv);
                     b = e2;
                 }
                 continue;
             }
-            launches.push_back({fam, off, (int)vs.size(), max_nseg, lv});
+            add_launch(fam, off, (int)vs.size(), max_nseg, lv);
         }
         for (float2* t : level_tmp) g->free_bufs.push_back(t);
         // release buffers whose last consumer sits at this level
@@ -1360,35 +1369,114 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
     const Vertex& outv = g->vertices[(size_t)g->output_vertex];
     if (pcm_dst && qmode && outv.kind != K_NORMALIZE) {
         std::vector<QuantDesc> d{{g->vbuf[(size_t)g->output_vertex], pcm_dst, amplitude, (uint32_t)qmode}};
-        launches.push_back({F_QUANT, st.put(d), 1, 0u, g->n_levels});
+        add_launch(F_QUANT, st.put(d), 1, 0u, g->n_levels);
     }
-
-    g->band_stats_base = 0;
-    // ---- 3. upload
     const auto tp2 = std::chrono::steady_clock::now();
+    g->host_ms[0] += ms_between(tp0, tp1);   // event compile
+    g->host_ms[1] += ms_between(tp1, tp2);   // descriptors
+    g->state_dev_dirty = true;
+    return 1;
+}
+
+static size_t desc_size(int fam) {
+    switch (fam) {
+        case F_LOOP: return sizeof(LoopDesc);
+        case F_MULTI: return sizeof(MultiDesc);
+        case F_LERP: return sizeof(LerpDesc);
+        case F_SINE: return sizeof(SineDesc);
+        case F_SYNTH: return sizeof(SynthDesc);
+        case F_SAMPSYN: return sizeof(SampsynDesc);
+        case F_SUM: return sizeof(SumDesc);
+        case F_SCALE: return sizeof(ScaleDesc);
+        case F_ADSR: return sizeof(AdsrVDesc);
+        case F_BAND: return sizeof(BandDesc);
+        case F_BAND_SPEC:
+        case F_BAND_FIX:
+        case F_BAND_FILL: return sizeof(BandSpecDesc);
+        case F_QUANT: return sizeof(QuantDesc);
+        default: return 0;
+    }
+}
+static bool is_band_family(int fam) { return fam == F_BAND_SPEC || fam == F_BAND_FIX || fam == F_BAND_FILL; }
+
+// Steps 3 and 4 for everything compiled into `cb`: patch pointers, upload the tables (skipped when the device
+// copy is already byte-identical), launch level by level on `stream`.  With several graphs in `cb` (a batch)
+// the launches are first merged: same level, family, launch parameters -> ONE grid whose blockIdx.y runs over
+// the descriptors of all the graphs (their descriptors are copied into one contiguous array behind the tables).
+// `fork_g`: the graph whose aux streams carry the independent launch families of a level (branch streams; single
+// graph only).  *scratch_base = device address the scratch offsets of this submission refer to.
+static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& prof, td_graph* fork_g,
+                        const uint8_t** scratch_base, double* host_ms /* [2]: upload, launches */) {
+    const auto tp2 = std::chrono::steady_clock::now();
+    Staging& st = *cb.st;
+    std::vector<Launch>& launches = cb.launches;
+    prof.now = prof.every && (prof.count++ % prof.every) == 0;
+    struct Copy { size_t dst, src, bytes; };
+    std::vector<Copy> copies;
+    if (cb.n_graphs > 1) {
+        auto key_less = [](const Launch& a, const Launch& b) {
+            if (a.level != b.level) return a.level < b.level;
+            if (a.fam != b.fam) return a.fam < b.fam;
+            if (a.M != b.M) return a.M < b.M;
+            if (a.bl != b.bl) return a.bl < b.bl;
+            if (a.is_scan != b.is_scan) return a.is_scan < b.is_scan;
+            if (!is_band_family(a.fam) && a.aux != b.aux) return a.aux < b.aux;
+            return false;
+        };
+        std::stable_sort(launches.begin(), launches.end(), key_less);
+        std::vector<Launch> merged;
+        merged.reserve(launches.size());
+        for (size_t i = 0; i < launches.size();) {
+            size_t j = i + 1;
+            int n = launches[i].n;
+            uint32_t aux = launches[i].aux;
+            while (j < launches.size() && !key_less(launches[i], launches[j]) && !key_less(launches[j], launches[i])) {
+                n += launches[j].n;
+                aux = std::max(aux, launches[j].aux);   // (equal unless a band family: its largest segment count)
+                ++j;
+            }
+            Launch L = launches[i];
+            if (j - i > 1) {
+                const size_t dsz = desc_size(L.fam);
+                size_t dst = st.alloc((size_t)n * dsz);
+                L.off = dst;
+                L.n = n;
+                L.aux = aux;
+                for (size_t q = i; q < j; ++q) {
+                    copies.push_back({dst, launches[q].off, (size_t)launches[q].n * dsz});
+                    dst += (size_t)launches[q].n * dsz;
+                }
+            }
+            merged.push_back(L);
+            i = j;
+        }
+        launches.swap(merged);
+    }
+    // ---- 3. upload
     const size_t upload = (st.b.size() + 255) & ~(size_t)255;
-    if (!ensure_arena(g, upload + scratch_bytes + 256)) return 0;
-    for (auto& f : pfix) {
-        uint64_t p = (uint64_t)(uintptr_t)(g->darena + f.staging_off);
+    if (!ensure_arena(ar, upload + cb.scratch_bytes + 256, stream)) return 0;
+    for (auto& f : cb.table_fix) {
+        uint64_t p = (uint64_t)(uintptr_t)(ar.d + f.off);
         memcpy(&st.b[f.at], &p, 8);
     }
-    g->band_stats_base = upload;
-    for (auto& f : fixes) {
-        uint64_t p = (uint64_t)(uintptr_t)(g->darena + upload + f.scratch_off);
+    for (auto& f : cb.scratch_fix) {
+        uint64_t p = (uint64_t)(uintptr_t)(ar.d + upload + f.off);
         memcpy(&st.b[f.at], &p, 8);
     }
-    if (g->arena_inflight) TD_HIP(hipEventSynchronize(g->arena_copied));
-    g->arena_inflight = false;
-    // re-rendering an unchanged project from the same state compiles to byte-identical tables: the copy
+    for (auto& c : copies) memcpy(&st.b[c.dst], &st.b[c.src], c.bytes);
+    *scratch_base = ar.d + upload;
+    if (ar.inflight) TD_HIP(hipEventSynchronize(ar.copied));
+    ar.inflight = false;
+    // re-rendering unchanged projects from the same state compiles to byte-identical tables: the copy
     // already on the device is reused (kernels never write the uploaded region)
-    if (!(g->arena_valid == st.b.size() && memcmp(g->harena, st.b.data(), st.b.size()) == 0)) {
-        memcpy(g->harena, st.b.data(), st.b.size());
-        TD_HIP(hipMemcpyAsync(g->darena, g->harena, st.b.size(), hipMemcpyHostToDevice, g->stream));
-        TD_HIP(hipEventRecord(g->arena_copied, g->stream));
-        g->arena_inflight = true;
-        g->arena_valid = st.b.size();
+    if (!(ar.valid == st.b.size() && memcmp(ar.h, st.b.data(), st.b.size()) == 0)) {
+        memcpy(ar.h, st.b.data(), st.b.size());
+        TD_HIP(hipMemcpyAsync(ar.d, ar.h, st.b.size(), hipMemcpyHostToDevice, stream));
+        TD_HIP(hipEventRecord(ar.copied, stream));
+        ar.inflight = true;
+        ar.valid = st.b.size();
     }
-    for (size_t pk : peaks_to_zero) TD_HIP(hipMemsetAsync(g->darena + upload + pk, 0, nb * sizeof(float), g->stream));
+    for (auto& z : cb.zero) TD_HIP(hipMemsetAsync(ar.d + upload + z.off, 0, z.bytes, stream));
 
     // ---- 4. launch, level by level
     const auto tp3 = std::chrono::steady_clock::now();
@@ -1401,127 +1489,161 @@ static int run_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* f
             groups |= a < 0 ? 1u : (2u << a);
             ++lj;
         }
-        const bool fork = g->branch_streams && __builtin_popcount(groups) > 1;
+        const bool fork = fork_g && fork_g->branch_streams && __builtin_popcount(groups) > 1;
         if (fork) {
-            TD_HIP(hipEventRecord(g->ev_fork, g->stream));
+            TD_HIP(hipEventRecord(fork_g->ev_fork, stream));
             for (int a = 0; a < td_graph::kAuxStreams; ++a)
-                if (groups & (2u << a)) TD_HIP(hipStreamWaitEvent(g->aux[a], g->ev_fork, 0));
+                if (groups & (2u << a)) TD_HIP(hipStreamWaitEvent(fork_g->aux[a], fork_g->ev_fork, 0));
         }
         for (size_t q = li; q < lj; ++q) {
             const Launch& L = launches[q];
-            const void* d = g->darena + L.off;
+            const void* d = ar.d + L.off;
             const int a = aux_stream_of(L.fam);
-            hipStream_t s = (fork && a >= 0) ? g->aux[a] : g->stream;
-            Prof prof(g, L.fam, s);
+            hipStream_t s = (fork && a >= 0) ? fork_g->aux[a] : stream;
+            Prof pr(prof, L.fam, s);
             switch (L.fam) {
-                case F_LOOP: launch_sample_loop((const LoopDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_MULTI: launch_sample_multi((const MultiDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_LERP: launch_sample_lerp((const LerpDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, s); break;
-                case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_SUM: launch_sum((const SumDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, s); break;
-                case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0, s); break;
-                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, (uint32_t)M, L.aux & 0xFFu, s); break;
-                case F_BAND: launch_band_pass((const BandDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
-                case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, (uint32_t)M, L.aux, s); break;
-                case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, (uint32_t)M, s); break;
-                case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, (uint32_t)M, s); break;
+                case F_LOOP: launch_sample_loop((const LoopDesc*)d, L.n, L.M, s); break;
+                case F_MULTI: launch_sample_multi((const MultiDesc*)d, L.n, L.M, s); break;
+                case F_LERP: launch_sample_lerp((const LerpDesc*)d, L.n, L.M, s); break;
+                case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, L.M, L.bl, s); break;
+                case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, L.M, s); break;
+                case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
+                case F_SUM: launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, s); break;
+                case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, L.M, L.bl, L.is_scan, s); break;
+                case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, L.M, L.aux & 0xFFu, s); break;
+                case F_BAND: launch_band_pass((const BandDesc*)d, L.n, L.M, s); break;
+                case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
+                case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
+                case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, L.M, s); break;
+                case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, L.M, s); break;
             }
         }
         if (fork) {
             for (int a = 0; a < td_graph::kAuxStreams; ++a)
                 if (groups & (2u << a)) {
-                    TD_HIP(hipEventRecord(g->ev_join[a], g->aux[a]));
-                    TD_HIP(hipStreamWaitEvent(g->stream, g->ev_join[a], 0));
+                    TD_HIP(hipEventRecord(fork_g->ev_join[a], fork_g->aux[a]));
+                    TD_HIP(hipStreamWaitEvent(stream, fork_g->ev_join[a], 0));
                 }
         }
         li = lj;
     }
     TD_HIP(hipGetLastError());
-    g->state_dev_dirty = true;
     const auto tp4 = std::chrono::steady_clock::now();
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
-    g->host_ms[0] += ms(tp0, tp1);   // event compile
-    g->host_ms[1] += ms(tp1, tp2);   // descriptors
-    g->host_ms[2] += ms(tp2, tp3);   // arena upload (or the compare that skips it)
-    g->host_ms[3] += ms(tp3, tp4);   // launches
-    g->host_chunks += 1;
+    host_ms[0] += ms_between(tp2, tp3);   // arena upload (or the compare that skips it)
+    host_ms[1] += ms_between(tp3, tp4);   // launches
     return 1;
 }
 
-// Renders n_blocks blocks in chunks.  advance_graph_time: Graph::render semantics (t += bl per block);
-// otherwise the scan's explicit j*bl clock starting at scan_t0 (graph.rs:229-233).  The FlowwBank is
-// advanced one block at a time exactly like state.rs:572 / graph.rs:232.
-int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
-                        int bits, bool advance_graph_time, size_t scan_t0, bool want_pcm) {
+// A render of n_blocks blocks runs in chunks of whole blocks (normally one).  The three pieces below are shared by the
+// single-graph path (graph_render_chunks) and the batch path (batch_render_chunks), which interleaves them over its graphs.
+struct RenderPlan {
+    size_t n_blocks = 0, chunk_blocks = 1, total = 0;
+    bool multi = false, want_pcm = false;
+    int qmode = 0, bits = 16;
+    float amplitude = 0.f;
+    size_t word = 0;
+};
+static int prepare_render(td_graph* g, size_t n_blocks, int bits, bool want_pcm, RenderPlan* rp) {
     if (!ensure_graph_device(g)) return 0;
     if (g->output_vertex < 0) return fail("TermDaw: error: output vertex not found.");
     if (g->plan_dirty) build_plan(g);
     if (!ensure_state_slots(g)) return 0;
     const size_t bl = g->bl;
     if (bl == 0) return fail("termdaw_amd: buffer length 0");
-    const size_t total = n_blocks * bl;
-    size_t chunk_blocks = std::max<size_t>(1, g->max_chunk_frames / bl);
-    chunk_blocks = std::min(chunk_blocks, std::max<size_t>(n_blocks, 1));
-    const bool multi = n_blocks > chunk_blocks;
-    int qmode = 0;
-    float amplitude = 0.f;
-    size_t word = 0;
+    rp->n_blocks = n_blocks;
+    rp->total = n_blocks * bl;
+    rp->chunk_blocks = std::max<size_t>(1, g->max_chunk_frames / bl);
+    rp->chunk_blocks = std::min(rp->chunk_blocks, std::max<size_t>(n_blocks, 1));
+    rp->multi = n_blocks > rp->chunk_blocks;
+    rp->want_pcm = want_pcm;
+    rp->bits = bits;
     if (want_pcm) {
         if (!(bits == 8 || bits == 16 || bits == 24 || bits == 32))   // state.rs:495-501
             return fail("Bitdepth not supported: choose bitdepth in {8, 16, 24, 32}.");
-        qmode = bits > 16 ? 2 : 1;                                    // write_16s / write_32s, state.rs:567-571
-        amplitude = bits < 32 ? (float)((1 << (bits - 1)) - 1) : (float)INT32_MAX;   // state.rs:515-516
-        word = qmode == 1 ? 2 : 4;
-        const size_t need = total * 2 * word + 64;
+        rp->qmode = bits > 16 ? 2 : 1;                                    // write_16s / write_32s, state.rs:567-571
+        rp->amplitude = bits < 32 ? (float)((1 << (bits - 1)) - 1) : (float)INT32_MAX;   // state.rs:515-516
+        rp->word = rp->qmode == 1 ? 2 : 4;
+        const size_t need = rp->total * 2 * rp->word + 64;
         if (need > g->pcm_cap) {
             TD_HIP(hipStreamSynchronize(g->stream));
             if (g->d_pcm) { (void)hipFree(g->d_pcm); g->device_bytes -= g->pcm_cap; }
+            g->d_pcm = nullptr;
+            g->pcm_cap = 0;
             TD_HIP(hipMalloc(&g->d_pcm, need));
             g->pcm_cap = need;
             g->device_bytes += need;
         }
-        g->pcm_bytes = total * 2 * word;
+        g->pcm_bytes = rp->total * 2 * rp->word;
     }
-    if (multi) {
-        const size_t need = (total + 2) * sizeof(float2);
+    if (rp->multi) {
+        const size_t need = (rp->total + 2) * sizeof(float2);
         if (need > g->out_f32_cap) {
             TD_HIP(hipStreamSynchronize(g->stream));
             if (g->d_out_f32) { (void)hipFree(g->d_out_f32); g->device_bytes -= g->out_f32_cap; }
+            g->d_out_f32 = nullptr;
+            g->out_f32_cap = 0;
             TD_HIP(hipMalloc(&g->d_out_f32, need));
             g->out_f32_cap = need;
             g->device_bytes += need;
         }
     }
+    return 1;
+}
+// Snapshots the FlowwBank cursor of the next nb blocks (advancing the bank one block at a time exactly like
+// state.rs:572 / graph.rs:232) and compiles the chunk into cb.
+static int compile_next_chunk(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, const RenderPlan& rp, size_t done,
+                              size_t nb, bool is_scan, bool advance_graph_time, size_t scan_t0, ChunkBuild& cb) {
+    const size_t bl = g->bl;
+    std::vector<BlockCursor>& cur = g->cursor;   // (capacity kept from render to render)
+    const size_t nfl = fb->start_indices.size();
+    cur.resize(nb);
+    g->cursor_starts.resize(nb * nfl + 1);
+    for (size_t b = 0; b < nb; ++b) {
+        size_t* s = g->cursor_starts.data() + b * nfl;
+        for (size_t i = 0; i < nfl; ++i) s[i] = fb->start_indices[i];
+        cur[b] = {fb->frame, s, nfl};
+        fb->set_time_to_next_block();
+    }
+    const uint64_t t0 = advance_graph_time ? g->t : scan_t0 + done * bl;
+    void* pcm_dst = rp.want_pcm ? (uint8_t*)g->d_pcm + done * bl * 2 * rp.word : nullptr;
+    return compile_chunk(g, sb, fb, cur, t0, is_scan, pcm_dst, rp.qmode, rp.amplitude, cb);
+}
+static int finish_chunk(td_graph* g, const RenderPlan& rp, size_t done, size_t nb, bool advance_graph_time,
+                        const uint8_t* scratch_base) {
+    g->band_stats_base = scratch_base;
+    if (advance_graph_time) g->t += nb * g->bl;
+    if (rp.multi)
+        TD_HIP(hipMemcpyAsync(g->d_out_f32 + done * g->bl, g->vbuf[(size_t)g->output_vertex], nb * g->bl * sizeof(float2),
+                              hipMemcpyDeviceToDevice, g->stream));
+    return 1;
+}
+static void finish_render(td_graph* g, const RenderPlan& rp) {
+    g->last_out_f32 = rp.multi ? g->d_out_f32 : (rp.n_blocks ? g->vbuf[(size_t)g->output_vertex] : nullptr);
+    g->last_frames = rp.total;
+    g->last_bits = rp.bits;
+}
+
+// Renders n_blocks blocks in chunks.  advance_graph_time: Graph::render semantics (t += bl per block);
+// otherwise the scan's explicit j*bl clock starting at scan_t0 (graph.rs:229-233).
+int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
+                        int bits, bool advance_graph_time, size_t scan_t0, bool want_pcm) {
+    RenderPlan rp;
+    if (!prepare_render(g, n_blocks, bits, want_pcm, &rp)) return 0;
+    ChunkBuild& cb = g->build;
+    cb.st = &g->staging;
+    // (a graph that belongs to a batch may still render alone: it then uses its own arena on the shared stream)
     size_t done = 0;
     while (done < n_blocks) {
-        const size_t nb = std::min(chunk_blocks, n_blocks - done);
-        std::vector<BlockCursor>& cur = g->cursor;   // (capacity kept from render to render)
-        const size_t nfl = fb->start_indices.size();
-        cur.resize(nb);
-        g->cursor_starts.resize(nb * nfl + 1);
-        for (size_t b = 0; b < nb; ++b) {
-            size_t* s = g->cursor_starts.data() + b * nfl;
-            for (size_t i = 0; i < nfl; ++i) s[i] = fb->start_indices[i];
-            cur[b] = {fb->frame, s, nfl};
-            fb->set_time_to_next_block();
-        }
-        const uint64_t t0 = advance_graph_time ? g->t : scan_t0 + done * bl;
-        void* pcm_dst = want_pcm ? (uint8_t*)g->d_pcm + done * bl * 2 * word : nullptr;
-        if (!run_chunk(g, sb, fb, cur, t0, is_scan, pcm_dst, qmode, amplitude)) return 0;
-        if (advance_graph_time) g->t += nb * bl;
-        if (multi)
-            TD_HIP(hipMemcpyAsync(g->d_out_f32 + done * bl, g->vbuf[(size_t)g->output_vertex], nb * bl * sizeof(float2),
-                                  hipMemcpyDeviceToDevice, g->stream));
+        const size_t nb = std::min(rp.chunk_blocks, n_blocks - done);
+        cb.clear();
+        if (!compile_next_chunk(g, sb, fb, rp, done, nb, is_scan, advance_graph_time, scan_t0, cb)) return 0;
+        const uint8_t* scratch_base = nullptr;
+        if (!submit_chunk(g->arena, cb, g->stream, g->prof, g, &scratch_base, &g->host_ms[2])) return 0;
+        g->host_chunks += 1;
+        if (!finish_chunk(g, rp, done, nb, advance_graph_time, scratch_base)) return 0;
         done += nb;
     }
-    g->last_out_f32 = multi ? g->d_out_f32 : (n_blocks ? g->vbuf[(size_t)g->output_vertex] : nullptr);
-    g->last_frames = total;
-    g->last_bits = bits;
+    finish_render(g, rp);
     return 1;
 }
 
@@ -1544,6 +1666,49 @@ static int graph_set_time_impl(td_graph* g, size_t time) {   // graph.rs:123-128
             default: break;
         }
     }
+    return 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch: many independent projects per submission (BASELINE config 5)
+// ------------------------------------------------------------------------------------------------
+// The same chunk loop as graph_render_chunks, interleaved over the graphs of the batch: every graph compiles its
+// chunk into the batch's ChunkBuild, ONE submission uploads the tables and launches the merged grids.  Graphs
+// may differ in everything (structure, block length, chunk cap); launches merge only where level, family and
+// launch parameters agree.
+static int batch_render_chunks(td_batch* b, size_t n_blocks, bool is_scan, int bits, bool advance_graph_time, bool want_pcm) {
+    const size_t P = b->graphs.size();
+    if (P == 0) return 1;
+    if (!ensure_device(b->device)) return 0;
+    std::vector<RenderPlan> rp(P);
+    for (size_t i = 0; i < P; ++i)
+        if (!prepare_render(b->graphs[i], n_blocks, bits, want_pcm, &rp[i])) return 0;
+    ChunkBuild& cb = b->build;
+    cb.st = &b->staging;
+    std::vector<size_t> done(P, 0), nb(P, 0);
+    for (;;) {
+        const auto t0 = std::chrono::steady_clock::now();
+        cb.clear();
+        bool any = false;
+        for (size_t i = 0; i < P; ++i) {
+            nb[i] = std::min(rp[i].chunk_blocks, n_blocks - done[i]);
+            if (!nb[i]) continue;
+            any = true;
+            if (!compile_next_chunk(b->graphs[i], b->sbs[i], b->fbs[i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb))
+                return 0;
+        }
+        if (!any) break;
+        const uint8_t* scratch_base = nullptr;
+        b->host_ms[0] += ms_between(t0, std::chrono::steady_clock::now());
+        if (!submit_chunk(b->arena, cb, b->stream, b->prof, nullptr, &scratch_base, &b->host_ms[2])) return 0;
+        for (size_t i = 0; i < P; ++i) {
+            if (!nb[i]) continue;
+            if (!finish_chunk(b->graphs[i], rp[i], done[i], nb[i], advance_graph_time, scratch_base)) return 0;
+            done[i] += nb[i];
+        }
+        b->host_steps += 1;
+    }
+    for (size_t i = 0; i < P; ++i) finish_render(b->graphs[i], rp[i]);
     return 1;
 }
 
@@ -1688,28 +1853,42 @@ td_graph* td_graph_new(size_t max_buffer_len, size_t sr) {
     g->device = t_device;
     return g;
 }
+static void free_prof(ProfCtx& pc) {
+    for (auto& e : pc.pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto e : pc.free_ev) (void)hipEventDestroy(e);
+    pc.pending.clear();
+    pc.free_ev.clear();
+}
 void td_graph_free(td_graph* g) {
     if (!g) return;
+    if (g->batch) {   // leave the batch first: it must not keep a dangling handle
+        td_batch* b = g->batch;
+        for (size_t i = 0; i < b->graphs.size(); ++i)
+            if (b->graphs[i] == g) {
+                b->graphs.erase(b->graphs.begin() + (long)i);
+                b->sbs.erase(b->sbs.begin() + (long)i);
+                b->fbs.erase(b->fbs.begin() + (long)i);
+                break;
+            }
+    }
     if (g->stream && hipSetDevice(g->device) == hipSuccess) {
         (void)hipStreamSynchronize(g->stream);
         for (float2* p : g->pool) (void)hipFree(p);
         for (float* p : g->wavetables) (void)hipFree(p);
         if (g->dstate) (void)hipFree(g->dstate);
-        if (g->harena) (void)hipHostFree(g->harena);
-        if (g->darena) (void)hipFree(g->darena);
+        free_arena(g->arena);
         if (g->d_pcm) (void)hipFree(g->d_pcm);
         if (g->d_out_f32) (void)hipFree(g->d_out_f32);
         if (g->d_resampled) (void)hipFree(g->d_resampled);
         if (g->d_scalar) (void)hipFree(g->d_scalar);
-        for (auto& e : g->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        for (auto e : g->ev_free) (void)hipEventDestroy(e);
-        (void)hipEventDestroy(g->arena_copied);
-        (void)hipEventDestroy(g->ev_fork);
-        for (int a = 0; a < td_graph::kAuxStreams; ++a) {
-            (void)hipEventDestroy(g->ev_join[a]);
-            (void)hipStreamDestroy(g->aux[a]);
-        }
-        (void)hipStreamDestroy(g->stream);
+        free_prof(g->prof);
+        if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
+        for (int a = 0; a < td_graph::kAuxStreams; ++a)
+            if (g->aux[a]) {
+                (void)hipEventDestroy(g->ev_join[a]);
+                (void)hipStreamDestroy(g->aux[a]);
+            }
+        if (g->owns_stream) (void)hipStreamDestroy(g->stream);
     }
     delete g;
 }
@@ -1947,10 +2126,13 @@ int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb
     const int ok = graph_render_chunks(g, sb, fb, 1, false, 16, true, 0, false);
     fb->frame = frame;
     fb->start_indices = starts;
-    if (!ok) return 0;
+    if (!ok) return -1;
     std::vector<float2> tmp(g->bl);
-    TD_HIP(hipMemcpyAsync(tmp.data(), g->last_out_f32, g->bl * sizeof(float2), hipMemcpyDeviceToHost, g->stream));
-    TD_HIP(hipStreamSynchronize(g->stream));
+    if (hipMemcpyAsync(tmp.data(), g->last_out_f32, g->bl * sizeof(float2), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
+        hipStreamSynchronize(g->stream) != hipSuccess) {
+        fail("HIP error: block read-back failed");
+        return -1;
+    }
     for (size_t i = 0; i < g->bl; ++i) {
         if (l) l[i] = tmp[i].x;
         if (r) r[i] = tmp[i].y;
@@ -1958,8 +2140,8 @@ int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb
     return 1;
 }
 
-int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t chunks) {   // graph.rs:222-237
-    if (g->output_vertex < 0) return 1;
+// Graph::true_normalize_scan (graph.rs:222-237) around the dry run itself
+static int scan_begin(td_graph* g, td_flowwbank* fb) {
     if (!ensure_graph_device(g)) return 0;
     if (g->plan_dirty) build_plan(g);
     if (!ensure_state_slots(g)) return 0;
@@ -1967,7 +2149,9 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
         if (v.kind == K_NORMALIZE)
             TD_HIP(hipMemsetD32Async((hipDeviceptr_t)&g->dstate[v.state_slot].norm.scan_max, 0, 1, g->stream));
     fb->set_time(0);
-    if (!graph_render_chunks(g, sb, fb, chunks, true, 16, false, 0, false)) return 0;
+    return 1;
+}
+static int scan_end(td_graph* g, td_flowwbank* fb) {
     for (auto& v : g->vertices)   // apply_scan_normalization: max = scan_max (every Normalize vertex, reached or not)
         if (v.kind == K_NORMALIZE) {
             v.has_init_override = false;
@@ -1977,6 +2161,13 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
     g->state_dev_dirty = true;
     if (!graph_set_time_impl(g, 0)) return 0;
     fb->set_time(0);
+    return 1;
+}
+int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t chunks) {   // graph.rs:222-237
+    if (g->output_vertex < 0) return 1;
+    if (!scan_begin(g, fb)) return 0;
+    if (!graph_render_chunks(g, sb, fb, chunks, true, 16, false, 0, false)) return 0;
+    if (!scan_end(g, fb)) return 0;
     TD_HIP(hipStreamSynchronize(g->stream));
     return 1;
 }
@@ -2069,35 +2260,32 @@ size_t td_graph_host_times(td_graph* g, double* ms4, int reset) {
     if (reset) { for (double& v : g->host_ms) v = 0.0; g->host_chunks = 0; }
     return n;
 }
-void td_graph_set_profiling(td_graph* g, int on) {
-    g->prof_every = on > 0 ? (unsigned)on : 0u;
-    g->prof_count = 0;
-    g->prof_now = false;
-    for (auto& e : g->ev_pending) { g->ev_free.push_back(e.a); g->ev_free.push_back(e.b); }
-    g->ev_pending.clear();
-    g->last_times.clear();
+static void prof_set(ProfCtx& pc, int on) {
+    pc.every = on > 0 ? (unsigned)on : 0u;
+    pc.count = 0;
+    pc.now = false;
+    for (auto& e : pc.pending) { pc.free_ev.push_back(e.a); pc.free_ev.push_back(e.b); }
+    pc.pending.clear();
+    pc.last_times.clear();
 }
-size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float* ms, size_t* launches, size_t cap) {
-    td_graph* g = const_cast<td_graph*>(gc);
-    if (g->stream && hipSetDevice(g->device) == hipSuccess) {
-        (void)hipStreamSynchronize(g->stream);
-        if (g->last_times.empty()) {
-            g->last_times.resize(F_COUNT);
-            for (int f = 0; f < F_COUNT; ++f) g->last_times[f].name = kFamilyName[f];
-        }
-        for (auto& e : g->ev_pending) {
-            float t = 0.f;
-            if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {
-                g->last_times[e.fam].ms += t;
-                g->last_times[e.fam].launches += 1;
-            }
-            g->ev_free.push_back(e.a);
-            g->ev_free.push_back(e.b);
-        }
-        g->ev_pending.clear();
+// (the caller has synchronised the stream the events were recorded on)
+static size_t prof_collect(ProfCtx& pc, const char** names, float* ms, size_t* launches, size_t cap) {
+    if (pc.last_times.empty()) {
+        pc.last_times.resize(F_COUNT);
+        for (int f = 0; f < F_COUNT; ++f) pc.last_times[f].name = kFamilyName[f];
     }
+    for (auto& e : pc.pending) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {
+            pc.last_times[e.fam].ms += t;
+            pc.last_times[e.fam].launches += 1;
+        }
+        pc.free_ev.push_back(e.a);
+        pc.free_ev.push_back(e.b);
+    }
+    pc.pending.clear();
     size_t n = 0;
-    for (auto& kt : g->last_times) {
+    for (auto& kt : pc.last_times) {
         if (!kt.launches) continue;
         if (n < cap) {
             names[n] = kt.name.c_str();
@@ -2108,17 +2296,24 @@ size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float*
     }
     return std::min(n, cap);
 }
-size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes; }
+void td_graph_set_profiling(td_graph* g, int on) { prof_set(g->prof, on); }
+size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float* ms, size_t* launches, size_t cap) {
+    td_graph* g = const_cast<td_graph*>(gc);
+    if (!(g->stream && hipSetDevice(g->device) == hipSuccess)) return 0;
+    (void)hipStreamSynchronize(g->stream);
+    return prof_collect(g->prof, names, ms, launches, cap);
+}
+size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes + g->arena.device_bytes; }
 
 int td_graph_band_stats(const td_graph* gc, uint32_t out[3]) {
     td_graph* g = const_cast<td_graph*>(gc);
     out[0] = out[1] = out[2] = 0;
-    if (g->band_stats_off.empty() || !g->darena) return 1;
+    if (g->band_stats_off.empty() || !g->band_stats_base) return 1;
     if (!ensure_device(g->device)) return 0;
     TD_HIP(hipStreamSynchronize(g->stream));
     for (size_t so : g->band_stats_off) {
         uint32_t s[4];
-        TD_HIP(hipMemcpy(s, g->darena + g->band_stats_base + so, 16, hipMemcpyDeviceToHost));
+        TD_HIP(hipMemcpy(s, g->band_stats_base + so, 16, hipMemcpyDeviceToHost));
         for (int i = 0; i < 3; ++i) out[i] += s[i];
     }
     return 1;
@@ -2139,6 +2334,154 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
         return 1;
     }
     return fail("unknown option \"" + k + "\"");
+}
+
+// ---- Batch (no reference counterpart: the reference renders one project per process; this is the loop a
+// batch driver would run State::render, state.rs:563-575, in for many independent States) ----
+td_batch* td_batch_new(void) {
+    td_batch* b = new td_batch();
+    b->device = t_device;
+    return b;
+}
+void td_batch_free(td_batch* b) {
+    if (!b) return;
+    const bool dev_ok = hipSetDevice(b->device) == hipSuccess;
+    if (b->stream && dev_ok) (void)hipStreamSynchronize(b->stream);
+    for (td_graph* g : b->graphs) {   // the projects outlive the batch: give each its own stream back (made on next use)
+        g->batch = nullptr;
+        g->stream = nullptr;
+        g->owns_stream = true;
+        if (dev_ok && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) g->stream = nullptr;
+    }
+    if (dev_ok) {
+        free_arena(b->arena);
+        free_prof(b->prof);
+        if (b->d_peaks) (void)hipFree(b->d_peaks);
+        if (b->stream) (void)hipStreamDestroy(b->stream);
+    }
+    delete b;
+}
+long td_batch_add(td_batch* b, td_graph* g, const td_samplebank* sb, td_flowwbank* fb) {
+    if (!g || !sb || !fb) { fail("td_batch_add: null handle"); return -1; }
+    if (g->batch) { fail("td_batch_add: the graph already belongs to a batch"); return -1; }
+    if (g->device != b->device || sb->device != b->device) { fail("td_batch_add: project and batch live on different devices"); return -1; }
+    if (!ensure_device(b->device)) return -1;
+    if (!b->stream && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+        fail("td_batch_add: cannot create a HIP stream");
+        return -1;
+    }
+    // the graph's launches, state copies and memsets move to the batch's stream
+    if (g->stream) {
+        (void)hipStreamSynchronize(g->stream);
+        if (g->owns_stream) (void)hipStreamDestroy(g->stream);
+    }
+    g->stream = b->stream;
+    g->owns_stream = false;
+    g->batch = b;
+    b->graphs.push_back(g);
+    b->sbs.push_back(sb);
+    b->fbs.push_back(fb);
+    return (long)b->graphs.size() - 1;
+}
+size_t td_batch_size(const td_batch* b) { return b->graphs.size(); }
+/* reset_normalize_vertices (state.rs:467) + FlowwBank::set_time(0) for every project: the state right after refresh */
+void td_batch_rewind(td_batch* b) {
+    for (size_t i = 0; i < b->graphs.size(); ++i) {
+        td_graph_reset_normalize_vertices(b->graphs[i]);
+        b->fbs[i]->set_time(0);
+    }
+}
+size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits) {
+    if (!batch_render_chunks(b, n_blocks, false, bits, true, true)) return 0;
+    for (td_graph* g : b->graphs)
+        if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
+    return b->graphs.empty() ? 0 : n_blocks * b->graphs[0]->bl;
+}
+int td_batch_sync(td_batch* b) {
+    if (!b->stream) return 1;
+    if (!ensure_device(b->device)) return 0;
+    TD_HIP(hipStreamSynchronize(b->stream));
+    return 1;
+}
+size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits) {
+    const size_t n = td_batch_render_all_async(b, n_blocks, bits);
+    if (!n) return 0;
+    if (!td_batch_sync(b)) return 0;
+    return n;
+}
+int td_batch_normalize_scan(td_batch* b, size_t chunks) {   // State::scan_exact (state.rs:473-475) for every project
+    for (size_t i = 0; i < b->graphs.size(); ++i) {
+        if (b->graphs[i]->output_vertex < 0) return fail("TermDaw: error: output vertex not found.");
+        if (!scan_begin(b->graphs[i], b->fbs[i])) return 0;
+    }
+    if (!batch_render_chunks(b, chunks, true, 16, false, false)) return 0;
+    for (size_t i = 0; i < b->graphs.size(); ++i)
+        if (!scan_end(b->graphs[i], b->fbs[i])) return 0;
+    return td_batch_sync(b);
+}
+// Per-project peak after the last render: the output Normalize vertex' running peak (`max`, extensions.rs:323 --
+// the project's pre-normalisation peak), or the absolute peak of the output buffer when the output vertex is no
+// Normalize.  Fills a table of n_total floats in DEVICE memory: project i of this batch goes to entry
+// first + i * stride, every other entry is written as 0 -- ready for one all-reduce(max) across the ranks.
+int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size_t first, size_t stride) {
+    const size_t P = b->graphs.size();
+    if (stride == 0 || (P && first + (P - 1) * stride >= n_total)) return fail("td_batch_peak_table_device: table too small");
+    if (n_total > 0xFFFFFFFFull) return fail("td_batch_peak_table_device: table too large");
+    if (!ensure_device(b->device)) return 0;
+    if (!b->stream) TD_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (P > b->peaks_cap) {
+        TD_HIP(hipStreamSynchronize(b->stream));
+        if (b->d_peaks) (void)hipFree(b->d_peaks);
+        b->d_peaks = nullptr;
+        b->peaks_cap = 0;
+        TD_HIP(hipMalloc(&b->d_peaks, (P + 10) * (sizeof(float) + sizeof(float*))));
+        b->peaks_cap = P + 8;
+    }
+    const float** d_src = reinterpret_cast<const float**>(b->d_peaks + ((b->peaks_cap + 1) & ~(size_t)1));
+    std::vector<const float*> src(P);
+    for (size_t i = 0; i < P; ++i) {
+        td_graph* g = b->graphs[i];
+        const Vertex* outv = g->output_vertex >= 0 ? &g->vertices[(size_t)g->output_vertex] : nullptr;
+        if (outv && outv->kind == K_NORMALIZE && g->dstate && !outv->has_init_override) {
+            src[i] = &g->dstate[outv->state_slot].norm.max;
+        } else {
+            src[i] = b->d_peaks + i;
+            if (g->last_out_f32 && g->last_frames)
+                launch_absmax((const float*)g->last_out_f32, (uint32_t)std::min<size_t>(g->last_frames * 2, 0xFFFFFFFFu), b->d_peaks + i, b->stream);
+            else
+                TD_HIP(hipMemsetAsync(b->d_peaks + i, 0, sizeof(float), b->stream));
+        }
+    }
+    if (P) TD_HIP(hipMemcpyAsync(d_src, src.data(), P * sizeof(float*), hipMemcpyHostToDevice, b->stream));
+    TD_HIP(hipStreamSynchronize(b->stream));   // (src lives on this stack frame)
+    if (n_total) launch_peak_table(d_src, d_table, (uint32_t)n_total, (uint32_t)P, (uint32_t)first, (uint32_t)stride, b->stream);
+    TD_HIP(hipGetLastError());
+    return 1;
+}
+int td_batch_peaks(td_batch* b, float* out) {   // host copy of this batch's own entries, in td_batch_add order
+    const size_t P = b->graphs.size();
+    if (!P) return 1;
+    if (!ensure_device(b->device)) return 0;
+    float* d_tab = nullptr;
+    TD_HIP(hipMalloc(&d_tab, P * sizeof(float)));
+    int ok = td_batch_peak_table_device(b, d_tab, P, 0, 1);
+    if (ok && (hipMemcpyAsync(out, d_tab, P * sizeof(float), hipMemcpyDeviceToHost, b->stream) != hipSuccess ||
+               hipStreamSynchronize(b->stream) != hipSuccess))
+        ok = fail("td_batch_peaks: read-back failed");
+    (void)hipFree(d_tab);
+    return ok;
+}
+void td_batch_set_profiling(td_batch* b, int on) { prof_set(b->prof, on); }
+size_t td_batch_last_kernel_times(td_batch* b, const char** names, float* ms, size_t* launches, size_t cap) {
+    if (!(b->stream && hipSetDevice(b->device) == hipSuccess)) return 0;
+    (void)hipStreamSynchronize(b->stream);
+    return prof_collect(b->prof, names, ms, launches, cap);
+}
+size_t td_batch_host_times(td_batch* b, double* ms4, int reset) {
+    for (int i = 0; i < 4; ++i) ms4[i] = b->host_ms[i];
+    const size_t n = b->host_steps;
+    if (reset) { for (double& v : b->host_ms) v = 0.0; b->host_steps = 0; }
+    return n;
 }
 
 }  // extern "C"

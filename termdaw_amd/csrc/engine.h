@@ -153,7 +153,66 @@ struct BlockCursor {   // FlowwBank state at the start of one block: frame + sta
     const size_t* start;   // [n], into the chunk's flat cursor table
     size_t n;
 };
+
+// Table / descriptor arena of one submission: pinned host mirror + device copy, device-only scratch behind the
+// uploaded part.  A graph rendering alone owns one; the graphs of a td_batch share the batch's.
+struct Arena {
+    uint8_t* h = nullptr;
+    uint8_t* d = nullptr;
+    size_t cap = 0;
+    hipEvent_t copied = nullptr;
+    bool inflight = false;
+    size_t valid = 0;          // bytes of `h` that `d` currently mirrors
+    size_t device_bytes = 0;
+};
+
+// HIP-event timing of launch families (bench hook)
+struct ProfCtx {
+    unsigned every = 0, count = 0;   // events around the launches of every `every`-th submission
+    bool now = false;
+    struct EvPair { hipEvent_t a, b; int fam; };
+    std::vector<EvPair> pending;
+    std::vector<hipEvent_t> free_ev;
+    std::vector<KernelTime> last_times;
+};
+
+// One kernel launch of a compiled chunk: `n` descriptors of family `fam` at staging offset `off`.
+struct Launch {
+    int fam;
+    size_t off;
+    int n;
+    uint32_t aux;      // F_SUM / F_ADSR: term mode | 0x100 (wide ok); band families: max segment count
+    int level;
+    uint32_t M, bl;    // frames of the chunk, reference block length
+    int is_scan;
+};
+
+// What compile_chunk() appends to: the staging arena under construction plus everything the submission needs
+// to patch and launch it.  Several graphs (a td_batch) compile into ONE ChunkBuild; same-family launches of
+// different graphs are then merged into one grid (blockIdx.y indexes the descriptors).
+struct ChunkBuild {
+    Staging* st = nullptr;
+    size_t scratch_bytes = 0;
+    struct Fix { size_t at; size_t off; };
+    std::vector<Fix> scratch_fix;   // pointer fields -> device scratch (patched once the upload size is known)
+    std::vector<Fix> table_fix;     // pointer fields -> uploaded tables
+    struct Zero { size_t off, bytes; };
+    std::vector<Zero> zero;         // scratch ranges that need a memset before the launches
+    std::vector<Launch> launches;
+    size_t n_graphs = 0;
+    void clear() {
+        st->b.clear();
+        scratch_bytes = 0;
+        scratch_fix.clear();
+        table_fix.clear();
+        zero.clear();
+        launches.clear();
+        n_graphs = 0;
+    }
+};
 }  // namespace tde
+
+struct td_batch;
 
 struct td_graph {
     // graph.rs:12-22
@@ -184,13 +243,11 @@ struct td_graph {
     tde::StateSlot* dstate = nullptr;
     size_t dstate_cap = 0;
     bool state_host_dirty = true, state_dev_dirty = false;
-    // per-chunk table arena (pinned host + device)
-    uint8_t* harena = nullptr;
-    uint8_t* darena = nullptr;
-    size_t arena_cap = 0;
-    hipEvent_t arena_copied = nullptr;
-    bool arena_inflight = false;
-    size_t arena_valid = 0;                   // bytes of harena that darena currently mirrors
+    // per-chunk table arena (pinned host + device); unused while the graph renders as part of a batch
+    tde::Arena arena;
+    tde::ChunkBuild build;
+    td_batch* batch = nullptr;                // set by td_batch_add: the graph shares the batch's stream
+    bool owns_stream = true;
     // outputs of the last render
     void* d_pcm = nullptr;
     size_t pcm_cap = 0, pcm_bytes = 0;
@@ -209,20 +266,33 @@ struct td_graph {
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
     std::vector<size_t> band_stats_off;        // scratch offsets of the last chunk's k_band_fix counters
-    size_t band_stats_base = 0;
+    const uint8_t* band_stats_base = nullptr;  // device scratch base those offsets refer to
     size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)
-    // profiling
-    unsigned prof_every = 0, prof_count = 0;   // HIP events around the launches of every prof_every-th chunk
-    bool prof_now = false;
+    tde::ProfCtx prof;
     tde::Staging staging;               // table / descriptor arena under construction (host)
     std::vector<tde::BlockCursor> cursor;   // per-block FlowwBank cursors of the chunk being compiled
     std::vector<size_t> cursor_starts;
     double host_ms[4] = {0, 0, 0, 0};   // host time per run_chunk phase: compile, descriptors, upload, launches
     size_t host_chunks = 0;
-    struct EvPair { hipEvent_t a, b; int fam; };
-    std::vector<EvPair> ev_pending;
-    std::vector<hipEvent_t> ev_free;
-    std::vector<tde::KernelTime> last_times;
+};
+
+// Many independent projects rendered together (BASELINE config 5: the body of State::render's loop,
+// state.rs:563-575, for every project of a GPU's share): the graphs compile into one arena and same-family
+// launches of different projects share one grid.
+struct td_batch {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<td_graph*> graphs;
+    std::vector<const td_samplebank*> sbs;
+    std::vector<td_flowwbank*> fbs;
+    tde::Arena arena;
+    tde::Staging staging;
+    tde::ChunkBuild build;
+    tde::ProfCtx prof;
+    float* d_peaks = nullptr;            // [size] per-project peak scratch + [size] source pointers behind it
+    size_t peaks_cap = 0;
+    double host_ms[4] = {0, 0, 0, 0};
+    size_t host_steps = 0;
 };
 
 namespace tde {

@@ -288,6 +288,10 @@ void launch_sample_pack(const float* l, const float* r, const float* max_l, cons
 // not an integer in [-32768, 32767] (then the packed form is not usable)
 void launch_sample_pack16(const float* l, const float* r, uint32_t* packed, uint32_t n, uint32_t* not_int16, hipStream_t s);
 
+// per-project peak table of a batch: table[first + i * stride] = *src[i] for i < n_own, every other entry 0
+void launch_peak_table(const float* const* src, float* table, uint32_t n_total, uint32_t n_own, uint32_t first, uint32_t stride,
+                       hipStream_t s);
+
 void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);

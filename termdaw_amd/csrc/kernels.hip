@@ -1756,6 +1756,18 @@ void launch_absmax(const float* v, uint32_t n, float* out, hipStream_t s) {
     (void)hipMemsetAsync(out, 0, sizeof(float), s);
     if (n) hipLaunchKernelGGL(k_absmax_atomic, dim3(grid_for(n)), dim3(kThreads), 0, s, v, n, out);
 }
+__global__ __launch_bounds__(kThreads) void k_peak_table(const float* const* __restrict__ src, float* __restrict__ table,
+                                                         uint32_t n_total, uint32_t n_own, uint32_t first, uint32_t stride) {
+    const uint32_t j = blockIdx.x * kThreads + threadIdx.x;
+    if (j >= n_total) return;
+    float v = 0.0f;
+    if (j >= first && (j - first) % stride == 0u && (j - first) / stride < n_own) v = *src[(j - first) / stride];
+    table[j] = v;
+}
+void launch_peak_table(const float* const* src, float* table, uint32_t n_total, uint32_t n_own, uint32_t first, uint32_t stride,
+                       hipStream_t s) {
+    if (n_total) hipLaunchKernelGGL(k_peak_table, dim3((n_total + kThreads - 1) / kThreads), dim3(kThreads), 0, s, src, table, n_total, n_own, first, stride);
+}
 void launch_resample(const ResampleDesc& d, hipStream_t s) {
     if (!d.nout) return;
     const uint64_t blocks = (d.nout + kThreads - 1) / kThreads;

@@ -208,7 +208,11 @@ int do_refresh(td_state* s, const std::string& contents) {
     std::vector<AdsrCall> adsrs;
     std::vector<BandCall> bandpasses;
     size_t cs = s->cs, render_sr = s->render_sr, bd = s->bd;
-    std::string output_file = s->output_file, output_vertex = s->output_vertex;
+    // std::mem::take (state.rs:79-80): the locals start from the previous values, the State's own fields are left
+    // EMPTY until the script has run (state.rs:169-170) -- so they stay empty when the script fails
+    std::string output_file = std::move(s->output_file), output_vertex = std::move(s->output_vertex);
+    s->output_file.clear();
+    s->output_vertex.clear();
     std::string& dump = s->dump;
     const long long IMAX = 2147483647LL, IMIN = -2147483648LL, UMAX = 9223372036854775807LL;
 

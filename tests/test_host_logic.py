@@ -145,6 +145,24 @@ def test_refresh_failures_are_reported(api, src, needle):
         s.render("/tmp/never.wav")
 
 
+def test_refresh_takes_output_settings(api):
+    """State::refresh std::mem::take()s output_file / output_vertex into locals before the script runs and stores
+    them back only after it ran (state.rs:79-80, 169-170): a script without set_output keeps the previous vertex,
+    but a script that FAILS leaves both fields empty -- the next script must set them again or fail check_graph."""
+    s = api.State("", 48000, 1024)
+    one = 'set_length(1.0) add_sum("a", 1, 0) declare_stream("f") add_debug_sine("s", 1, 0, "f") connect("s", "a")\n'
+    assert s.refresh(one + 'set_output("a") set_output_file("x.wav")'), api.last_error()
+    assert s.output_file == "x.wav"
+    assert s.refresh(one), api.last_error()            # no set_output: the taken value is put back
+    assert s.output_file == "x.wav"
+    assert not s.refresh("x = = 3")                    # a failing script: taken, never put back
+    assert s.output_file == ""
+    assert not s.refresh(one)                          # ... so the old output vertex is gone too
+    assert "graph check failed" in api.last_error(), api.last_error()
+    assert s.refresh(one + 'set_output("a")'), api.last_error()
+    assert s.output_file == ""
+
+
 def test_reference_example_scripts_parse(api):
     """The reference's own example scripts run through the front-end up to the first missing asset file
     (their /home/cody/... paths do not exist anywhere but the author's machine)."""
