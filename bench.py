@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py -- offline render throughput of the HIP engine on BASELINE config 2.
+"""bench.py -- offline render throughput of the HIP engine on BASELINE config 2 (+ the other configs beside it).
 
-A "step" is one complete fresh render of the project (64 sampleloop vertices -> one normalize,
-60 s @ 48 kHz, bl 1024 = 2,880,512 stereo frames) from sample PCM resident in HBM to the 16-bit PCM
-buffer in HBM: reset normalize vertices, rewind the FlowwBank, compile + launch every vertex kernel.
-At N > 1 every rank renders its own project (seed offset 64 x rank, BASELINE config 5's sharding: no
-data-path collective) and the ranks exchange only the per-project peak table with one RCCL
-all-reduce(max) inside the timed region.
+A "step" is one complete fresh render of every project of this GPU's batch (default: ONE project = BASELINE
+config 2: 64 sampleloop vertices -> one normalize, 60 s @ 48 kHz, bl 1024 = 2,880,512 stereo frames) from sample
+PCM resident in HBM to the 16-bit PCM buffer in HBM: reset normalize vertices, rewind the FlowwBank, compile +
+launch every vertex kernel.  `--projects-per-gpu P` puts P such projects (seeds offset by 64 per project id, BASELINE
+config 5's per-GPU share at P = 64) into the batch; same-kind launches of different projects share one grid.  At
+N > 1 project p of the job lives on rank p mod N (no data-path collective) and the ranks exchange only the
+per-project peak table with ONE RCCL all-reduce(max) inside the timed region.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--projects-per-gpu P]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (by HIP-event time measured
-live on the engine's stream during the timed steps); `kernels` lists every kernel family the same
-way.  `cpu_baseline` times the CPU oracle (oracle/, a C++ restatement of the reference's block-serial
-algorithm -- NOT the Rust reference, which cannot be built here) single-threaded on the same project.
+Prints ONE JSON line on rank 0.  Besides the contract fields:
+  roofline      the dominant kernel (by HIP-event time measured live on the engine's stream during the timed steps)
+                against a ceiling MEASURED in this process on this device (tools/ubench/ceilings.hip)
+  rooflines     the same for every kernel family of the timed region
+  cpu_baseline  the CPU oracle (oracle/, a C++ restatement of the reference's block-serial algorithm -- NOT the
+                Rust reference, which cannot be built here) single-threaded on the same project
+  config5       (default run) 64 projects per GPU through the same batch path, aggregate Msamples/s
+  scanned       (N = 1) the reference's normalize-then-render workflow on the same project
+  configs       (N = 1) BASELINE configs 1, 3, 4: ms per render, dominant kernel, its bound and fraction
 """
 import argparse
+import ctypes
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,10 +39,13 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0      # ... 6.29 TB/s measured float4 copy
+SIMDS = 256 * 4            # CUs x SIMDs
+CLOCK_HZ = 2.4e9           # max clock (guide); a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
 
 SECONDS = 60.0
 N_SRC = 64
 PROF_EVERY = 8
+PROFILE_TAG = "r02"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
 
 
 def algorithmic_bytes_per_frame(k, fused, packed):
@@ -48,6 +59,22 @@ def algorithmic_bytes_per_frame(k, fused, packed):
         "k_sum": per_src * k + 8.0,       # Normalize pass A: k edge (or inlined sample) reads + raw sum write
         "k_scale": 8.0 + 8.0 + 4.0,       # Normalize pass B with fused int16 quantise
     }
+
+
+def ubench():
+    """tools/ubench/libtd_ubench.so (built by __graft_entry__.build(); rebuilt here if missing)."""
+    d = os.path.join(ROOT, "tools", "ubench")
+    so = os.path.join(d, "libtd_ubench.so")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(d, "ceilings.hip")):
+        subprocess.check_call(["make", "-C", d, "-s"])
+    L = ctypes.CDLL(so)
+    L.td_ubench_gather.restype = ctypes.c_float
+    L.td_ubench_gather.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.td_ubench_stream.restype = ctypes.c_float
+    L.td_ubench_stream.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.td_ubench_valu_chain_ns.restype = ctypes.c_float
+    L.td_ubench_valu_chain_ns.argtypes = []
+    return L
 
 
 def cpu_baseline(project, frames, runs=5):
@@ -89,7 +116,6 @@ def cpu_worker(seed_offset, seconds):
 def cpu_all_cores(seconds, workers):
     """Context for config 5: one project per host core, all at once, each through the single-threaded
     oracle in its own process (started before anything here touches the GPU runtime in THAT process)."""
-    import subprocess
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(64 * i), "--seconds", str(seconds)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(workers)]
     rate = 0.0
@@ -117,14 +143,142 @@ def cpu_all_cores(seconds, workers):
                       "per-process rates; slowest render %.3f s" % (done, slowest)}
 
 
+def profiled(name):
+    """A committed rocprofv3 summary of THIS round (profiles/<tag>_<name>.json), or None."""
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))
+    try:
+        return json.load(open(path))
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def build_batch(api, workloads, rank, world, n_per_gpu, seconds, no_fuse, no_pack):
+    """This rank's share of the job: global project ids rank, rank + world, ... (p mod world == rank)."""
+    batch = api.Batch()
+    first = None
+    for i in range(n_per_gpu):
+        pid = rank + i * world
+        p = workloads.config2(seconds=seconds, n_src=N_SRC, seed_offset=64 * pid)
+        sb, fb, g = p.build(api)
+        g.set_option("fuse_sources", 0 if no_fuse else 1)
+        g.set_option("packed_samples", 0 if no_pack else 1)
+        batch.add(sb, fb, g)
+        if first is None:
+            first = p
+        else:
+            p.assets.clear()
+    return batch, first
+
+
+def time_batch(batch, cs, steps, warmup, barrier, exchange):
+    """W untimed + K timed steps bracketed by barriers; the peak exchange sits inside the timed region."""
+    def step():
+        batch.rewind()                       # fresh-after-refresh state (state.rs:467) for every project
+        batch.render_all_async(cs, 16)
+    for _ in range(warmup):
+        step()
+    batch.sync()
+    batch.host_times(reset=True)             # (the first steps allocate edge buffers: not steady-state host work)
+    exchange()                               # warm the exchange path too (lazy initialisation is not render work)
+    barrier()
+    # HIP events around every launch of every PROF_EVERY-th step, on the engine's stream (the events cost a
+    # few microseconds per launch -- a tenth of a single-project step if every render carried them)
+    batch.set_profiling(PROF_EVERY)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    batch.sync()
+    peaks = exchange()                       # the path's only exchange: one all-reduce(max) of the peak table
+    barrier()
+    dt = time.perf_counter() - t0
+    ktimes = batch.kernel_times()
+    batch.set_profiling(0)
+    return dt, ktimes, peaks
+
+
+def other_configs(api, workloads, ub, chain_ns):
+    """BASELINE configs 1, 3, 4 (N = 1): ms per render in a pipelined loop, kernel breakdown, dominant kernel with its
+    bound.  Bounds: config 1 launch latency; k_synth f32 VALU issue (instruction count from the committed PMC pass);
+    k_band_spec the dependent-chain latency of its warm-up walk (ns per dependent VALU measured in this process)."""
+    out = []
+    valu = profiled("valu") or {}
+    for name, mk, reps in (("config1", workloads.config1, 50), ("config3", workloads.config3, 10), ("config4", workloads.config4, 4)):
+        p = mk()
+        sb, fb, g = p.build(api)
+        frames = p.cs * p.bl
+
+        def render():
+            g.reset_normalize_vertices()
+            fb.set_time(0)
+            g.set_time(0)
+            g.render_all_async(sb, fb, p.cs, 16)
+        for _ in range(2):
+            render()
+        g.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            render()
+        g.sync()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        g.set_profiling(1)
+        for _ in range(2):
+            render()
+        g.sync()
+        kt = g.kernel_times()
+        g.set_profiling(0)
+        hosts = g.host_times()
+        kernels = sorted(((k, v[0] / 2.0, v[1] // 2, v[0] / max(v[1], 1)) for k, v in kt.items()), key=lambda r: -r[1])
+        dom = kernels[0]
+        launches = sum(k[2] for k in kernels)
+        entry = {"config": name, "frames": frames, "vertices": sum(len(v) for k, v in p.calls.items() if k.startswith("add_")),
+                 "ms_per_render": round(ms, 4), "Msamples_per_s": round(frames / ms / 1e3, 1), "launches_per_render": int(launches),
+                 "kernel_ms_per_render": round(sum(k[1] for k in kernels), 4),
+                 "host_ms_per_render": {k: round(v / max(hosts["chunks"], 1), 4) for k, v in hosts.items() if k != "chunks"},
+                 "kernels": [{"kernel": k[0], "ms_per_render": round(k[1], 4), "launches": int(k[2]), "avg_ms": round(k[3], 5)} for k in kernels],
+                 "dominant": dom[0]}
+        if name == "config1":
+            floor = launches * 1.45e-3    # MI355X_MICROARCH.md price list, row "boundary": dependent kernel boundary 1.45 us
+            entry["bound"] = {"kind": "launch latency", "floor_ms": round(floor, 5), "frac": round(floor / ms, 4),
+                              "note": "%d dependent launches x 1.45 us (guide: same-stream kernel boundary); the kernels themselves move "
+                                      "%.1f MB" % (launches, frames * (2 * 4 + 8 + 20) / 1e6)}
+        elif dom[0] == "k_synth":
+            insts = (valu.get("config3", {}).get("k_synth") or {}).get("SQ_INSTS_VALU")
+            if insts:
+                floor = insts * 2.0 / (SIMDS * CLOCK_HZ) * 1e3   # wave64 on a SIMD-32: 2 cycles of issue per instruction
+                entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4),
+                                  "SQ_INSTS_VALU_profiled": insts, "profile": "profiles/%s_valu.json" % PROFILE_TAG,
+                                  "note": "wave-level VALU instructions (PMC, committed profile) x 2 cycles / (1024 SIMDs x 2.4 GHz); "
+                                          "transcendental and f32-division sequences issue slower than 2 cycles, so the true floor is higher"}
+            else:
+                entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": None, "frac": None, "note": "no committed PMC pass for this round"}
+        elif dom[0] == "k_band_spec" and chain_ns and chain_ns > 0:
+            st = g.band_stats()
+            gmin = 1.0 - float(np.exp(np.float32(-2.0 * np.pi * 20.0 / 48000.0)))
+            ws = (int(40.0 / gmin + 64.0) + 31) // 32 * 32
+            ws = (ws + 255) // 256 * 256
+            steps = ws + 256
+            floor = steps * 3 * chain_ns * 1e-6
+            entry["bound"] = {"kind": "dependent-chain latency", "floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4),
+                              "steps_per_launch": steps, "ns_per_dependent_valu_measured": round(chain_ns, 3),
+                              "band_stats_last_render": st,
+                              "note": "short warm-up (40/gamma, 20 Hz stage) + one 256-frame segment, 3 dependent VALU per step, one wave "
+                                      "alone on its SIMD (tools/ubench/ceilings.hip td_ubench_valu_chain_ns)"}
+        out.append(entry)
+        del sb, fb, g
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--projects-per-gpu", type=int, default=1, help="projects in this GPU's batch (config 5: 64)")
     ap.add_argument("--seconds", type=float, default=SECONDS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no config5 / scanned / configs / ceilings of other kernels")
     ap.add_argument("--no-fuse", action="store_true", help="edge-buffer model: one HBM buffer per source vertex (no source inlining)")
     ap.add_argument("--no-pack", action="store_true", help="inlined sources gather the f32 sample form (8 B/frame) instead of the packed 16-bit one")
     args = ap.parse_args()
@@ -139,9 +293,9 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
 
-    import torch
+    import torch   # (before the engine: both then share ONE HIP runtime in this process)
     import torch.distributed as dist
-    from termdaw_amd import api, batch, workloads
+    from termdaw_amd import api, workloads
 
     if api.device_count() < 1 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP render path has no CPU fallback")
@@ -150,67 +304,91 @@ def main():
     torch.cuda.set_device(local_rank)
     api.set_device(local_rank)
     use_dist = world > 1 or os.environ.get("TD_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank RCCL self-test
+    backend = os.environ.get("TD_BENCH_BACKEND", "nccl")   # "gloo" only for the 1-GPU self-test above
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("TD_BENCH_BACKEND", "nccl")   # "gloo" only for the 1-GPU self-test above
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    # ---- build this rank's project: config 2 with seed offset 64 * rank (config 5 sharding) ----
-    project = workloads.config2(seconds=args.seconds, n_src=N_SRC, seed_offset=64 * rank)
-    sb, fb, g = project.build(api)
-    cs, bl = project.cs, project.bl
-    g.set_option("fuse_sources", 0 if args.no_fuse else 1)
-    g.set_option("packed_samples", 0 if args.no_pack else 1)
-    frames = cs * bl
-
-    def step():
-        g.reset_normalize_vertices()   # fresh-after-refresh state (state.rs:467)
-        fb.set_time(0)
-        g.render_all_async(sb, fb, cs, 16)
-
     def barrier():
-        g.sync()
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
-        step()
-    g.sync()
-    # warm the exchange path too (first CUDA tensor / first collective initialise lazily: not render work)
-    coll_dev = "cuda" if os.environ.get("TD_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
-    peak_buf = torch.empty(world, dtype=torch.float32, device=coll_dev) if use_dist else None
-    batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, coll_dev, peak_buf)
-    barrier()
-    # HIP events around every launch of every PROF_EVERY-th render, on the engine's stream (the events cost a
-    # few microseconds per launch -- a tenth of this step if every render carried them)
-    g.set_profiling(PROF_EVERY)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    g.sync()
-    # the path's only exchange: per-project (pre-normalisation) peak table, one all-reduce(max) over RCCL
-    peaks = batch.exchange_peaks({rank: g.get_normalization_value("sum")}, world, dist if use_dist else None, coll_dev, peak_buf)
-    barrier()
-    dt = time.perf_counter() - t0
-    ktimes = g.kernel_times()
-    g.set_profiling(False)
+    def make_exchange(batch, n_per_gpu):
+        """Per-project peak table of the whole job (n_per_gpu x world floats): this rank's entries are written on the
+        device by the engine (zeros elsewhere), then ONE all-reduce(max) -- RCCL on device memory, no host round trip."""
+        n_total = n_per_gpu * world
+        table = torch.zeros(n_total, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        def exchange():
+            batch.peak_table_device(table.data_ptr(), n_total, first=rank, stride=world)
+            batch.sync()
+            if use_dist:
+                if backend == "nccl":
+                    dist.all_reduce(table, op=dist.ReduceOp.MAX)
+                else:
+                    t = table.cpu()
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    return t.numpy()
+            return table.cpu().numpy()
+        return exchange
 
-    # the >= 40 % target is against a device-copy rate measured on this box, not the guide's number
-    copy_gbs = HBM_COPY_GBS
+    def reduce_max(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- the timed region: this rank's batch of config-2 projects ----
+    P = max(1, args.projects_per_gpu)
+    batch, project = build_batch(api, workloads, rank, world, P, args.seconds, args.no_fuse, args.no_pack)
+    cs, bl = project.cs, project.bl
+    frames = cs * bl
+    dt, ktimes, peaks = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
+    dt = reduce_max(dt)
+    device_bytes = sum(g.device_bytes() for _, _, g in batch.projects)
+    host = batch.host_times()
+
+    # ---- config 5 proper beside it: 64 projects per GPU through the same path (skipped when the main region already is that) ----
+    c5 = None
+    if not args.no_extras and P != 64 and not args.no_fuse and not args.no_pack:
+        c5_steps = max(2, min(10, args.steps))
+        b64, _ = build_batch(api, workloads, rank, world, 64, args.seconds, False, False)
+        dt5, kt5, pk5 = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
+        dt5 = reduce_max(dt5)
+        c5 = {"projects_per_gpu": 64, "projects": 64 * world, "steps": c5_steps, "ms_per_step": round(dt5 / c5_steps * 1e3, 4),
+              "ms_per_project": round(dt5 / c5_steps / 64 * 1e3, 5),
+              "value": round(frames * 64 * world * c5_steps / dt5 / 1e6, 2), "unit": "Msamples/s",
+              "kernels": {k: round(v[0] / max(v[1], 1), 5) for k, v in kt5.items()},
+              "host_ms_per_step": {k: round(v / max(b64.host_times(reset=False)["steps"], 1), 4) for k, v in b64.host_times(reset=False).items() if k != "steps"},
+              "peak_table_entries": int(len(pk5)), "peak_table_min_max": [round(float(np.min(pk5)), 6), round(float(np.max(pk5)), 6)],
+              "note": "BASELINE config 5's per-GPU share: 64 independent config-2 projects (seed offset 64 x project id) resident per GPU, "
+                      "one batch submission per step (launches of the 64 projects merged into one grid per kernel family), ONE "
+                      "all-reduce(max) of the %d-entry peak table in the timed region" % (64 * world)}
+        del b64
+
+    result_line = None
     if rank == 0:
+        total_frames = frames * P * args.steps * world
+        value = total_frames / dt / 1e6
+        fused, packed = not args.no_fuse, not args.no_pack
+        abf = algorithmic_bytes_per_frame(N_SRC, fused, packed)
+        survey_abf = algorithmic_bytes_per_frame(N_SRC, False, False)   # SURVEY 8(d) edge-buffer figure
+        ub = None
         try:
-            n = 256 << 20   # 1 GiB of float32 each way
+            ub = ubench()
+        except Exception as e:   # noqa: BLE001
+            sys.stderr.write("bench.py: no ubench library (%s): ceilings omitted\n" % e)
+
+        # SURVEY 8(d): the HBM denominator measured on this box (1 GiB each way: beyond the Infinity Cache)
+        copy_gbs = HBM_COPY_GBS
+        try:
+            n = 256 << 20
             src = torch.empty(n, dtype=torch.float32, device="cuda").normal_()
             dst = torch.empty_like(src)
             for _ in range(3):
@@ -225,28 +403,85 @@ def main():
             del src, dst
         except Exception:   # noqa: BLE001
             copy_gbs = HBM_COPY_GBS
-    if rank == 0:
-        total_frames = frames * args.steps * world
-        value = total_frames / dt / 1e6
-        fused, packed = not args.no_fuse, not args.no_pack
-        abf = algorithmic_bytes_per_frame(N_SRC, fused, packed)
-        survey_abf = algorithmic_bytes_per_frame(N_SRC, False, False)   # SURVEY 8(d) edge-buffer figure
+
+        # ---- measured ceilings for the kernels of the timed region ----
+        lens = np.array([project.assets["s%02d" % k].pcm.shape[0] for k in range(N_SRC)], dtype=np.uint32)
+        nq = 4 if frames >= 2600 * 1024 else (2 if frames >= 1800 * 1024 else 1)
+        gather_ms = gather_l2_ms = stream_ms = None
+        if ub is not None and fused and packed:
+            lp = lens.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+            gather_ms = float(ub.td_ubench_gather(lp, N_SRC, frames, nq, 20, P))
+            small = np.full(N_SRC, 1021, dtype=np.uint32)     # 64 x 4 KB: resident in every XCD's L2 (and mostly in L1)
+            gather_l2_ms = float(ub.td_ubench_gather(small.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), N_SRC, frames, nq, 20, P))
+        if ub is not None:
+            stream_ms = float(ub.td_ubench_stream(frames, 1, 1, 20))
+        tp = profiled("pmc_summary") or {}
+        mode_key = "nofuse" if args.no_fuse else ("fused_f32" if args.no_pack else "fused")
+
         kernels = []
         for name, (ms, launches) in sorted(ktimes.items(), key=lambda kv: -kv[1][0]):
-            avg_ms = ms / max(launches, 1)
-            bytes_per_launch = abf.get(name, 0.0) * frames
+            avg_ms = ms / max(launches, 1)                    # one launch covers the P projects of the batch
+            bytes_per_launch = abf.get(name, 0.0) * frames * P
             gbs = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-            kernels.append({"kernel": name, "avg_ms": round(avg_ms, 5), "launches": int(launches),
-                            "algorithmic_bytes_per_launch": int(bytes_per_launch), "achieved_GBs": round(gbs, 1),
-                            "frac_of_8TBs": round(gbs / HBM_PEAK_GBS, 4), "frac_of_measured_copy": round(gbs / copy_gbs, 4)})
+            prof = (tp.get(mode_key) or {}).get(name) or {}
+            row = {"kernel": name, "avg_ms": round(avg_ms, 5), "launches": int(launches), "projects_per_launch": P,
+                   "algorithmic_bytes_per_launch": int(bytes_per_launch), "achieved": round(gbs, 1), "unit": "GB/s",
+                   "traffic": None,
+                   "traffic_profiled": None if "hbm_side_bytes_per_launch" not in prof else {
+                       "bytes_per_launch": prof["hbm_side_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate"),
+                       "profile": "profiles/%s_pmc_summary.json" % PROFILE_TAG,
+                       "note": "separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 per the gfx950 half-count rule + "
+                               "WRITE_SIZE); fabric-side bytes: Infinity-Cache hits are included, so HBM bytes are at most this"}}
+            if name == "k_sum" and fused and packed and gather_ms and gather_ms > 0:
+                ceil_gbs = bytes_per_launch / (gather_ms * 1e-3) / 1e9
+                compulsory = (int(lens.sum()) * 4 + 8 * frames) * P
+                row.update({"bound": "cache-gather ceiling (measured)", "peak": round(ceil_gbs, 1), "frac": round(gbs / ceil_gbs, 4),
+                            "ceiling_ms": round(gather_ms, 5),
+                            "ceiling_l2_resident_GBs": None if not gather_l2_ms else round(bytes_per_launch / (gather_l2_ms * 1e-3) / 1e9, 1),
+                            "frac_of_l2_resident_ceiling": None if not gather_l2_ms else round(gather_l2_ms / avg_ms, 4),
+                            "hbm_compulsory_bytes": compulsory,
+                            "hbm_compulsory_frac": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            "bytes_per_frame": abf[name],
+                            "note": "source inlining: k_sum's algorithmic bytes are its own gathers, (4k+8) B/frame -- k looping samples "
+                                    "read in place in their packed 16-bit form + one raw-sum write.  The gathers re-read a %.0f MB "
+                                    "sample set ~37x per launch, so they are cache hits, not HBM traffic: `peak` is the rate at which "
+                                    "tools/ubench/ceilings.hip performs the SAME gathers and the same 8 B/frame write with the arithmetic "
+                                    "removed (best of three issue depths, same lengths, same grid, this process, this device); "
+                                    "`hbm_compulsory_frac` prices the bytes that must cross HBM once (packed samples + sum write) "
+                                    "against 8 TB/s" % (lens.sum() * 4 / 1e6)})
+            else:
+                row.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "frac_of_measured_copy": round(gbs / copy_gbs, 4), "bytes_per_frame": abf.get(name)})
+                if name == "k_scale" and stream_ms and stream_ms > 0:
+                    row["stream_ceiling_ms"] = round(stream_ms, 5)
+                    row["note"] = ("Normalize pass B: 8 B read + 8 B write + 4 B PCM per frame; stream_ceiling_ms = a bare 8 B in / 8 B out "
+                                   "float4 stream over the same %d frames (tools/ubench/ceilings.hip), i.e. launch ramp + tail included" % frames)
+            kernels.append(row)
         dom = kernels[0] if kernels else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if dom and os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("nofuse" if args.no_fuse else ("fused_f32" if args.no_pack else "fused"), {}).get(dom["kernel"])
-            except Exception:
-                traffic = None
+        rocprof_kernel = None
+        if dom:
+            if dom["kernel"] == "k_sum":
+                rocprof_kernel = (("tdk::k_sum16w<4, true>" if nq == 4 else "tdk::k_sum16w<2, true>" if nq == 2 else "tdk::k_sum<3>") if packed
+                                  else ("tdk::k_sum16w<2, false>" if frames >= 1800 * 1024 else "tdk::k_sum<2>")) if fused else "tdk::k_sum<1>"
+            else:
+                rocprof_kernel = "tdk::" + dom["kernel"]
+        roofline = None
+        if dom:
+            roofline = {k: dom.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_profiled",
+                                                 "bytes_per_frame", "ceiling_ms", "ceiling_l2_resident_GBs", "frac_of_l2_resident_ceiling",
+                                                 "hbm_compulsory_bytes", "hbm_compulsory_frac", "frac_of_measured_copy", "note") if k in dom}
+            roofline["avg_ms"] = dom["avg_ms"]
+            roofline["rocprof_kernel"] = rocprof_kernel   # the engine times launch FAMILIES; this instantiation is the rocprofv3 name
+            roofline["measured_copy_GBs"] = round(copy_gbs, 1)
+            vp = ((profiled("valu") or {}).get("config2") or {}).get(dom["kernel"])
+            if vp:
+                roofline["valu_profiled"] = dict(vp, profile="profiles/%s_valu.json" % PROFILE_TAG)
+            if fused and dom["kernel"] == "k_sum":
+                roofline["survey_model"] = {
+                    "bytes_per_frame": survey_abf["k_sum"],
+                    "note": "SURVEY 8(d)'s edge-buffer figure (8k+8) for the same launch time -- not a bandwidth: the k source edge "
+                            "buffers do not exist in this mode (--no-fuse runs that model, where the kernel is HBM-bound)",
+                    "equivalent_GBs": round(survey_abf["k_sum"] * frames * P / (dom["avg_ms"] * 1e-3) / 1e9, 1)}
         out = {
             "metric": "offline render Msamples/sec (stereo 48 kHz) + % HBM roofline, 64-vertex graph",
             "value": round(value, 2),
@@ -260,77 +495,78 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: 64 sampleloop -> 1 normalize, %g s @48 kHz, bl 1024, 16-bit PCM out "
-                                   "(one project per GPU, seed offset 64*rank)" % args.seconds,
-                       "frames_per_step_per_gpu": frames, "vertices": N_SRC + 1,
+            "config": {"workload": "BASELINE config 2: 64 sampleloop -> 1 normalize, %g s @48 kHz, bl 1024, 16-bit PCM out; %d project(s) "
+                                   "per GPU per step (project p of the job on rank p mod N, seed offset 64*p)" % (args.seconds, P),
+                       "frames_per_project": frames, "projects_per_gpu": P, "vertices_per_project": N_SRC + 1,
                        "source_inlining": not args.no_fuse, "packed_samples": (not args.no_fuse) and (not args.no_pack),
-                       "parallelism": "projects sharded 1 per GPU; RCCL all-reduce(max) of the peak table only"},
-            "roofline": None if not dom else {
-                "bound": "hbm", "kernel": dom["kernel"], "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": dom["frac_of_8TBs"], "measured_copy_GBs": round(copy_gbs, 1),
-                "frac_of_measured_copy": dom["frac_of_measured_copy"], "traffic": traffic,
-                "bytes_per_frame": abf.get(dom["kernel"]),
-                # the engine times launch FAMILIES; which instantiation ran (= the name in the rocprofv3 summary):
-                "rocprof_kernel": (("tdk::k_sum16w<4, true>" if frames >= 2600 * 1024 else "tdk::k_sum16w<2, true>" if frames >= 1800 * 1024
-                                    else "tdk::k_sum<3>") if packed else
-                                   ("tdk::k_sum16w<2, false>" if frames >= 1800 * 1024 else "tdk::k_sum<2>")) if fused and dom["kernel"] == "k_sum"
-                                  else ("tdk::k_sum<1>" if dom["kernel"] == "k_sum" else "tdk::" + dom["kernel"]),
-                "note": ("edge-buffer model (SURVEY 8d): every algorithmic byte is an HBM byte (PMC traffic == algorithmic "
-                         "bytes)") if not fused else
-                        ("source inlining: k_sum's algorithmic bytes are its own gathers, (%dk+8) B/frame -- k looping "
-                         "samples read in place (%s) + one raw-sum write; the k source edge buffers of SURVEY 8(d)'s "
-                         "(8k+8) model never exist.  The gathers re-read the %s sample set ~37x per launch, so they are "
-                         "served by L2 (hit rate 25-76%%) and the 256 MB Infinity Cache, not HBM -- which is why `frac` can "
-                         "exceed 1 (`traffic` = PMC L2-miss-side bytes per launch, profiles/traffic.json; `beyond_l2` "
-                         "prices those against the 8 TB/s peak): the bound that applies is the cache hierarchy's gather "
-                         "rate (MI355X_MICROARCH.md: 8.6 TB/s for a 38 MB table from the Infinity Cache), "
-                         "frac_of_mall_gather below; "
-                         "`survey_model` restates the same launch time against SURVEY's (8k+8) figure; --no-fuse runs "
-                         "the edge-buffer model itself" % ((4, "packed 16-bit, 4 B", "20 MB") if packed else (8, "f32, 8 B", "40 MB"))),
-                "frac_of_mall_gather_8.6TBs": None if not fused else round(dom["achieved_GBs"] / 8600.0, 4),
-                # what actually crosses the L2 -> fabric boundary (Infinity Cache + HBM), from the PMC pass
-                "beyond_l2": None if not traffic else {
-                    "bytes_per_launch": traffic,
-                    "GBs": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9, 1),
-                    "frac_of_8TBs": round(traffic / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                "survey_model": None if not fused else {
-                    "bytes_per_frame": survey_abf[dom["kernel"]] if dom["kernel"] in survey_abf else None,
-                    "achieved": round(survey_abf.get(dom["kernel"], 0.0) * frames / (dom["avg_ms"] * 1e-3) / 1e9, 1),
-                    "frac": round(survey_abf.get(dom["kernel"], 0.0) * frames / (dom["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}},
-            "kernels": kernels,
+                       "parallelism": "projects sharded across GPUs; RCCL all-reduce(max) of the %d-entry peak table only" % (P * world)},
+            "roofline": roofline,
+            "rooflines": kernels,
             "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % PROF_EVERY,
-            "peak_table": [round(float(x), 6) for x in peaks],
-            "device_bytes": g.device_bytes(),
+            "host_ms_per_step": {k: round(v / max(host["steps"], 1), 5) for k, v in host.items() if k != "steps"},
+            "peak_table": [round(float(x), 6) for x in peaks[:16]],
+            "peak_table_entries": int(len(peaks)),
+            "device_bytes": int(device_bytes),
             # vertex-frames/s = frames x vertices reached from the output
             "vertex_frames_per_s": round(value * 1e6 * (N_SRC + 1), 0),
         }
-        if world == 1:
+        if c5:
+            out["config5"] = c5
+        if world == 1 and not args.no_extras:
+            sb0, fb0, g0 = batch.projects[0]
+            # the reference's recommended workflow: `normalize` (scan_exact, state.rs:473) then `render`; the scan is paid
+            # once per project edit, the render each time -- both are reported
+            ts, tsc = [], []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                g0.true_normalize_scan(sb0, fb0, cs)
+                tsc.append(time.perf_counter() - t0)
+            g0.set_profiling(1)
+            g0.sync()
+            t0 = time.perf_counter()
+            reps = max(10, min(100, args.steps))
+            for _ in range(reps):
+                fb0.set_time(0)
+                g0.render_all_async(sb0, fb0, cs, 16)
+            g0.sync()
+            ts = (time.perf_counter() - t0) / reps
+            kts = g0.kernel_times()
+            g0.set_profiling(0)
+            out["scanned"] = {"ms_per_render": round(ts * 1e3, 4), "Msamples_per_s": round(frames / ts / 1e6, 1),
+                              "scan_ms": round(sorted(tsc)[1] * 1e3, 4),
+                              "kernels": {k: round(v[0] / max(v[1], 1), 5) for k, v in kts.items()},
+                              "note": "render after true_normalize_scan (graph.rs:222-237): the peak is known, every block is scaled by the "
+                                      "same 1/max (timed with a HIP-event pair around every launch, i.e. slightly pessimistic)"}
             # outside the timed region, for reference only (never `value`): one render plus the copy of its
             # 16-bit PCM to host memory (pageable numpy array), median of 5
             ts = []
             for _ in range(5):
                 step_t0 = time.perf_counter()
-                g.reset_normalize_vertices()
-                fb.set_time(0)
-                g.render_all(sb, fb, cs, 16, want_f32=False, want_pcm=True)
+                g0.reset_normalize_vertices()
+                fb0.set_time(0)
+                g0.render_all(sb0, fb0, cs, 16, want_f32=False, want_pcm=True)
                 ts.append(time.perf_counter() - step_t0)
             ts.sort()
             out["pcie_inclusive"] = {"ms_per_render": round(ts[2] * 1e3, 4), "Msamples_per_s": round(frames / ts[2] / 1e6, 1),
                                      "note": "render + D2H of the PCM into pageable host memory; not part of `value`"}
+            chain_ns = float(ub.td_ubench_valu_chain_ns()) if ub is not None else None
+            try:
+                out["configs"] = other_configs(api, workloads, ub, chain_ns)
+            except Exception as e:   # noqa: BLE001
+                out["configs"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(project, frames)
             out["gpu_over_cpu_1thread"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
-            try:
-                ncores = len(os.sched_getaffinity(0))
-            except AttributeError:
-                ncores = os.cpu_count() or 1
-            allc = cpu_all_cores(args.seconds, min(ncores, 256))
-            if allc:
-                out["cpu_baseline_all_cores"] = allc
-                out["gpu_over_cpu_all_cores"] = round(out["value"] / allc["value"], 1)
+            if not args.no_extras:
+                try:
+                    ncores = len(os.sched_getaffinity(0))
+                except AttributeError:
+                    ncores = os.cpu_count() or 1
+                allc = cpu_all_cores(args.seconds, min(ncores, 256))
+                if allc:
+                    out["cpu_baseline_all_cores"] = allc
+                    out["gpu_over_cpu_all_cores"] = round(out["value"] / allc["value"], 1)
         result_line = json.dumps(out)
-    else:
-        result_line = None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -338,7 +574,6 @@ def main():
         # RCCL writes its version banner to the C stdout buffer; flush that first so the JSON line is the
         # last (and only JSON) line on stdout
         try:
-            import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:   # noqa: BLE001
             pass

@@ -99,24 +99,87 @@ int resample_device(const float2* in, size_t len, size_t from, size_t to, float2
     float* d_T = nullptr;
     float2* d_out = nullptr;
     TD_HIP(hipMalloc(&d_T, T.size() * sizeof(float)));
-    TD_HIP(hipMalloc(&d_out, (nout + (nout & 1) + 17) * sizeof(float2)));
-    TD_HIP(hipMemcpyAsync(d_T, T.data(), T.size() * sizeof(float), hipMemcpyHostToDevice, st));
-    TD_HIP(hipMemsetAsync(d_out + nout - (nout ? 1 : 0), 0, 18 * sizeof(float2), st));
+    if (hipMalloc(&d_out, (nout + (nout & 1) + 17) * sizeof(float2)) != hipSuccess) {
+        (void)hipFree(d_T);
+        return fail("termdaw_amd: out of device memory for the resampled sample");
+    }
+    auto bail = [&](hipError_t e, const char* what) {
+        (void)hipFree(d_T);
+        (void)hipFree(d_out);
+        return fail(std::string("HIP error: ") + hipGetErrorString(e) + " at " + what);
+    };
+    hipError_t he;
+    if ((he = hipMemcpyAsync(d_T, T.data(), T.size() * sizeof(float), hipMemcpyHostToDevice, st)) != hipSuccess) return bail(he, "table upload");
+    // the pad behind the last frame (odd tail + wrap frames) starts out as zeros
+    if ((he = hipMemsetAsync(d_out + nout, 0, ((nout & 1) + 17) * sizeof(float2), st)) != hipSuccess) return bail(he, "pad memset");
+    if (nout == 0) {
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(d_T);
+        *out = d_out;
+        *nout_p = 0;
+        return 1;
+    }
     ResampleDesc d{in, d_out, d_T, len, nout, from, to};
     launch_resample(d, st);
     // frames nout .. nout + 14 = the first frames again (wrap frames, as in every bank entry)
     for (size_t i = 0; nout && i < 15;) {
         const size_t src = i % nout, cnt = std::min<size_t>(15 - i, nout - src);
-        TD_HIP(hipMemcpyAsync(d_out + nout + i, d_out + src, cnt * sizeof(float2), hipMemcpyDeviceToDevice, st));
+        if ((he = hipMemcpyAsync(d_out + nout + i, d_out + src, cnt * sizeof(float2), hipMemcpyDeviceToDevice, st)) != hipSuccess)
+            return bail(he, "wrap frames");
         i += cnt;
     }
-    TD_HIP(hipStreamSynchronize(st));
-    TD_HIP(hipGetLastError());
+    if ((he = hipStreamSynchronize(st)) != hipSuccess) return bail(he, "resample");
+    if ((he = hipGetLastError()) != hipSuccess) return bail(he, "resample launch");
     (void)hipFree(d_T);
     *out = d_out;
     *nout_p = nout;
     return 1;
 }
+
+}  // namespace tde
+
+void* td_samplebank::alloc(int pool, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    auto& v = slabs[pool];
+    if (v.empty() || v.back().cap - v.back().used < bytes) {
+        Slab s;
+        s.cap = std::max<size_t>(bytes, (size_t)16 << 20);
+        if (hipMalloc(&s.base, s.cap) != hipSuccess) {
+            tde::fail("termdaw_amd: out of device memory for the sample bank");
+            return nullptr;
+        }
+        v.push_back(s);
+    }
+    Slab& s = v.back();
+    void* p = s.base + s.used;
+    s.used += bytes;
+    s.live += 1;
+    return p;
+}
+void td_samplebank::release(void* p) {
+    if (!p) return;
+    for (auto& v : slabs)
+        for (size_t i = 0; i < v.size(); ++i) {
+            Slab& s = v[i];
+            if ((unsigned char*)p >= s.base && (unsigned char*)p < s.base + s.cap) {
+                if (s.live) --s.live;
+                if (s.live == 0) {               // nothing left in it: reuse from the start, or give it back
+                    if (i + 1 == v.size()) s.used = 0;
+                    else { (void)hipFree(s.base); v.erase(v.begin() + (long)i); }
+                }
+                return;
+            }
+        }
+    (void)hipFree(p);   // a stand-alone allocation (resampled entries)
+}
+void td_samplebank::release_all() {
+    for (auto& v : slabs) {
+        for (auto& s : v) (void)hipFree(s.base);
+        v.clear();
+    }
+}
+
+namespace tde {
 
 // SampleBank::add after the WAV header is known (sample.rs:240-313).  The host only takes the decisions
 // that depend on counts (channel / length checks, Sample::from's Err arms); decode, de-interleave, load
@@ -241,14 +304,21 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     SampleEntry e;
     e.len = n;
     // n frames, then the first 15 again (wrap frames for looping readers), padded to an even count
-    TD_HIP(hipMalloc(&e.d, (n + 16 + (n & 1)) * sizeof(float2)));
+    // (every failure return below hands the entry's memory back to the bank)
+    e.d = static_cast<float2*>(sb->alloc(0, (n + 16 + (n & 1)) * sizeof(float2)));
+    if (!e.d) return 0;
+    struct Guard {
+        td_samplebank* sb; SampleEntry* e; bool armed = true;
+        ~Guard() { if (armed) { sb->release(e->d); sb->release(e->d16); } }
+    } guard{sb, &e};
     TD_HIP(hipMemsetAsync(e.d + n, 0, (16 + (n & 1)) * sizeof(float2), st));
     launch_sample_pack(d_l, d_r, p_max_l, p_max_r, e.d, (uint32_t)n, st);
     // packed 16-bit twin: only when l / r are still the raw integer PCM values times one scale per channel
     // (every mode but mix-down) and no resample follows
     bool want16 = method != LM_MIX && sr == sb->sample_rate && n >= 1 && n < 0x3FFFFFF0u;
     if (want16) {
-        TD_HIP(hipMalloc(&e.d16, ((n + 18) & ~(size_t)3) * sizeof(uint32_t)));   // the loop + its first 15 frames again
+        e.d16 = static_cast<uint32_t*>(sb->alloc(1, ((n + 18) & ~(size_t)3) * sizeof(uint32_t)));   // the loop + its first 15 frames again
+        if (!e.d16) return 0;
         TD_HIP(hipMemsetAsync(d_s + 8, 0, sizeof(uint32_t), st));
         launch_sample_pack16(d_l, d_r, e.d16, (uint32_t)n, reinterpret_cast<uint32_t*>(d_s + 8), st);
     }
@@ -261,7 +331,7 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
         memcpy(&bad, &host_s[8], 4);
         const float ml = host_s[p_max_l - d_s], mr = host_s[p_max_r - d_s];
         if (bad) {
-            (void)hipFree(e.d16);
+            sb->release(e.d16);
             e.d16 = nullptr;
         } else {
             e.scale_l = 1.0f / ml;   // the same `1.0 / max` k_sample_pack multiplied by
@@ -272,12 +342,13 @@ static int bank_add_stream(td_samplebank* sb, const std::string& name, const flo
     if (sr != sb->sample_rate) {   // sample.rs:305-310: Sample::resample after the normalisation
         float2* rs = nullptr;
         size_t nout = 0;
-        if (!resample_device(e.d, e.len, sr, sb->sample_rate, &rs, &nout, st)) { (void)hipFree(e.d); return 0; }
-        (void)hipFree(e.d);
-        if (nout == 0) { (void)hipFree(rs); return fail("termdaw_amd: resampled sample is empty"); }
-        e.d = rs;
+        if (!resample_device(e.d, e.len, sr, sb->sample_rate, &rs, &nout, st)) return 0;
+        sb->release(e.d);
+        e.d = rs;   // (a stand-alone allocation: release() tells it from slab memory)
+        if (nout == 0) return fail("termdaw_amd: resampled sample is empty");
         e.len = nout;
     }
+    guard.armed = false;
     sb->samples.push_back(e);
     sb->names[name] = sb->samples.size() - 1;
     return 1;
@@ -1741,9 +1812,11 @@ td_samplebank* td_samplebank_new(size_t sample_rate) {
 }
 void td_samplebank_free(td_samplebank* sb) {
     if (!sb) return;
-    if (!sb->samples.empty() && hipSetDevice(sb->device) == hipSuccess)
-        for (auto& e : sb->samples) { (void)hipFree(e.d); if (e.d16) (void)hipFree(e.d16); }
-    if (sb->tmp && hipSetDevice(sb->device) == hipSuccess) (void)hipFree(sb->tmp);
+    if (hipSetDevice(sb->device) == hipSuccess) {
+        for (auto& e : sb->samples) { sb->release(e.d); sb->release(e.d16); }
+        sb->release_all();
+        if (sb->tmp) (void)hipFree(sb->tmp);
+    }
     delete sb;
 }
 int td_samplebank_add_decoded(td_samplebank* sb, const char* name, const float* linear, size_t n, int channels,

@@ -49,6 +49,14 @@ struct td_samplebank {
     // hipFree pair per temporary and sample was most of what loading a project cost
     unsigned char* tmp = nullptr;
     size_t tmp_cap = 0;
+    // Sample storage comes out of a few large slabs instead of one hipMalloc per sample: the tables a sum kernel
+    // gathers from then sit in one or two big allocations (2 MB page fragments, a handful of TLB entries for a whole
+    // project) instead of dozens of small ones.  Pool 0: f32 entries, pool 1: packed 16-bit entries.
+    struct Slab { unsigned char* base = nullptr; size_t cap = 0, used = 0, live = 0; };
+    std::vector<Slab> slabs[2];
+    void* alloc(int pool, size_t bytes);     // nullptr on failure (g_error set)
+    void release(void* p);                   // slab memory or a stand-alone hipMalloc
+    void release_all();
 };
 
 struct td_flowwbank {

@@ -146,8 +146,8 @@ void bank_remove(td_samplebank* sb, const std::string& name) {   // mark_dead + 
     if (it == sb->names.end()) return;
     const size_t idx = it->second;
     if (hipSetDevice(sb->device) == hipSuccess) {
-        (void)hipFree(sb->samples[idx].d);
-        if (sb->samples[idx].d16) (void)hipFree(sb->samples[idx].d16);
+        sb->release(sb->samples[idx].d);
+        sb->release(sb->samples[idx].d16);
     }
     sb->samples.erase(sb->samples.begin() + (long)idx);
     sb->names.erase(it);
