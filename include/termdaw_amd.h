@@ -177,6 +177,10 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
  * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed
  * only, the bit-wise check and repair keep every result exact);
+ * "spec_normalize" 0|1 (default 1: a render after td_graph_normalize_scan normalises in ONE pass, speculating that
+ * no block exceeds the scanned peak; a check kernel redoes the vertex the two-pass way when one does -- same values);
+ * "output_f32" 0|1 (default 1; 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames --
+ * td_graph_read_f32 then fails, the PCM is unchanged);
  * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
  * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */
 int td_graph_set_option(td_graph* g, const char* key, long value);

@@ -852,9 +852,9 @@ static void free_arena(Arena& ar) {
     ar = Arena{};
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
-                                           "k_synth",       "k_sampsyn", "k_sum",          "k_scale",
+                                           "k_synth",       "k_sampsyn", "k_sum",          "k_scale",       "k_norm_fix",
                                            "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_quantise"};
 
 static hipEvent_t get_event(ProfCtx& pc) {
@@ -1049,7 +1049,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 case K_SYNTH: fam_v[F_SYNTH].push_back(vi); break;
                 case K_SAMPSYN: fam_v[F_SAMPSYN].push_back(vi); break;
                 case K_SUM: fam_v[F_SUM].push_back(vi); break;
-                case K_NORMALIZE: fam_v[F_SUM].push_back(vi); fam_v[F_SCALE].push_back(vi); break;
+                case K_NORMALIZE:
+                    fam_v[F_SUM].push_back(vi);
+                    // after a normalize scan the peak is known: one pass + a (normally empty) fix launch instead of two
+                    fam_v[(g->spec_normalize && !is_scan && v.peak_known && !v.has_init_override) ? F_NORMFIX : F_SCALE].push_back(vi);
+                    break;
                 case K_ADSR: fam_v[(v.wet < 0.0001f) ? F_SUM : F_ADSR].push_back(vi); break;
                 case K_BAND_PASS:
                     if (v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) {
@@ -1118,6 +1122,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             ins_off[vi] = st.put(ins);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
+        std::map<size_t, SumDesc> sum_desc_of;                      // Normalize vertices: their k_sum descriptor (k_norm_fix reuses it)
         size_t band_desc_off = 0;
         uint32_t max_nseg = 0;
         for (int fam = 0; fam < F_COUNT; ++fam) {
@@ -1258,7 +1263,15 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.out = presum ? band_plan[vi].tmp : g->vbuf[vi];
                         x.out_q4 = presum ? band_plan[vi].tmpq : nullptr;
                         x.k = (uint32_t)g->edges[vi].size();
-                        x.mode = v.kind == K_NORMALIZE ? 1u : (presum ? 2u : 0u);
+                        const bool spec = v.kind == K_NORMALIZE &&
+                                          std::find(fam_v[F_NORMFIX].begin(), fam_v[F_NORMFIX].end(), vi) != fam_v[F_NORMFIX].end();
+                        x.mode = v.kind == K_NORMALIZE ? (spec ? 3u : 1u) : (presum ? 2u : 0u);
+                        if (spec && (long)vi == g->output_vertex && pcm_dst && qmode) {
+                            x.pcm = pcm_dst;
+                            x.amplitude = amplitude;
+                            x.qmode = (uint32_t)qmode;
+                            if (!g->output_f32) x.out = nullptr;
+                        }
                         x.term_mode = term_mode[vi];
                         x.pg = presum ? PanGain{1.0f, 1.0f, 1.0f, 0u} : make_pg(v.gain, v.angle);
                         if (v.kind == K_NORMALIZE) {
@@ -1275,6 +1288,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         if (g->vertices[vs[i]].kind == K_NORMALIZE) {
                             const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
                             norm_scratch[vs[i]] = {pk, ic};
+                            sum_desc_of[vs[i]] = d[i];
                             scratch_field(o, offsetof(SumDesc, peaks), pk);
                             scratch_field(o, offsetof(SumDesc, init_copy), ic);
                             if (peaks_need_zero) cb.zero.push_back({pk, nb * sizeof(float)});
@@ -1298,12 +1312,24 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.amplitude = amplitude;
                         x.qmode = is_out ? (uint32_t)qmode : 0u;
                         x.pg = make_pg(v.gain, v.angle);
+                        x.pcm_only = (is_out && !g->output_f32) ? 1u : 0u;
                         d.push_back(x);
                     }
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         scratch_field(off + i * sizeof(ScaleDesc), offsetof(ScaleDesc, peaks), norm_scratch[vs[i]].first);
                         scratch_field(off + i * sizeof(ScaleDesc), offsetof(ScaleDesc, init_copy), norm_scratch[vs[i]].second);
+                    }
+                } break;
+                case F_NORMFIX: {   // the same descriptors the speculative k_sum launch got
+                    std::vector<SumDesc> d;
+                    for (size_t vi : vs) d.push_back(sum_desc_of[vi]);
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(SumDesc);
+                        ptr_field(o, offsetof(SumDesc, ins), ins_off[vs[i]]);
+                        scratch_field(o, offsetof(SumDesc, peaks), norm_scratch[vs[i]].first);
+                        scratch_field(o, offsetof(SumDesc, init_copy), norm_scratch[vs[i]].second);
                     }
                 } break;
                 case F_ADSR: {
@@ -1459,6 +1485,7 @@ static size_t desc_size(int fam) {
         case F_SAMPSYN: return sizeof(SampsynDesc);
         case F_SUM: return sizeof(SumDesc);
         case F_SCALE: return sizeof(ScaleDesc);
+        case F_NORMFIX: return sizeof(SumDesc);
         case F_ADSR: return sizeof(AdsrVDesc);
         case F_BAND: return sizeof(BandDesc);
         case F_BAND_SPEC:
@@ -1581,6 +1608,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
                 case F_SUM: launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, L.M, L.bl, L.is_scan, s); break;
+                case F_NORMFIX: launch_norm_fix((const SumDesc*)d, L.n, L.M, L.bl, s); break;
                 case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, L.M, L.aux & 0xFFu, s); break;
                 case F_BAND: launch_band_pass((const BandDesc*)d, L.n, L.M, s); break;
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
@@ -1690,6 +1718,8 @@ static int finish_chunk(td_graph* g, const RenderPlan& rp, size_t done, size_t n
 }
 static void finish_render(td_graph* g, const RenderPlan& rp) {
     g->last_out_f32 = rp.multi ? g->d_out_f32 : (rp.n_blocks ? g->vbuf[(size_t)g->output_vertex] : nullptr);
+    if (!g->output_f32 && rp.want_pcm && g->vertices[(size_t)g->output_vertex].kind == K_NORMALIZE)
+        g->last_out_f32 = nullptr;   // (the f32 frames of the output were never written)
     g->last_frames = rp.total;
     g->last_bits = rp.bits;
 }
@@ -2019,7 +2049,7 @@ int td_graph_add_normalize(td_graph* g, const char* name, float gain, float angl
     const int slot = new_slot(g);
     Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_NORMALIZE);
     v.state_slot = slot;
-    g->hstate[slot].norm = {0.0f, 0.0f};   // extensions.rs:87-92
+    g->hstate[slot].norm = {0.0f, 0.0f, 0u, 0u};   // extensions.rs:87-92
     return 1;
 }
 int td_graph_add_sampleloop(td_graph* g, const char* name, float gain, float angle, size_t sample_index) {
@@ -2177,6 +2207,7 @@ void td_graph_reset_normalize_vertices(td_graph* g) {   // extensions.rs:295-299
         if (vx.kind != K_NORMALIZE) continue;
         vx.has_init_override = true;
         vx.init_override = 0.000001f;
+        vx.peak_known = false;
     }
 }
 float td_graph_get_normalization_value(const td_graph* gc, const char* name) {
@@ -2228,6 +2259,7 @@ static int scan_end(td_graph* g, td_flowwbank* fb) {
     for (auto& v : g->vertices)   // apply_scan_normalization: max = scan_max (every Normalize vertex, reached or not)
         if (v.kind == K_NORMALIZE) {
             v.has_init_override = false;
+            v.peak_known = true;
             TD_HIP(hipMemcpyAsync(&g->dstate[v.state_slot].norm.max, &g->dstate[v.state_slot].norm.scan_max, 4,
                                   hipMemcpyDeviceToDevice, g->stream));
         }
@@ -2400,6 +2432,8 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
+    if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
+    if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }
     if (k == "max_chunk_frames") {
         if (value < 1) return fail("max_chunk_frames must be >= 1");

@@ -108,6 +108,9 @@ struct Vertex {
     // reset_normalization (extensions.rs:295-299) is kept on the host until the next render consumes it
     bool has_init_override = false;
     float init_override = 0.0f;
+    // Normalize: the carried max is the result of a normalize scan (graph.rs:222-237), so a render is expected to
+    // stay below it -> speculative single-pass form (SumDesc mode 3)
+    bool peak_known = false;
     bool has_input() const {
         return kind == K_SUM || kind == K_NORMALIZE || kind == K_ADSR || kind == K_BAND_PASS;
     }
@@ -269,6 +272,8 @@ struct td_graph {
     size_t device_bytes = 0;
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
+    bool output_f32 = true;                    // 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames
+    bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)

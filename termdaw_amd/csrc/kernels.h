@@ -52,7 +52,8 @@ enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32
                            TERMS_EDGE_FEW = 4 };   // all edge buffers, fewer than 8: no deep prefetch pipeline (and its registers)
 
 // Running-peak bookkeeping of normalize_gen (extensions.rs:321-329), carried across chunks / passes.
-struct NormState { float max, scan_max; };
+// `violated` / `ticket` belong to the speculative single-pass normalize (SumDesc mode 3): both are 0 between launches.
+struct NormState { float max, scan_max; uint32_t violated, ticket; };
 
 // sum_inputs (extensions.rs:310-319), optionally + per-reference-block absolute peak
 // (normalize_gen's scan_max, extensions.rs:322 / sample.rs:116-118).
@@ -69,6 +70,11 @@ struct SumDesc {
     uint32_t k;
     uint32_t mode;             // 0: Sum vertex (epilogue applied), 1: Normalize pass A (raw sum + peaks),
                                // 2: band-pass input (raw sum + peak of every 256-frame block -> peaks)
+                               // 3: Normalize in ONE pass, speculating that no block peak exceeds the carried max (true
+                               //    after a normalize scan, graph.rs:222-237, unless carried vertex state makes this
+                               //    render louder than the scan was): sum, scale by 1 / max, epilogue, optional quantise
+                               //    straight out of registers; block peaks still go to `peaks`, a peak above max sets
+                               //    state->violated and k_norm_fix (same descriptors) redoes the vertex the two-pass way
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
     uint32_t pad;
     PanGain pg;
@@ -76,6 +82,10 @@ struct SumDesc {
     // {l0 l1 l2 l3}{r0 r1 r2 r3} instead of {l0 r0 l1 r1}{l2 r2 l3 r3} -- the form k_band_spec's warm-up
     // walks (one register = one chain's next four inputs).  Same size and word addresses as `out`.
     float2* out_q4;
+    // mode 3: fused quantise when the vertex is the output (as in ScaleDesc); `state` is written by k_norm_fix
+    void* pcm;
+    float amplitude;
+    uint32_t qmode;
 };
 
 // Normalize pass B: running max over the block peaks (`*max = buf_max.max(*max)`), buf.scale(len, 1.0 / max)
@@ -91,6 +101,8 @@ struct ScaleDesc {
     float amplitude;
     uint32_t qmode;         // 0 none, 1 int16, 2 int32
     PanGain pg;
+    uint32_t pcm_only;      // the scaled f32 frames are not written back (nobody reads them: engine option "output_f32" 0)
+    uint32_t pad[3];
 };
 
 struct QuantDesc {
@@ -298,6 +310,8 @@ void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStr
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
 void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
+// second half of the speculative single-pass normalize: a no-op unless a block peak exceeded the carried max
+void launch_norm_fix(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
 void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_multi(const MultiDesc* d, int n_desc, uint32_t frames, hipStream_t s);

@@ -407,8 +407,26 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
         store_pair(d.out, m1, M, epilogue4(a1, d.pg));
         return;
     }
-    store_pair(d.out, m0, M, a0);
-    store_pair(d.out, m1, M, a1);
+    float spec_init = 0.0f;
+    if (d.mode == 3) {
+        // speculative single pass: every block is assumed to keep the carried max, so the scale is 1 / max for all
+        // of them (extensions.rs:323-328 with max_b == max_{b-1}); raw sums never reach memory
+        spec_init = d.use_init ? d.init_max : d.state->max;
+        const float r = 1.0f / spec_init;
+        const float4 s0 = epilogue4(make_float4(a0.x * r, a0.y * r, a0.z * r, a0.w * r), d.pg);
+        const float4 s1 = epilogue4(make_float4(a1.x * r, a1.y * r, a1.z * r, a1.w * r), d.pg);
+        if (d.out) {
+            store_pair(d.out, m0, M, s0);
+            store_pair(d.out, m1, M, s1);
+        }
+        if (d.qmode) {
+            store_quant_pair(d.pcm, d.qmode, m0, M, s0, d.amplitude);
+            store_quant_pair(d.pcm, d.qmode, m1, M, s1, d.amplitude);
+        }
+    } else {
+        store_pair(d.out, m0, M, a0);
+        store_pair(d.out, m1, M, a1);
+    }
     if (d.mode == 2) {
         if (!quad_map) {
             // planar-in-4 copy: lanes 2u / 2u+1 hold frames 4u..4u+3; the even lane assembles the L word, the
@@ -462,6 +480,7 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
         d.init_copy[0] = d.use_init ? d.init_max : d.state->max;
         d.init_copy[1] = d.state->scan_max;
     }
+    const bool spec = d.mode == 3;
     if (tiles_per_block) {
         float pk = 0.0f;
         if (m0 < M) pk = absmax4(pk, a0);
@@ -475,8 +494,13 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
             uint32_t b = blockIdx.x / tiles_per_block;
             if (tiles_per_block == 1) d.peaks[b] = pk;
             else atomicMax(reinterpret_cast<unsigned int*>(d.peaks + b), __float_as_uint(pk));  // pk >= 0
+            if (spec && pk > spec_init) const_cast<NormState*>(d.state)->violated = 1u;   // the speculation failed
         }
     } else {
+        if (spec) {
+            const float pk = fmaxf(m0 < M ? absmax4(0.0f, a0) : 0.0f, m1 < M ? absmax4(0.0f, a1) : 0.0f);
+            if (pk > spec_init) const_cast<NormState*>(d.state)->violated = 1u;
+        }
         // generic block length: per-frame block id, peaks pre-zeroed by the host
         const float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
 #pragma unroll
@@ -504,15 +528,50 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, epilogue4(a[q], d.pg));
         return;
     }
+    float pk = 0.0f;   // block peaks are those of the RAW sum
 #pragma unroll
-    for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
+    for (int q = 0; q < 2 * NQ; ++q) if (m + 2u * q < M) pk = absmax4(pk, a[q]);
+    float spec_init = 0.0f;
+    if (d.mode == 3) {   // speculative single-pass normalize (see SumDesc): scaled, finished frames out of registers
+        spec_init = d.use_init ? d.init_max : d.state->max;
+        const float r = 1.0f / spec_init;
+#pragma unroll
+        for (int q = 0; q < 2 * NQ; ++q) a[q] = epilogue4(make_float4(a[q].x * r, a[q].y * r, a[q].z * r, a[q].w * r), d.pg);
+        if (d.out) {   // (nullptr: nobody reads the f32 form of this output vertex -- engine option "output_f32" 0)
+#pragma unroll
+            for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
+        }
+        if (d.qmode == 1u) {
+            // int16 PCM: the lane's 4 * NQ frames are 16 * NQ contiguous bytes -> one 16-byte store per 4 frames
+            uint32_t* o = reinterpret_cast<uint32_t*>(d.pcm);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t mm = m + 4u * q;
+                if (mm + 3u < M) {
+                    const float4 v0 = a[2 * q], v1 = a[2 * q + 1];
+                    u4v w;
+                    w.x = ((uint32_t)quant16(v0.x, d.amplitude) & 0xFFFFu) | ((uint32_t)quant16(v0.y, d.amplitude) << 16);
+                    w.y = ((uint32_t)quant16(v0.z, d.amplitude) & 0xFFFFu) | ((uint32_t)quant16(v0.w, d.amplitude) << 16);
+                    w.z = ((uint32_t)quant16(v1.x, d.amplitude) & 0xFFFFu) | ((uint32_t)quant16(v1.y, d.amplitude) << 16);
+                    w.w = ((uint32_t)quant16(v1.z, d.amplitude) & 0xFFFFu) | ((uint32_t)quant16(v1.w, d.amplitude) << 16);
+                    *reinterpret_cast<u4v TD_GLOBAL*>((TD_GLOBAL char*)(o + mm)) = w;
+                } else {
+                    store_quant_pair(d.pcm, 1u, mm, M, a[2 * q], d.amplitude);
+                    store_quant_pair(d.pcm, 1u, mm + 2u, M, a[2 * q + 1], d.amplitude);
+                }
+            }
+        } else if (d.qmode) {
+#pragma unroll
+            for (int q = 0; q < 2 * NQ; ++q) store_quant_pair(d.pcm, d.qmode, m + 2u * q, M, a[q], d.amplitude);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.init_copy[0] = d.use_init ? d.init_max : d.state->max;
         d.init_copy[1] = d.state->scan_max;
     }
-    float pk = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 2 * NQ; ++q) if (m + 2u * q < M) pk = absmax4(pk, a[q]);
     pk = wave_max(pk);
     __shared__ float wm[kThreads / 64];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = pk;
@@ -523,7 +582,10 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         float p = wm[threadIdx.x * wpb];
         for (uint32_t u = 1; u < wpb; ++u) p = fmaxf(p, wm[threadIdx.x * wpb + u]);
         const uint32_t b = blockIdx.x * NQ + threadIdx.x;
-        if (b * kTileFrames < M) d.peaks[b] = p;
+        if (b * kTileFrames < M) {
+            d.peaks[b] = p;
+            if (d.mode == 3 && p > spec_init) const_cast<NormState*>(d.state)->violated = 1u;
+        }
     }
 }
 
@@ -574,7 +636,7 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
             const float r0 = one_block ? r_tile : rscale_of(m);
             const float r1 = one_block ? r_tile : ((m + 1 < M) ? rscale_of(m + 1) : r0);
             v = epilogue4(make_float4(v.x * r0, v.y * r0, v.z * r1, v.w * r1), d.pg);
-            store_pair(d.buf, m, M, v);
+            if (!d.pcm_only) store_pair(d.buf, m, M, v);
             if (d.qmode) store_quant_pair(d.pcm, d.qmode, m, M, v, d.amplitude);
         }
     }
@@ -587,6 +649,70 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
         } else {
             d.state->max = fmaxf(all, init);
             d.state->scan_max = d.init_copy[1];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_norm_fix: second half of the speculative single-pass normalize (SumDesc mode 3)
+// ------------------------------------------------------------------------------------------------
+// Nothing to do -- one scalar load per workgroup -- unless some block peak exceeded the carried max.  Then every
+// tile whose running max differs from the carried one is redone the two-pass way (sum_inputs again, the exact
+// running max of its blocks from the peak table, scale, epilogue, quantise); the workgroup that finishes last
+// stores the new carried max and re-arms the flag.
+__global__ __launch_bounds__(kThreads) void k_norm_fix(const SumDesc* __restrict__ descs, uint32_t M, uint32_t bl, uint32_t nb) {
+    const SumDesc& d = descs[blockIdx.y];
+    NormState* st = const_cast<NormState*>(d.state);
+    if (d.mode != 3u || st->violated == 0u) return;   // the normal case: the whole launch is a few hundred one-load workgroups
+    const float init = d.init_copy[0];
+    __shared__ float wmax[kThreads / 64];
+    const uint32_t n_tiles = (M + kTileFrames - 1) / kTileFrames;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t tile0 = tile * kTileFrames;
+        const uint32_t m0 = tile0 + 2 * threadIdx.x, m1 = m0 + kTileFrames / 2;
+        const uint32_t b_lo = tile0 / bl;
+        const uint32_t b_hi = min((min(tile0 + (uint32_t)kTileFrames, M) - 1u) / bl, nb - 1u);
+        float p = 0.0f;
+        for (uint32_t b = threadIdx.x; b < b_lo; b += kThreads) p = fmaxf(d.peaks[b], p);
+        p = wave_max(p);
+        __syncthreads();   // (wmax of the previous tile has been read by everyone)
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = p;
+        __syncthreads();
+        const float before = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        const float upto = b_lo ? fmaxf(before, init) : init;      // running max entering the tile's first block
+        float last = upto;
+        for (uint32_t bb = b_lo; bb <= b_hi; ++bb) last = fmaxf(d.peaks[bb], last);
+        if (!(last > init)) continue;   // (uniform) every block of this tile was scaled by 1 / init: already right
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        sum_terms<TERMS_MIXED>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
+        auto rscale_of = [&](uint32_t m) -> float {
+            float run = upto;
+            const uint32_t b = m / bl;
+            for (uint32_t bb = b_lo; bb <= b; ++bb) run = fmaxf(d.peaks[bb], run);
+            return 1.0f / run;
+        };
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t m = h ? m1 : m0;
+            if (m < M) {
+                float4 v = h ? a1 : a0;
+                const float r0 = rscale_of(m), r1 = (m + 1 < M) ? rscale_of(m + 1) : r0;
+                v = epilogue4(make_float4(v.x * r0, v.y * r0, v.z * r1, v.w * r1), d.pg);
+                if (d.out) store_pair(d.out, m, M, v);
+                if (d.qmode) store_quant_pair(d.pcm, d.qmode, m, M, v, d.amplitude);
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        // (the flag was read above, before this increment: the workgroup that draws the last ticket is the last reader)
+        const uint32_t t = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == gridDim.x - 1u) {
+            float all = init;
+            for (uint32_t bb = 0; bb < nb; ++bb) all = fmaxf(d.peaks[bb], all);
+            st->max = all;                       // *max = buf_max.max(*max) over every block of the chunk
+            st->ticket = 0u;
+            st->violated = 0u;
         }
     }
 }
@@ -1694,6 +1820,10 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
 void launch_scale(const ScaleDesc* d, int n, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s) {
     if (!n || !frames) return;
     TD_BATCHED(k_scale, tiles(frames), kThreads, d, n, frames, bl, frames / bl, is_scan);
+}
+void launch_norm_fix(const SumDesc* d, int n, uint32_t frames, uint32_t bl, hipStream_t s) {
+    if (!n || !frames) return;
+    TD_BATCHED(k_norm_fix, std::min(tiles(frames), 512u), kThreads, d, n, frames, bl, frames / bl);
 }
 void launch_quantise(const QuantDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
