@@ -45,6 +45,7 @@ CLOCK_HZ = 2.4e9           # max clock (guide); a wave64 VALU instruction occupi
 SECONDS = 60.0
 N_SRC = 64
 PROF_EVERY = 8
+PREWARM_S = 0.25           # untimed, before the W warm-up steps: steady device clocks (see time_batch)
 PROFILE_TAG = "r02"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
 
 
@@ -154,23 +155,12 @@ def profiled(name):
 
 def build_batch(api, workloads, rank, world, n_per_gpu, seconds, no_fuse, no_pack):
     """This rank's share of the job: global project ids rank, rank + world, ... (p mod world == rank)."""
-    batch = api.Batch()
-    first = None
-    for i in range(n_per_gpu):
-        pid = rank + i * world
-        p = workloads.config2(seconds=seconds, n_src=N_SRC, seed_offset=64 * pid)
-        sb, fb, g = p.build(api)
-        g.set_option("fuse_sources", 0 if no_fuse else 1)
-        g.set_option("packed_samples", 0 if no_pack else 1)
-        # the path's product is the integer PCM (what State::render hands to the WAV writer, state.rs:517-532); the f32
-        # copy of the output vertex that the engine can keep for inspection is switched off (with it: `with_f32_copy`)
-        g.set_option("output_f32", 0)
-        batch.add(sb, fb, g)
-        if first is None:
-            first = p
-        else:
-            p.assets.clear()
-    return batch, first
+    from termdaw_amd import batch as tb
+    ids = tb.shard(n_per_gpu * world, world, rank)
+    # the path's product is the integer PCM (what State::render hands to the WAV writer, state.rs:517-532); the f32
+    # copy of the output vertex that the engine can keep for inspection is switched off (with it: `with_f32_copy`)
+    opts = {"fuse_sources": 0 if no_fuse else 1, "packed_samples": 0 if no_pack else 1, "output_f32": 0}
+    return tb.build_shard(api, lambda pid: workloads.config2(seconds=seconds, n_src=N_SRC, seed_offset=64 * pid), ids, opts)
 
 
 def time_batch(batch, cs, steps, warmup, barrier, exchange):
@@ -178,6 +168,16 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     def step():
         batch.rewind()                       # fresh-after-refresh state (state.rs:467) for every project
         batch.render_all_async(cs, 16)
+    # bring the device to its steady clocks first: the first ~50 ms of work after an idle period run measurably slower
+    # (0.079 vs 0.073 ms per step measured), which is a property of the power state, not of the path
+    t_pre = time.perf_counter()
+    prewarm = 0
+    while time.perf_counter() - t_pre < PREWARM_S:
+        step()
+        prewarm += 1
+        if prewarm % 16 == 0:
+            batch.sync()
+    batch.sync()
     for _ in range(warmup):
         step()
     batch.sync()
@@ -219,6 +219,7 @@ def other_configs(api, workloads, ub, chain_ns):
         for _ in range(2):
             render()
         g.sync()
+        g.host_times(reset=True)     # (the first render allocates buffers and arenas)
         t0 = time.perf_counter()
         for _ in range(reps):
             render()
@@ -276,8 +277,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--projects-per-gpu", type=int, default=1, help="projects in this GPU's batch (config 5: 64)")
     ap.add_argument("--seconds", type=float, default=SECONDS, help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -322,24 +323,9 @@ def main():
             dist.barrier()
 
     def make_exchange(batch, n_per_gpu):
-        """Per-project peak table of the whole job (n_per_gpu x world floats): this rank's entries are written on the
-        device by the engine (zeros elsewhere), then ONE all-reduce(max) -- RCCL on device memory, no host round trip."""
-        n_total = n_per_gpu * world
-        table = torch.zeros(n_total, dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
-
-        def exchange():
-            batch.peak_table_device(table.data_ptr(), n_total, first=rank, stride=world)
-            batch.sync()
-            if use_dist:
-                if backend == "nccl":
-                    dist.all_reduce(table, op=dist.ReduceOp.MAX)
-                else:
-                    t = table.cpu()
-                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                    return t.numpy()
-            return table.cpu().numpy()
-        return exchange
+        """Per-project peak table of the whole job (n_per_gpu x world floats), see termdaw_amd.batch.PeakExchange."""
+        from termdaw_amd import batch as tb
+        return tb.PeakExchange(batch, n_per_gpu, rank, world, dist if use_dist else None, on_device=(backend == "nccl"))
 
     def reduce_max(dt):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
@@ -507,6 +493,7 @@ def main():
             "roofline": roofline,
             "rooflines": kernels,
             "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % PROF_EVERY,
+            "prewarm": "%.2f s of untimed steps before the W warm-up steps (steady device clocks)" % PREWARM_S,
             "host_ms_per_step": {k: round(v / max(host["steps"], 1), 5) for k, v in host.items() if k != "steps"},
             "peak_table": [round(float(x), 6) for x in peaks[:16]],
             "peak_table_entries": int(len(peaks)),

@@ -181,6 +181,9 @@ size_t td_graph_device_bytes(const td_graph* g);
  * no block exceeds the scanned peak; a check kernel redoes the vertex the two-pass way when one does -- same values);
  * "output_f32" 0|1 (default 1; 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames --
  * td_graph_read_f32 then fails, the PCM is unchanged);
+ * "table_cache" 0|1 (default 1: the compiled event tables of an event-driven vertex stay on the device and are
+ * reused while events, FlowwBank cursor, chunk shape and the vertex' carried state at the chunk start are unchanged;
+ * identical vertices of one chunk share one set -- 0 replays the events for every vertex and render);
  * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
  * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */
 int td_graph_set_option(td_graph* g, const char* key, long value);

@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <limits>
 
 #include "wav.h"
@@ -361,6 +362,10 @@ using namespace tde;
 // ------------------------------------------------------------------------------------------------
 // FlowwBank cursor (floww.rs:70-91)
 // ------------------------------------------------------------------------------------------------
+uint64_t td_flowwbank::next_version() {
+    static std::atomic<uint64_t> counter{1};
+    return counter.fetch_add(1);
+}
 void td_flowwbank::set_start_indices_to_frame(size_t t_frame, bool do_skip) {
     for (size_t i = 0; i < flowws.size(); ++i) {
         const auto& fl = flowws[i];
@@ -459,7 +464,8 @@ struct IntervalBuilder {
 
 static inline float note_hz(float note) { return 440.0f * powf(2.0f, (note - 69.0f) / 12.0f); }   // extensions.rs:451,503
 
-struct VTables {   // per-vertex compile result: offsets into the staging arena
+struct VTables {   // per-vertex compile result: offsets into the vertex' table buffer (TableCache)
+    const uint8_t* dev = nullptr;   // device address the offsets refer to
     size_t hits_off = 0;
     uint32_t n_hits = 0;
     size_t istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0;
@@ -708,6 +714,121 @@ static void compile_adsr(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
         v.ag.t += (float)bl / (float)sr;
     }
     put_intervals(ib, st, vt);
+}
+
+// ------------------------------------------------------------------------------------------------
+// event-table cache (TableCache, engine.h)
+// ------------------------------------------------------------------------------------------------
+template <class T>
+static void put_pod(std::string& s, const T& v) { s.append(reinterpret_cast<const char*>(&v), sizeof(T)); }
+template <class T>
+static void get_pod(const std::string& s, size_t& at, T& v) { memcpy(&v, s.data() + at, sizeof(T)); at += sizeof(T); }
+
+// the carried host state of an event-driven vertex (what the reference keeps inside VertexExt), as bytes
+static void save_state(const Vertex& v, std::string& out) {
+    switch (v.kind) {
+        case K_SAMPLE_MULTI:
+            put_pod(out, (uint64_t)v.ts.size());
+            for (auto& e : v.ts) { put_pod(out, e.first); put_pod(out, e.second); }
+            break;
+        case K_SAMPLE_LERP:
+            put_pod(out, v.p_off); put_pod(out, v.g_off); put_pod(out, v.p_vel); put_pod(out, v.g_vel); put_pod(out, v.countdown);
+            break;
+        case K_DEBUG_SINE:
+            put_pod(out, (uint64_t)v.sine_notes.size());
+            for (auto& n : v.sine_notes) put_pod(out, n);
+            break;
+        case K_SYNTH:
+        case K_SAMPSYN:
+            put_pod(out, (uint64_t)v.notes.size());
+            for (auto& n : v.notes) put_pod(out, n);
+            break;
+        case K_ADSR: put_pod(out, v.ap); put_pod(out, v.ag); break;
+        default: break;
+    }
+}
+static void load_state(Vertex& v, const std::string& in) {
+    size_t at = 0;
+    uint64_t n = 0;
+    switch (v.kind) {
+        case K_SAMPLE_MULTI:
+            get_pod(in, at, n);
+            v.ts.clear();
+            for (uint64_t i = 0; i < n; ++i) { std::pair<int64_t, float> e; get_pod(in, at, e.first); get_pod(in, at, e.second); v.ts.push_back(e); }
+            break;
+        case K_SAMPLE_LERP:
+            get_pod(in, at, v.p_off); get_pod(in, at, v.g_off); get_pod(in, at, v.p_vel); get_pod(in, at, v.g_vel); get_pod(in, at, v.countdown);
+            break;
+        case K_DEBUG_SINE:
+            get_pod(in, at, n);
+            v.sine_notes.resize((size_t)n);
+            for (auto& x : v.sine_notes) get_pod(in, at, x);
+            break;
+        case K_SYNTH:
+        case K_SAMPSYN:
+            get_pod(in, at, n);
+            v.notes.resize((size_t)n);
+            for (auto& x : v.notes) get_pod(in, at, x);
+            break;
+        case K_ADSR: get_pod(in, at, v.ap); get_pod(in, at, v.ag); break;
+        default: break;
+    }
+}
+// Everything the compiled tables of vertex v for this chunk depend on.  (The per-block FlowwBank cursor follows from
+// its first block: set_time_to_next_block is a pure function of the events and the previous cursor, floww.rs:70-91.)
+static void table_key(const Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl, size_t sr,
+                      size_t sample_len, std::string& key) {
+    key.clear();
+    put_pod(key, (uint32_t)v.kind);
+    put_pod(key, (uint64_t)(uintptr_t)fb);
+    put_pod(key, (uint64_t)v.floww_index);
+    put_pod(key, v.floww_index < fb->versions.size() ? fb->versions[v.floww_index] : (uint64_t)0);
+    put_pod(key, (uint64_t)cur.size()); put_pod(key, (uint64_t)bl); put_pod(key, (uint64_t)sr);
+    put_pod(key, (uint64_t)cur[0].frame);
+    put_pod(key, (uint64_t)(v.floww_index < cur[0].n ? cur[0].start[v.floww_index] : 0));
+    put_pod(key, (uint8_t)v.has_note); put_pod(key, (uint64_t)v.note);
+    switch (v.kind) {
+        case K_SAMPLE_MULTI: put_pod(key, (uint64_t)sample_len); break;
+        case K_SAMPLE_LERP: put_pod(key, (uint64_t)v.lerp_len); break;
+        case K_SYNTH: put_pod(key, v.square); put_pod(key, v.topflat); put_pod(key, v.triangle); break;   // (retain rule: release times)
+        case K_SAMPSYN: put_pod(key, v.conf); break;
+        case K_ADSR: put_pod(key, (uint8_t)v.use_off); put_pod(key, v.conf); break;
+        default: break;
+    }
+    save_state(v, key);
+}
+static int upload_tables(td_graph* g, TableCache& tc, const Staging& tmp) {
+    const size_t bytes = std::max<size_t>(tmp.b.size(), 16);
+    if (bytes > tc.cap) {
+        TD_HIP(hipStreamSynchronize(g->stream));   // (kernels of earlier renders may still read the old buffer)
+        if (tc.d) { (void)hipFree(tc.d); g->device_bytes -= tc.cap; }
+        if (tc.h) (void)hipHostFree(tc.h);
+        tc.d = tc.h = nullptr;
+        tc.cap = 0;
+        tc.inflight = false;
+        const size_t cap = bytes + bytes / 4 + 256;
+        TD_HIP(hipMalloc(&tc.d, cap));
+        TD_HIP(hipHostMalloc(&tc.h, cap, hipHostMallocDefault));
+        if (!tc.copied) TD_HIP(hipEventCreateWithFlags(&tc.copied, hipEventDisableTiming));
+        tc.cap = cap;
+        g->device_bytes += cap;
+    }
+    if (tc.inflight) TD_HIP(hipEventSynchronize(tc.copied));
+    tc.inflight = false;
+    memcpy(tc.h, tmp.b.data(), tmp.b.size());
+    TD_HIP(hipMemcpyAsync(tc.d, tc.h, tmp.b.size(), hipMemcpyHostToDevice, g->stream));
+    TD_HIP(hipEventRecord(tc.copied, g->stream));
+    tc.inflight = true;
+    return 1;
+}
+static void free_tables(td_graph* g) {   // (device selected, stream synchronised by the caller)
+    for (auto& v : g->vertices)
+        if (v.tables) {
+            if (v.tables->d) { (void)hipFree(v.tables->d); g->device_bytes -= v.tables->cap; }
+            if (v.tables->h) (void)hipHostFree(v.tables->h);
+            if (v.tables->copied) (void)hipEventDestroy(v.tables->copied);
+            v.tables.reset();
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -963,33 +1084,76 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     Staging& st = *cb.st;   // capacity kept from render to render
     cb.n_graphs += 1;
     std::vector<VTables> vt(nv);
+    std::map<std::string, size_t> chunk_keys;   // table key -> first vertex of this chunk compiled from it
+    std::string key;
+    Staging tmp;
     for (size_t vi : g->order) {
         Vertex& v = g->vertices[vi];
         vt[vi].t0 = t0;
+        size_t sample_len = 0;
         switch (v.kind) {
             case K_SAMPLE_LOOP:
                 if (v.sample_index >= sb->samples.size()) return fail("sampleloop: sample index out of range");
                 vt[vi].t0 = v.loop_t;
                 v.loop_t += M;   // *t += len per block (extensions.rs:340)
-                break;
+                continue;
             case K_SAMPLE_MULTI:
                 if (v.sample_index >= sb->samples.size()) return fail("sample_multi: sample index out of range");
-                compile_multi(v, sb->samples[v.sample_index].len, fb, cur, bl, st, vt[vi]);
+                sample_len = sb->samples[v.sample_index].len;
                 break;
             case K_SAMPLE_LERP:
                 if (v.sample_index >= sb->samples.size()) return fail("sample_lerp: sample index out of range");
-                compile_lerp(v, fb, cur, bl, st, vt[vi]);
                 break;
-            case K_DEBUG_SINE: compile_sine(v, fb, cur, bl, st, vt[vi]); break;
+            case K_DEBUG_SINE:
             case K_SYNTH:
-            case K_SAMPSYN:
-                if (!compile_synth(v, fb, cur, bl, sr, st, vt[vi])) return 0;
-                break;
+            case K_SAMPSYN: break;
             case K_ADSR:
-                if (!(v.wet < 0.0001f)) compile_adsr(v, fb, cur, bl, sr, st, vt[vi]);   // :598 early return keeps clocks
+                if (v.wet < 0.0001f) continue;   // :598 early return keeps clocks
                 break;
-            default: break;
+            default: continue;
         }
+        // an event-driven vertex: tables from (1) a vertex of this chunk with the same key, (2) this vertex' own cache
+        // when the key has not changed since it was filled, (3) a replay of the events
+        table_key(v, fb, cur, bl, sr, sample_len, key);
+        TableCache* tc = nullptr;
+        auto shared = g->table_cache ? chunk_keys.find(key) : chunk_keys.end();
+        if (shared != chunk_keys.end()) {
+            tc = g->vertices[shared->second].tables.get();
+            load_state(v, tc->end_state);
+        } else {
+            if (!v.tables) v.tables = std::make_shared<TableCache>();
+            tc = v.tables.get();
+            if (g->table_cache && !tc->key.empty() && tc->key == key) {
+                load_state(v, tc->end_state);
+            } else {
+                tmp.b.clear();
+                VTables t;
+                switch (v.kind) {
+                    case K_SAMPLE_MULTI: compile_multi(v, sample_len, fb, cur, bl, tmp, t); break;
+                    case K_SAMPLE_LERP: compile_lerp(v, fb, cur, bl, tmp, t); break;
+                    case K_DEBUG_SINE: compile_sine(v, fb, cur, bl, tmp, t); break;
+                    case K_SYNTH:
+                    case K_SAMPSYN:
+                        if (!compile_synth(v, fb, cur, bl, sr, tmp, t)) return 0;
+                        break;
+                    default: compile_adsr(v, fb, cur, bl, sr, tmp, t); break;
+                }
+                tc->key.clear();   // (not valid until the upload below has been queued)
+                if (!upload_tables(g, *tc, tmp)) return 0;
+                tc->hits_off = t.hits_off; tc->n_hits = t.n_hits;
+                tc->istart_off = t.istart_off; tc->ivoff_off = t.ivoff_off; tc->voices_off = t.voices_off;
+                tc->tile_first_off = t.tile_first_off; tc->n_int = t.n_int;
+                tc->end_state.clear();
+                save_state(v, tc->end_state);
+                tc->key = key;
+            }
+            chunk_keys[key] = vi;
+        }
+        VTables& o = vt[vi];
+        o.dev = tc->d;
+        o.hits_off = tc->hits_off; o.n_hits = tc->n_hits;
+        o.istart_off = tc->istart_off; o.ivoff_off = tc->ivoff_off; o.voices_off = tc->voices_off;
+        o.tile_first_off = tc->tile_first_off; o.n_int = tc->n_int;
     }
 
     // ---- 2. descriptors: walk levels, assign edge buffers
@@ -1027,6 +1191,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     auto scratch = [&](size_t n) { size_t o = cb.scratch_bytes; cb.scratch_bytes += (n + 255) & ~(size_t)255; return o; };
     auto ptr_field = [&](size_t desc_off, size_t field_off, size_t staging_off) {
         cb.table_fix.push_back({desc_off + field_off, staging_off});
+    };
+    // pointer to a table of an event-driven vertex: those live in the vertex' own device buffer (TableCache)
+    auto tab_field = [&](size_t desc_off, size_t field_off, const VTables& t, size_t off) {
+        const uint64_t p = (uint64_t)(uintptr_t)(t.dev + off);
+        memcpy(&st.b[desc_off + field_off], &p, 8);
     };
     auto scratch_field = [&](size_t desc_off, size_t field_off, size_t s_off) { cb.scratch_fix.push_back({desc_off + field_off, s_off}); };
 
@@ -1151,8 +1320,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     }
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
-                        ptr_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, hits), vt[vs[i]].hits_off);
-                        ptr_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, tile_first), vt[vs[i]].tile_first_off);
+                        tab_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, hits), vt[vs[i]], vt[vs[i]].hits_off);
+                        tab_field(off + i * sizeof(MultiDesc), offsetof(MultiDesc, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
                     }
                 } break;
                 case F_LERP: {
@@ -1165,8 +1334,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     }
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
-                        ptr_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, hits), vt[vs[i]].hits_off);
-                        ptr_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, tile_first), vt[vs[i]].tile_first_off);
+                        tab_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, hits), vt[vs[i]], vt[vs[i]].hits_off);
+                        tab_field(off + i * sizeof(LerpDesc), offsetof(LerpDesc, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
                     }
                 } break;
                 case F_SINE: {
@@ -1184,10 +1353,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SineDesc) + offsetof(SineDesc, tab);
-                        ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
-                        ptr_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
-                        ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
-                        ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                        tab_field(o, offsetof(IntervalTab, istart), vt[vs[i]], vt[vs[i]].istart_off);
+                        tab_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
+                        tab_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]], vt[vs[i]].ivoff_off);
+                        tab_field(o, offsetof(IntervalTab, voices), vt[vs[i]], vt[vs[i]].voices_off);
                     }
                 } break;
                 case F_SYNTH: {
@@ -1220,10 +1389,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SynthDesc) + offsetof(SynthDesc, tab);
-                        ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
-                        ptr_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
-                        ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
-                        ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                        tab_field(o, offsetof(IntervalTab, istart), vt[vs[i]], vt[vs[i]].istart_off);
+                        tab_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
+                        tab_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]], vt[vs[i]].ivoff_off);
+                        tab_field(o, offsetof(IntervalTab, voices), vt[vs[i]], vt[vs[i]].voices_off);
                     }
                 } break;
                 case F_SAMPSYN: {
@@ -1244,10 +1413,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SampsynDesc) + offsetof(SampsynDesc, tab);
-                        ptr_field(o, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
-                        ptr_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
-                        ptr_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
-                        ptr_field(o, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                        tab_field(o, offsetof(IntervalTab, istart), vt[vs[i]], vt[vs[i]].istart_off);
+                        tab_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
+                        tab_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]], vt[vs[i]].ivoff_off);
+                        tab_field(o, offsetof(IntervalTab, voices), vt[vs[i]], vt[vs[i]].voices_off);
                     }
                 } break;
                 case F_SUM: {
@@ -1359,10 +1528,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         const size_t o = off + i * sizeof(AdsrVDesc);
                         ptr_field(o, offsetof(AdsrVDesc, ins), ins_off[vs[i]]);
                         const size_t t = o + offsetof(AdsrVDesc, tab);
-                        ptr_field(t, offsetof(IntervalTab, istart), vt[vs[i]].istart_off);
-                        ptr_field(t, offsetof(IntervalTab, tile_first), vt[vs[i]].tile_first_off);
-                        ptr_field(t, offsetof(IntervalTab, ivoff), vt[vs[i]].ivoff_off);
-                        ptr_field(t, offsetof(IntervalTab, voices), vt[vs[i]].voices_off);
+                        tab_field(t, offsetof(IntervalTab, istart), vt[vs[i]], vt[vs[i]].istart_off);
+                        tab_field(t, offsetof(IntervalTab, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
+                        tab_field(t, offsetof(IntervalTab, ivoff), vt[vs[i]], vt[vs[i]].ivoff_off);
+                        tab_field(t, offsetof(IntervalTab, voices), vt[vs[i]], vt[vs[i]].voices_off);
                     }
                 } break;
                 case F_BAND: {
@@ -1900,9 +2069,11 @@ void td_flowwbank_reset(td_flowwbank* fb) {
     fb->start_indices.clear();
     fb->names.clear();
     fb->stream_list.clear();
+    fb->versions.clear();
 }
 long td_flowwbank_add_events(td_flowwbank* fb, const char* name, const td_event* events, size_t n) {
     fb->flowws.emplace_back(events, events + n);
+    fb->versions.push_back(td_flowwbank::next_version());
     fb->start_indices.push_back(0);
     const size_t index = fb->flowws.size() - 1;
     fb->names[name] = index;
@@ -1927,12 +2098,14 @@ long td_flowwbank_append_stream(td_flowwbank* fb, const char* name, const td_eve
     if (it == fb->names.end()) return -1;
     auto& f = fb->flowws[it->second];
     f.insert(f.end(), events, events + n);
+    fb->versions[it->second] = td_flowwbank::next_version();
     return (long)f.size();
 }
 void td_flowwbank_trim_streams(td_flowwbank* fb) {   // start_indices are not rewound (floww.rs:59-64)
     for (size_t index : fb->stream_list) {
         auto& f = fb->flowws[index];
         f.erase(f.begin(), f.begin() + (long)std::min(fb->start_indices[index], f.size()));
+        fb->versions[index] = td_flowwbank::next_version();
     }
 }
 size_t td_flowwbank_get_events(const td_flowwbank* fb, size_t index, td_event* out, size_t cap) {
@@ -1978,6 +2151,7 @@ void td_graph_free(td_graph* g) {
         (void)hipStreamSynchronize(g->stream);
         for (float2* p : g->pool) (void)hipFree(p);
         for (float* p : g->wavetables) (void)hipFree(p);
+        free_tables(g);
         if (g->dstate) (void)hipFree(g->dstate);
         free_arena(g->arena);
         if (g->d_pcm) (void)hipFree(g->d_pcm);
@@ -1996,9 +2170,10 @@ void td_graph_free(td_graph* g) {
     delete g;
 }
 void td_graph_reset(td_graph* g) {
-    if (!g->wavetables.empty() && g->stream && hipSetDevice(g->device) == hipSuccess) {
-        (void)hipStreamSynchronize(g->stream);
+    if ((g->stream || !g->wavetables.empty()) && hipSetDevice(g->device) == hipSuccess) {
+        if (g->stream) (void)hipStreamSynchronize(g->stream);
         for (float* p : g->wavetables) (void)hipFree(p);
+        free_tables(g);
     }
     g->wavetables.clear();
     g->vertices.clear();
@@ -2434,6 +2609,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
+    if (k == "table_cache") { g->table_cache = value != 0; return 1; }
     if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }
     if (k == "max_chunk_frames") {
         if (value < 1) return fail("max_chunk_frames must be >= 1");

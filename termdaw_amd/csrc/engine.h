@@ -65,6 +65,8 @@ struct td_flowwbank {
     std::vector<size_t> start_indices;
     std::map<std::string, size_t> names;
     std::vector<size_t> stream_list;
+    std::vector<uint64_t> versions;   // per floww: process-wide unique stamp, renewed whenever its events change
+    static uint64_t next_version();
     size_t frame_of(const td_event& e) const { return tde::f32_as_usize(e.t_sec * (float)sr); }
     void set_start_indices_to_frame(size_t t_frame, bool do_skip);
     void set_time(size_t t);
@@ -79,6 +81,23 @@ enum Kind { K_SUM, K_NORMALIZE, K_SAMPLE_LOOP, K_SAMPLE_MULTI, K_SAMPLE_LERP, K_
 struct SineNote { float note, vel; };
 struct SynthNote { float note, vel, env_t, rel_t, hz; };   // hz = 440 * 2^((note - 69) / 12), extensions.rs:503
 struct Voice3 { float t, vel, rel; };
+
+// Compiled event tables of one event-driven vertex (hit lists / interval tables), resident in a device buffer of their
+// own together with the key they were compiled from.  A chunk whose key is byte-identical -- same events, same
+// FlowwBank cursor, same chunk shape, same carried vertex state at the chunk start -- reuses the tables without
+// replaying a single event (and the carried state jumps to the stored end state).
+struct TableCache {
+    std::string key;                 // empty: nothing cached
+    std::string end_state;           // carried host state after the chunk
+    uint8_t* d = nullptr;            // device copy of the tables
+    uint8_t* h = nullptr;            // pinned host staging of the last upload
+    size_t cap = 0;
+    hipEvent_t copied = nullptr;
+    bool inflight = false;
+    // table layout: offsets into d
+    size_t hits_off = 0, istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0;
+    uint32_t n_hits = 0, n_int = 0;
+};
 
 struct Vertex {
     Kind kind = K_SUM;
@@ -111,6 +130,7 @@ struct Vertex {
     // Normalize: the carried max is the result of a normalize scan (graph.rs:222-237), so a render is expected to
     // stay below it -> speculative single-pass form (SumDesc mode 3)
     bool peak_known = false;
+    std::shared_ptr<TableCache> tables;   // event-driven kinds only (shared_ptr: Vertex stays copyable)
     bool has_input() const {
         return kind == K_SUM || kind == K_NORMALIZE || kind == K_ADSR || kind == K_BAND_PASS;
     }
@@ -273,6 +293,7 @@ struct td_graph {
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
     bool output_f32 = true;                    // 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames
+    bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames

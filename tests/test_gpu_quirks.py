@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 from termdaw_amd import workloads as W
+from test_gpu_parity import assert_bit_exact, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -266,3 +267,33 @@ def test_q18_vertices_built_by_type_edges_in_script_order(gpu_api, oracle):
     p.connect("b", "o")
     p.set_output("o")
     both(p, gpu_api, oracle)
+
+
+@pytest.mark.parametrize("project", ["drum", "synth", "config4"])
+def test_event_table_cache_is_value_neutral(gpu_api, oracle, project):
+    """Compiled event tables are reused across renders (same events, cursor and carried state) and across identical
+    vertices of one chunk; with the cache off every vertex replays its events every time.  Same bytes either way,
+    also across renders whose carried state differs (quirk Q4) and after set_time."""
+    mk = {"drum": lambda: W.drum_project(seconds=1.5), "synth": lambda: W.synth_project(seconds=1.5),
+          "config4": lambda: W.config4(seconds=1.0, depth=30)}[project]
+    outs = []
+    for cache in (1, 0):
+        p = mk()
+        sb, fb, g = p.build(gpu_api)
+        g.set_option("table_cache", cache)
+        seq = []
+        for rep in range(3):
+            seq.append(g.render_all(sb, fb, p.cs, 16))
+        g.set_time(5 * p.bl)                      # playhead moved: FlowwBank cursor and loop cursors change the key
+        fb.set_time(5 * p.bl)
+        seq.append(g.render_all(sb, fb, 7, 16))
+        fb.set_time(0)
+        g.true_normalize_scan(sb, fb, p.cs)
+        seq.append(g.render_all(sb, fb, p.cs, 16))
+        outs.append(seq)
+    for a, b in zip(*outs):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+    p = mk()
+    ob = p.build(oracle)
+    ref = ob[2].render_all(ob[0], ob[1], p.cs, 16)
+    (assert_close if project == "synth" else assert_bit_exact)(outs[0][0], ref)

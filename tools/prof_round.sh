@@ -1,17 +1,26 @@
-TAG=${1:-e}
+# Round profile set (run on the MI355X box through gpurun):  bash tools/prof_round.sh <tag>
+#   gpurun_out/prof_<tag>_<mode>/   rocprofv3 --kernel-trace --stats of bench.py (fused = default engine, nofuse = edge-buffer model)
+#   gpurun_out/pmc_<tag>_<mode>_*/  separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | VALU counters
+#   gpurun_out/pmc_<tag>_c3_VALU, _c4_VALU   the same VALU pass for configs 3 and 4 (tools/time_configs.py)
+# then tools/pmc_summary.py <tag> writes profiles/<tag>_pmc_summary.json and profiles/<tag>_valu.json.
+TAG=${1:-r02}
 R=/root/repo
 cd /tmp && export TMPDIR=/tmp
+B="--no-cpu-baseline --no-extras"
+VALU="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES"
 for mode in fused nofuse; do
   flag=""; [ $mode = nofuse ] && flag="--no-fuse"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$mode -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline $flag > $R/gpurun_out/prof_${TAG}_$mode.log 2>&1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_FETCH_SIZE -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_WRITE_SIZE -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > /dev/null 2>&1
-  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_TCC_HIT_sum_TCC_MISS_sum -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline $flag > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$mode -- python3 $R/bench.py --steps 20 --warmup 5 $B $flag > $R/gpurun_out/prof_${TAG}_$mode.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_FETCH_SIZE -- python3 $R/bench.py --steps 3 --warmup 1 $B $flag > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_WRITE_SIZE -- python3 $R/bench.py --steps 3 --warmup 1 $B $flag > /dev/null 2>&1
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_TCC_HIT_sum_TCC_MISS_sum -- python3 $R/bench.py --steps 3 --warmup 1 $B $flag > /dev/null 2>&1
+  rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${mode}_VALU -- python3 $R/bench.py --steps 3 --warmup 1 $B $flag > /dev/null 2>&1
+done
+# the batch (config 5 share) launch of the sum kernel
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_batch64 -- python3 $R/bench.py --steps 5 --warmup 2 $B --projects-per-gpu 64 > $R/gpurun_out/prof_${TAG}_batch64.log 2>&1
+for c in c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$c -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_$c.log 2>&1
+  rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
 done
 cd $R
-python bench.py > gpurun_out/bench_${TAG}_fused.json 2> gpurun_out/bench_${TAG}_fused.err
-python bench.py --no-fuse > gpurun_out/bench_${TAG}_nofuse.json 2>/dev/null
-python bench.py --no-pack --no-cpu-baseline > gpurun_out/bench_${TAG}_fused_f32.json 2>/dev/null
-find gpurun_out -name "*.csv" | head -40
-python tools/time_configs.py c1 c2 c3 drum synth c4 > gpurun_out/configs_${TAG}.txt 2>/dev/null
-python tools/hosttime_all.py > gpurun_out/hosttime_${TAG}.txt 2>/dev/null
+python tools/pmc_summary.py $TAG

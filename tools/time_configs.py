@@ -1,6 +1,6 @@
 """Per-kernel HIP-event times of the non-headline configs (run on the GPU box)."""
-import sys, time
-sys.path.insert(0, '.')
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from termdaw_amd import api, workloads as W
 
