@@ -177,6 +177,10 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
  * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed
  * only, the bit-wise check and repair keep every result exact);
+ * "band_quick" n / "band_medium" n / "band_depth" n (defaults 12 / 30 / 100; band_quick 0 switches the mechanism off):
+ * for cut-offs below ~75 Hz the warm-up starts from the exact-arithmetic state at its first frame (per-256-frame
+ * block responses of the two smoothers, chained in double until (1-gamma)^(256 K) <= e^-band_depth) and then only
+ * takes n / gamma frames -- again speed only;
  * "spec_normalize" 0|1 (default 1: a render after td_graph_normalize_scan normalises in ONE pass, speculating that
  * no block exceeds the scanned peak; a check kernel redoes the vertex the two-pass way when one does -- same values);
  * "output_f32" 0|1 (default 1; 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames --

@@ -1036,6 +1036,10 @@ struct BandPlan {
     float2* tmp = nullptr;    // materialised input sum
     float2* tmpq = nullptr;   // ... and its planar-in-4 copy (warm-up input)
     size_t blk_peaks_off = 0;
+    // block-response guess (kernels.h BandRespParam): quick warm-up, Horner depth per smoother
+    uint32_t Wq = 0, Wq2 = 0, Kl = 0, Kh = 0;
+    double Al = 0.0, Ah = 0.0;
+    size_t resp_off = 0, rp_off = 0;
 };
 static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     BandPlan p;
@@ -1050,12 +1054,37 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     p.W = ((uint32_t)w + 31u) & ~31u;
     p.Ws = std::min(p.W, ((uint32_t)((double)g->band_short / (double)gmin + 64.0) + 31u) & ~31u);   // coalescence only
     p.Ws = (p.Ws + 255u) & ~255u;                                                   // whole 256-frame liveness blocks
-    p.W = std::max(p.W, p.Ws);
+    p.W = (std::max(p.W, p.Ws) + 255u) & ~255u;                                     // (every window starts on a block boundary)
     p.S = 256;
     while ((M + p.S - 1) / p.S > kBandMaxSegs && p.S < kBandMaxS) p.S *= 2;
     p.nseg = (uint32_t)((M + p.S - 1) / p.S);
     if (p.nseg > kBandMaxSegs) return p;
     p.parallel = p.nseg >= 8;        // tiny chunks (block pulls) stay on the serial kernel
+    // (the guess pays where the short warm-up is long -- cut-offs below ~75 Hz; elsewhere the walk is a few
+    // hundred steps anyway and the block responses would only cost their reduction in the input-sum kernel)
+    if (p.parallel && g->band_quick && p.S == 256 && p.Ws >= 4096u) {
+        // Horner depth: the chained block responses must carry the memory of everything that can still matter.  A deep
+        // effect chain swings over tens of decades (84 envelope stages: 25), so "matter" is priced against the whole
+        // f32 exponent range a past burst can tower over the present: (1 - gamma)^(256 K) <= e^-band_depth, 100 by
+        // default.  A smoother slower than 256 blocks' worth keeps the plain warm-up.
+        const double depth_nats = (double)g->band_depth;
+        auto depth = [depth_nats](float gamma, double* A) -> uint32_t {
+            if (gamma == 0.0f) { *A = 1.0; return 1u; }          // constant chain: the guess is never used for it
+            const double q = 1.0 - (double)gamma;
+            if (!(q > 0.0)) { *A = 0.0; return 1u; }
+            *A = pow(q, 256.0);
+            const double k = ceil(depth_nats / (-256.0 * log(q)));
+            return k < 1.0 ? 1u : (k > 1e6 ? 1000000u : (uint32_t)k);
+        };
+        p.Kl = depth(v.lgamma, &p.Al);
+        p.Kh = depth(v.hgamma, &p.Ah);
+        const uint32_t wq = (((uint32_t)((double)g->band_quick / (double)gmin + 64.0) + 31u) & ~31u);
+        const uint32_t wq2 = (((uint32_t)((double)g->band_medium / (double)gmin + 64.0) + 31u) & ~31u);
+        if (p.Kl <= 200u && p.Kh <= 200u) {
+            p.Wq = std::min(p.Ws, (wq + 255u) & ~255u);
+            p.Wq2 = std::min(p.Ws, (std::max(wq, wq2) + 255u) & ~255u);
+        }
+    }
     return p;
 }
 
@@ -1443,6 +1472,18 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         }
                         x.term_mode = term_mode[vi];
                         x.pg = presum ? PanGain{1.0f, 1.0f, 1.0f, 0u} : make_pg(v.gain, v.angle);
+                        if (presum && band_plan[vi].Wq) {   // block responses for the warm-up guess
+                            BandPlan& bp = band_plan[vi];
+                            BandRespParam rp{};
+                            double ql = 1.0 - (double)v.lgamma, qh = 1.0 - (double)v.hgamma;
+                            for (int j = 0; j < 8; ++j) { rp.ql[j] = ql; rp.qh[j] = qh; ql *= ql; qh *= qh; }
+                            rp.gl = (double)v.lgamma;
+                            rp.gh = (double)v.hgamma;
+                            bp.rp_off = st.alloc(sizeof rp);
+                            memcpy(&st.b[bp.rp_off], &rp, sizeof rp);
+                            bp.resp_off = scratch(((M + 255) / 256) * 4 * sizeof(double));
+                            scratch_field(bp.rp_off, offsetof(BandRespParam, resp), bp.resp_off);
+                        }
                         if (v.kind == K_NORMALIZE) {
                             x.state = &g->dstate[v.state_slot].norm;
                             x.use_init = v.has_init_override ? 1u : 0u;   // reset_normalization consumed here
@@ -1466,6 +1507,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             const size_t bpk = scratch(((M + 255) / 256) * sizeof(float));
                             band_plan[vs[i]].blk_peaks_off = bpk;
                             scratch_field(o, offsetof(SumDesc, peaks), bpk);
+                            if (band_plan[vs[i]].Wq) ptr_field(o, offsetof(SumDesc, rp), band_plan[vs[i]].rp_off);
                         }
                     }
                 } break;
@@ -1581,6 +1623,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.lgamma = v.lgamma;
                         x.hgamma = v.hgamma;
                         x.pg = make_pg(v.gain, v.angle);
+                        x.Wq = bp.Wq;
+                        x.Wq2 = bp.Wq2;
+                        x.quick_thr = fminf(1.0f, g->band_live_thr * 1.0e5f);
+                        x.Al = bp.Al; x.Ah = bp.Ah;
+                        x.Kl = bp.Kl; x.Kh = bp.Kh;
                         d.push_back(x);
                         max_nseg = std::max(max_nseg, bp.nseg);
                     }
@@ -1593,6 +1640,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         scratch_field(o, offsetof(BandSpecDesc, seg_final), scratch((size_t)ns * 16));
                         scratch_field(o, offsetof(BandSpecDesc, seg_flags), scratch((size_t)ns * 4));
                         scratch_field(o, offsetof(BandSpecDesc, blk_peaks), band_plan[vs[i]].blk_peaks_off);
+                        if (band_plan[vs[i]].Wq) scratch_field(o, offsetof(BandSpecDesc, resp), band_plan[vs[i]].resp_off);
                         scratch_field(o, offsetof(BandSpecDesc, seg_x0), scratch((size_t)ns * 8));
                         scratch_field(o, offsetof(BandSpecDesc, jobs), scratch((size_t)ns * sizeof(BandJob)));
                         scratch_field(o, offsetof(BandSpecDesc, seg_job), scratch((size_t)ns * 4));
@@ -1613,6 +1661,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     bool wide_ok = true;   // (k_sum16w: plain sums, or normalize pass A with the tile as reference block)
                     while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) {
                         wide_ok = wide_ok && (g->vertices[vs[e2]].kind != K_NORMALIZE || bl == (size_t)kTileFrames);
+                        // (a band-pass vertex' input sum -- mode 2: planar copy, 256-frame liveness -- only exists in the pair-mapped k_sum)
+                        wide_ok = wide_ok && !(fam == F_SUM && band_plan.count(vs[e2]));
                         ++e2;
                     }
                     add_launch(fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u), lv);
@@ -2605,6 +2655,9 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
     if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
     if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
+    if (k == "band_quick") { g->band_quick = value > 0 ? (unsigned)value : 0u; return 1; }
+    if (k == "band_medium") { g->band_medium = value > 0 ? (unsigned)value : 30u; return 1; }
+    if (k == "band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }

@@ -55,6 +55,17 @@ enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32
 // `violated` / `ticket` belong to the speculative single-pass normalize (SumDesc mode 3): both are 0 between launches.
 struct NormState { float max, scan_max; uint32_t violated, ticket; };
 
+// Block responses of a band-pass vertex' two smoothers, made by the k_sum launch that materialises its input (mode 2)
+// and used by k_band_spec as the starting point of its speculative warm-up: for every aligned 256-frame block b and
+// chain c (low L, low R, high L, high R)   resp[4 b + c] = sum_i gamma (1 - gamma)^(255 - i) x_c[256 b + i],
+// i.e. what the block alone adds to the smoother's state at its end -- in double, so that a few dozen of them chained by
+// y <- (1 - gamma)^256 y + resp reproduce the exact-arithmetic state to far below an f32 ulp.
+struct BandRespParam {
+    double ql[8], qh[8];   // (1 - gamma)^(2^j), j = 0..7, low / high smoother
+    double gl, gh;         // the two gammas
+    double* resp;          // [ceil(frames / 256)][4]
+};
+
 // sum_inputs (extensions.rs:310-319), optionally + per-reference-block absolute peak
 // (normalize_gen's scan_max, extensions.rs:322 / sample.rs:116-118).
 struct SumDesc {
@@ -86,6 +97,7 @@ struct SumDesc {
     void* pcm;
     float amplitude;
     uint32_t qmode;
+    const BandRespParam* rp;   // mode 2: block responses wanted (nullptr: not)
 };
 
 // Normalize pass B: running max over the block peaks (`*max = buf_max.max(*max)`), buf.scale(len, 1.0 / max)
@@ -270,6 +282,14 @@ struct BandSpecDesc {
     uint32_t pass;
     float lgamma, hgamma;
     PanGain pg;
+    // warm-up guess from the block responses (BandRespParam): state at a block boundary = Horner over the last K blocks
+    const double* resp;     // nullptr: no guess (the warm-up starts from the input frame itself and takes Ws)
+    double Al, Ah;          // (1 - gamma)^256 of the low / high smoother
+    uint32_t Kl, Kh;        // blocks after which A^K is negligible
+    uint32_t Wq;            // quick warm-up, taken when the energy from before it is below quick_thr x the energy inside it
+    uint32_t Wq2;           // medium warm-up, taken when the window is merely alive (no parked stretch); then Ws, then W
+    float quick_thr;
+    uint32_t pad2[3];
 };
 
 // ---- build-defined sinc resampler (stands in for the un-vendored rubato crate; DESIGN.md "Resampler") ----

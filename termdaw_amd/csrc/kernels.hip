@@ -443,6 +443,38 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
             if ((m0 | 3u) < M) gstore4(d.out_q4 + m0, q0);
             if ((m1 | 3u) < M) gstore4(d.out_q4 + m1, q1);
         }
+        if (d.rp && !quad_map) {
+            // block responses for k_band_spec's warm-up guess (BandRespParam): weights gamma (1 - gamma)^(255 - i) in double
+            // by binary powers, the lane's four frames, then a fixed-order sum over the block's 128 lanes
+            const BandRespParam& rp = *d.rp;
+            const uint32_t i0 = (2u * threadIdx.x) & 255u;      // in-block index of the lane's first frame (even)
+            const uint32_t k1 = 254u - i0;                      // exponent of the second frame; the first has k1 + 1
+            double pl = 1.0, ph = 1.0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if ((k1 >> j) & 1u) { pl *= rp.ql[j]; ph *= rp.qh[j]; }
+            const double wl1 = rp.gl * pl, wl0 = wl1 * rp.ql[0], wh1 = rp.gh * ph, wh0 = wh1 * rp.qh[0];
+            double v[8] = {wl0 * (double)a0.x + wl1 * (double)a0.z, wl0 * (double)a0.y + wl1 * (double)a0.w,
+                           wh0 * (double)a0.x + wh1 * (double)a0.z, wh0 * (double)a0.y + wh1 * (double)a0.w,
+                           wl0 * (double)a1.x + wl1 * (double)a1.z, wl0 * (double)a1.y + wl1 * (double)a1.w,
+                           wh0 * (double)a1.x + wh1 * (double)a1.z, wh0 * (double)a1.y + wh1 * (double)a1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) v[e] += __shfl_xor(v[e], off, 64);
+            __shared__ double rs[kThreads / 64][8];
+            if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rs[threadIdx.x >> 6][e] = v[e];
+            }
+            __syncthreads();
+            if (threadIdx.x < 16u) {
+                const uint32_t blk_in_tile = threadIdx.x >> 2, chain = threadIdx.x & 3u;   // blocks 0, 1: first pair; 2, 3: second pair
+                const uint32_t w0 = (blk_in_tile & 1u) * 2u, e = (blk_in_tile >> 1) * 4u + chain;
+                const uint32_t blk = blockIdx.x * 4u + blk_in_tile;
+                if (blk * 256u < M) rp.resp[4u * blk + chain] = rs[w0][e] + rs[w0 + 1u][e];
+            }
+        }
         // Liveness of the tile's four 256-frame blocks (threads 0..127 / 128..255 x first / second frame pair):
         // the block's absolute peak, or -1 when every frame of the block is bit-identical (a held constant
         // parks the filter state just like silence does).
@@ -1188,10 +1220,26 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     const bool pk_lds = pk_cnt <= 1024u && d.Ws < d.W;
     if (pk_lds)
         for (uint32_t i = threadIdx.x; i < pk_cnt; i += kThreads) pk_l[i] = d.blk_peaks[pk_base + i];
+    // ... and so are the block responses of the warm-up guess: the quick windows of the workgroup's 64 neighbouring
+    // segments end at consecutive blocks, each looks Kmax blocks back (<= 63 + 256 blocks of 4 doubles)
+    __shared__ double resp_l[(kThreads / 4 + 256) * 4];
+    const uint32_t Kmax = max(d.Kl, d.Kh), wq_blk = d.Wq >> 8, wq2_blk = max(d.Wq, d.Wq2) >> 8;
+    uint32_t rs_base = 0u, rs_cnt = 0u;
+    if (d.resp && seg_last * s256 > wq_blk) {
+        const uint32_t hi_blk = seg_last * s256 - wq_blk;                                  // one past the last block any window needs
+        const uint32_t lo_seg_blk = seg_first * s256 > wq2_blk ? seg_first * s256 - wq2_blk : 0u;
+        rs_base = lo_seg_blk > Kmax ? lo_seg_blk - Kmax : 0u;
+        rs_cnt = min(hi_blk - rs_base, (uint32_t)(kThreads / 4 + 256));
+        for (uint32_t i = threadIdx.x; i < rs_cnt * 4u; i += kThreads) resp_l[i] = d.resp[rs_base * 4u + i];
+    }
     __syncthreads();
     auto blk_peak = [&](uint32_t b) -> float { return pk_lds ? pk_l[b - pk_base] : d.blk_peaks[b]; };
-    if (d.Ws < d.W && start > d.Ws) {
-        const uint32_t nw = d.Ws / 256u, b1 = start / 256u, b0 = b1 - nw, bA = b0 > nw ? b0 - nw : 0u;
+    // window_live(w, strict): may the warm-up be the w frames before the segment?  (quad-uniform)  strict: the energy
+    // criterion above, for a warm-up that starts from a wrong value; a warm-up that starts from the block-response guess
+    // already carries everything before the window exactly and only needs the window to be alive (no parked stretch).
+    auto window_live = [&](uint32_t w, float thr) -> bool {
+        if (!(start > w)) return false;
+        const uint32_t nw = w / 256u, b1 = start / 256u, b0 = b1 - nw, bA = b0 > nw ? b0 - nw : 0u;
         // (near the chunk start the history before the window is the carried state itself, decayed to here)
         const float A0 = bA == 0u ? fabsf(y_true0) * __expf(-d.gmin * (float)start) : 0.0f;
         float A = 0.0f, B = 0.0f, tail_min = 1.0f;
@@ -1212,7 +1260,18 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         A = fmaxf(fmaxf(quad_bcast<0>(A), quad_bcast<1>(A)), fmaxf(quad_bcast<2>(A), quad_bcast<3>(A)));
         B = fmaxf(fmaxf(quad_bcast<0>(B), quad_bcast<1>(B)), fmaxf(quad_bcast<2>(B), quad_bcast<3>(B)));
         tail_min = fminf(fminf(quad_bcast<0>(tail_min), quad_bcast<1>(tail_min)), fminf(quad_bcast<2>(tail_min), quad_bcast<3>(tail_min)));
-        if (tail_min >= 0.0f && B >= 1e-30f && A <= B * d.live_thr) my_w = d.Ws;
+        return tail_min >= 0.0f && B >= 1e-30f && A <= B * thr;
+    };
+    if (d.Ws < d.W) {
+        // with block responses the quick window is tried first (its own, shorter, liveness windows), then the short one
+        // What a warm-up from the guess still has to outlast is the rounding residue of louder times: the true f32 state
+        // carries ~2^-24 of everything it ever held, decaying like the state itself, and exact arithmetic knows nothing
+        // of it.  Quick window: the energy from before it is small against the energy inside (quick_thr, ~2^24 x the
+        // garbage-guess threshold); medium window: long enough for 8 decades of level drop (measured on the 84-stage
+        // chain); both need the window alive.
+        if (d.resp && d.Wq < d.Ws && window_live(d.Wq, d.quick_thr)) my_w = d.Wq;
+        else if (d.resp && d.Wq2 < d.Ws && window_live(d.Wq2, 3.0e38f)) my_w = d.Wq2;
+        else if (window_live(d.Ws, d.live_thr)) my_w = d.Ws;
     }
     // Every lane of the wave walks the same number of steps -- the longest warm-up any of its quads picked (a
     // longer warm-up than needed never hurts) -- over its OWN window [start - w, start).  Quads whose window is
@@ -1222,8 +1281,40 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     for (int off = 32; off > 0; off >>= 1) w_wave = max(w_wave, (uint32_t)__shfl_xor((int)w_wave, off, 64));
     const uint32_t my_begin = start > w_wave ? start - w_wave : 0u;
     uint32_t n = my_begin;
-    // exact state at frame 0, constant chain, or the guess
-    float y = (my_begin == 0u || gam == 0.0f) ? y_true0 : gload1(xf + 2u * my_begin + ch);
+    // exact state at frame 0, constant chain, or a guess.  With block responses (BandRespParam) the guess is the
+    // exact-arithmetic state at the window start -- the responses of the last K blocks chained in double -- which
+    // the true f32 trajectory only leaves by its own accumulated rounding (a few ulp): the quick warm-up Wq then only
+    // has to let the two trajectories MEET (a gap of an ulp closes with probability gamma per step), not to forget a
+    // wrong starting value first.  Without them the guess is the input frame itself.
+    float y;
+    if (my_begin == 0u || gam == 0.0f) {
+        y = y_true0;
+    } else if (d.resp && (my_begin & 255u) == 0u) {
+        const double A = (c & 2u) ? d.Ah : d.Al;
+        const uint32_t K = (c & 2u) ? d.Kh : d.Kl;
+        const uint32_t nblk = my_begin >> 8, first = nblk > K ? nblk - K : 0u;
+        double yd = first == 0u ? (double)y_true0 : 0.0;
+        if (first >= rs_base && nblk <= rs_base + rs_cnt) {
+            const double* rl = resp_l + (size_t)(first - rs_base) * 4u + c;
+            uint32_t b = first;
+            for (; b + 4u <= nblk; b += 4u, rl += 16) {   // (four independent LDS reads per trip)
+                const double r0 = rl[0], r1 = rl[4], r2 = rl[8], r3 = rl[12];
+                yd = yd * A + r0; yd = yd * A + r1; yd = yd * A + r2; yd = yd * A + r3;
+            }
+            for (; b < nblk; ++b, rl += 4) yd = yd * A + rl[0];
+        } else {   // (a window other than the quick one: straight from memory)
+            const double* rg = d.resp + (size_t)first * 4u + c;
+            uint32_t b = first;
+            for (; b + 4u <= nblk; b += 4u, rg += 16) {
+                const double r0 = rg[0], r1 = rg[4], r2 = rg[8], r3 = rg[12];
+                yd = yd * A + r0; yd = yd * A + r1; yd = yd * A + r2; yd = yd * A + r3;
+            }
+            for (; b < nblk; ++b, rg += 4) yd = yd * A + rg[0];
+        }
+        y = (float)yd;
+    } else {
+        y = gload1(xf + 2u * my_begin + ch);
+    }
     if (n + 32u <= start && (n & 31u) == 0u) {
         // three register sets in rotation (no copies): each batch of 32 steps runs on loads issued two batches
         // (~0.5 us) earlier -- every quad streams its own window, mostly out of L2

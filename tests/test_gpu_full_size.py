@@ -78,3 +78,23 @@ def test_config4_full_60s(gpu_api, oracle):
     p = W.config4()
     assert p.cs == 2813
     assert_bit_exact(p.render(gpu_api), p.render(oracle))
+
+
+def test_band_pass_over_f32_loops_on_a_long_timeline(gpu_api, oracle):
+    """A band-pass whose only inputs are inlined f32 looping sources (24-bit assets have no packed form) on a timeline
+    long enough for the wide all-loop sum kernels: its input sum (planar copy + 256-frame liveness) must still come
+    from the pair-mapped kernel."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(42.0)
+    for k in range(3):
+        pcm = W.noise_int16(820 + k, 5003 + 411 * k).astype(np.int32) * 256 + (k + 1)
+        p.assets["s%d" % k] = W.Asset(pcm, bits=24)
+        p.load_sample("s%d" % k, "s%d" % k, "")
+        p.add_sampleloop("v%d" % k, 0.4 + 0.2 * k, -30.0 + 30.0 * k, "s%d" % k)
+    p.add_bandpass("bp", 1.0, 0.0, 1.0, 120.0, 7000.0, True)
+    p.add_normalize("out", 1.0, 0.0)
+    for k in range(3):
+        p.connect("v%d" % k, "bp")
+    p.connect("bp", "out")
+    p.set_output("out")
+    assert_bit_exact(p.render(gpu_api), p.render(oracle))
