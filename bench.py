@@ -70,7 +70,7 @@ def ubench():
         subprocess.check_call(["make", "-C", d, "-s"])
     L = ctypes.CDLL(so)
     L.td_ubench_gather.restype = ctypes.c_float
-    L.td_ubench_gather.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    L.td_ubench_gather.argtypes = [ctypes.POINTER(ctypes.c_uint32), ctypes.c_int, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.td_ubench_stream.restype = ctypes.c_float
     L.td_ubench_stream.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.td_ubench_valu_chain_ns.restype = ctypes.c_float
@@ -399,9 +399,13 @@ def main():
         gather_ms = gather_l2_ms = stream_ms = None
         if ub is not None and fused and packed:
             lp = lens.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
-            gather_ms = float(ub.td_ubench_gather(lp, N_SRC, frames, nq, 20, P))
+            gx = (frames + 1024 * nq - 1) // (1024 * nq)
+            per = max(1, (256 * 4) // gx)                     # the engine's batch slicing (launch_sum, kernels.hip)
+            it = 20 if P == 1 else 5
+            gather_ms = min(float(ub.td_ubench_gather(lp, N_SRC, frames, nq, it, P, per)), float(ub.td_ubench_gather(lp, N_SRC, frames, nq, it, P, 0)))
             small = np.full(N_SRC, 1021, dtype=np.uint32)     # 64 x 4 KB: resident in every XCD's L2 (and mostly in L1)
-            gather_l2_ms = float(ub.td_ubench_gather(small.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), N_SRC, frames, nq, 20, P))
+            sp = small.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+            gather_l2_ms = min(float(ub.td_ubench_gather(sp, N_SRC, frames, nq, it, P, per)), float(ub.td_ubench_gather(sp, N_SRC, frames, nq, it, P, 0)))
         if ub is not None:
             stream_ms = float(ub.td_ubench_stream(frames, 1, 1, 20))
         tp = profiled("pmc_summary") or {}

@@ -862,6 +862,42 @@ TD_DEV uint32_t find_interval(const IntervalTab& tab, uint32_t m) {
 
 constexpr float kPi = 3.14159274101257324f;   // core::f32::consts::PI
 
+// sin of an f32 argument of any size, for the tolerance-class kernels (debug_sine, synth: <= 1e-6 RMS against the
+// oracle's glibc sinf).  The argument itself is rounded exactly like the reference rounds it (`time * hz * 2.0 * PI`,
+// extensions.rs:450,501 -- it reaches ~1e6 rad); the range reduction is exact enough in double (|n| <= 2e5 turns, 2 pi
+// to 1e-16: < 1e-10 rad), folded to a quarter turn there, and the quarter is a degree-11 odd polynomial in f32
+// (truncation 6e-8 at pi/2).  ~25 instructions instead of the ~100 of ocml's sinf with its Payne-Hanek path.
+TD_DEV float sin_any(float arg) {
+    const double t = (double)arg * 0.15915494309189533577;   // turns
+    double f = t - rint(t);                                  // [-0.5, 0.5]
+    if (fabs(f) > 0.25) f = copysign(0.5, f) - f;            // sin(pi - x) = sin(x): [-0.25, 0.25], exact
+    const float r = (float)(f * 6.28318530717958647692);     // [-pi/2, pi/2]
+    const float r2 = r * r;
+    float p = -2.5052108385441718775e-8f;                    // -1/11!
+    p = p * r2 + 2.7557319223985890653e-6f;                  //  1/9!
+    p = p * r2 - 1.9841269841269841270e-4f;                  // -1/7!
+    p = p * r2 + 8.3333333333333333333e-3f;                  //  1/5!
+    p = p * r2 - 1.6666666666666666667e-1f;                  // -1/3!
+    return r + r * (r2 * p);
+}
+// x / y for the same kernels: v_rcp_f32 + multiply (1 ulp) instead of the 10-instruction IEEE division.  0 / 0 is still
+// NaN and t / 0 still +-inf (quirk Q6's cases).
+TD_DEV float fdiv_fast(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
+TD_DEV float ads_internal_fast(const AdsrConfD& c, float t) {   // adsr.rs:46-60
+    if (t <= c.attack_sec) return lerpf(c.std_vel, c.attack_vel, fdiv_fast(t, c.attack_sec));
+    if (t <= c.attack_sec + c.decay_sec) return lerpf(c.attack_vel, c.decay_vel, fdiv_fast(t - c.attack_sec, c.decay_sec));
+    if (t <= c.attack_sec + c.decay_sec + c.sustain_sec)
+        return lerpf(c.decay_vel, c.sustain_vel, fdiv_fast(t - c.attack_sec - c.decay_sec, c.sustain_sec));
+    return -1000.0f;
+}
+TD_DEV float apply_ads_fast(const AdsrConfD& c, float t) {
+    const float res = ads_internal_fast(c, t);
+    return res <= -1.0f ? c.sustain_vel : res;
+}
+TD_DEV float apply_r_rt_fast(const AdsrConfD& c, float t, float rt) {   // adsr.rs:71-73, 89-92
+    return lerpf(apply_ads_fast(c, rt), c.release_vel, fminf(fdiv_fast(t, c.release_sec), 1.0f));
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_debug_sine (extensions.rs:423-457)
 // ------------------------------------------------------------------------------------------------
@@ -872,7 +908,7 @@ TD_DEV float sine_frame(const SineDesc& d, uint32_t m) {
     float acc = 0.0f;
     for (uint32_t v = v0; v < v1; ++v) {
         const float4 nv = d.tab.voices[v];   // (hz, vel)
-        acc += sinf(time * nv.x * 2.0f * kPi) * nv.y;
+        acc += sin_any(time * nv.x * 2.0f * kPi) * nv.y;
     }
     return acc;
 }
@@ -906,25 +942,25 @@ TD_DEV float synth_frame(const SynthDesc& d, uint32_t m) {
         float s = 0.0f;
         float sn = 0.0f;
         float env_sq = 0.0f, env_tf = 0.0f;
-        if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sinf(time * hz * 2.0f * kPi);
+        if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any(time * hz * 2.0f * kPi);
         if (d.square.volume > 0.0f) {
             const float z = d.square.param;
             const float osc = fminf(fmaxf(sn, -z), z) * (1.0f / z);
-            env_sq = rel_t == 0.0f ? apply_ads(d.square.adsr, env_time) : apply_r_rt(d.square.adsr, env_time, rel_t);
+            env_sq = rel_t == 0.0f ? apply_ads_fast(d.square.adsr, env_time) : apply_r_rt_fast(d.square.adsr, env_time, rel_t);
             s += osc * vel * env_sq * d.square.volume;
         }
         if (d.topflat.volume > 0.0f) {
             const float z = d.topflat.param;
             const float osc = (fminf(sn, z) + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
             env_tf = d.tf_env_src == 1u ? env_sq
-                   : rel_t == 0.0f ? apply_ads(d.topflat.adsr, env_time) : apply_r_rt(d.topflat.adsr, env_time, rel_t);
+                   : rel_t == 0.0f ? apply_ads_fast(d.topflat.adsr, env_time) : apply_r_rt_fast(d.topflat.adsr, env_time, rel_t);
             s += osc * vel * env_tf * d.topflat.volume;
         }
         if (d.triangle.volume > 0.0f) {
             const float th = time * hz;
             const float osc = 4.0f * fabsf(th - floorf(th + 0.5f)) - 1.0f;
             const float env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf
-                            : rel_t == 0.0f ? apply_ads(d.triangle.adsr, env_time) : apply_r_rt(d.triangle.adsr, env_time, rel_t);
+                            : rel_t == 0.0f ? apply_ads_fast(d.triangle.adsr, env_time) : apply_r_rt_fast(d.triangle.adsr, env_time, rel_t);
             s += osc * vel * env * d.triangle.volume;
         }
         s *= d.osc_amp_multiplier;
@@ -1880,6 +1916,7 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
     static const int forced_nq = getenv("TD_FORCE_NQ") ? atoi(getenv("TD_FORCE_NQ")) : 0;   // tuning aid: 1 | 2 | 4
+    static const int slice_env = getenv("TD_SUM_SLICE") ? atoi(getenv("TD_SUM_SLICE")) : 0;  // tuning aid: projects per launch slice
     switch (term_mode) {
         case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         case TERMS_ALL_LOOP32:
@@ -1897,10 +1934,23 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
             // (measured on config-2-like renders of 3 .. 300 s, tools/nq_sweep.py: below ~1 800 tiles the narrow form wins --
             // a wide workgroup's own serial walk over the sources, ~55 us for 64 of them at 16 frames per lane, is then
             // the whole launch; 8 per lane pays from ~1 800 tiles, 16 per lane from ~2 600)
-            if (wide_ok && (forced_nq ? forced_nq == 4 : frames >= 2600u * kTileFrames))
-                TD_BATCHED(HIP_KERNEL_NAME(k_sum16w<4>), (frames + kTileFrames * 4 - 1) / (kTileFrames * 4), kThreads, d, n, frames);
-            else if (wide_ok && (forced_nq ? forced_nq == 2 : frames >= 1800u * kTileFrames))
-                TD_BATCHED(HIP_KERNEL_NAME(k_sum16w<2>), (frames + kTileFrames * 2 - 1) / (kTileFrames * 2), kThreads, d, n, frames);
+            // Batched launches (td_batch: n descriptors = n projects) go out in slices of about four workgroups per CU -- one
+            // project per launch at config 2's size: the workgroups of a slice start together and walk the sources in step,
+            // so every source table is gathered by all of them while it sits in L2 (hit rate ~75 %), exactly like the
+            // single-project launch.  One grid over 64 projects instead staggers the workgroups over all 64 source indices:
+            // 0.080 ms per project against 0.0685 sliced (2 / 3 / 4 projects per slice: 0.074 / 0.077 / 0.074; tools/ubench's
+            // bare gather shows the same loss, so it is the access pattern, not the arithmetic).
+            if (wide_ok && (forced_nq ? forced_nq == 4 : frames >= 2600u * kTileFrames)) {
+                const uint32_t gx = (frames + kTileFrames * 4 - 1) / (kTileFrames * 4);
+                const int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
+                for (int o = 0; o < n; o += per)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<4>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+            } else if (wide_ok && (forced_nq ? forced_nq == 2 : frames >= 1800u * kTileFrames)) {
+                const uint32_t gx = (frames + kTileFrames * 2 - 1) / (kTileFrames * 2);
+                const int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
+                for (int o = 0; o < n; o += per)
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<2>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+            }
             else
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb);
             break;

@@ -124,15 +124,22 @@ __global__ void k_fill(uint32_t* p, size_t n, uint32_t salt) {
     }
 }
 
+// `per` table sets per launch (0: all n_sets in one grid), the rest in further launches -- the engine's batch slicing
 template <int NQ, int B>
-float time_gather(const Tab* d_tabs, int k, uint32_t frames, float* d_out, int iters, int n_sets) {
-    const dim3 grid((frames + 1024u * NQ - 1) / (1024u * NQ), n_sets);
+float time_gather(const Tab* d_tabs, int k, uint32_t frames, float* d_out, int iters, int n_sets, int per) {
+    const uint32_t gx = (frames + 1024u * NQ - 1) / (1024u * NQ);
+    if (per <= 0 || per > n_sets) per = n_sets;
+    auto pass = [&]() {
+        for (int o = 0; o < n_sets; o += per)
+            hipLaunchKernelGGL((k_gather<NQ, B>), dim3(gx, std::min(per, n_sets - o)), dim3(256), 0, 0, d_tabs + (size_t)o * k, k, frames,
+                               d_out + (size_t)o * 2 * ((size_t)frames + 64));
+    };
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((k_gather<NQ, B>), grid, dim3(256), 0, 0, d_tabs, k, frames, d_out);
+    for (int w = 0; w < 3; ++w) pass();
     hipEventRecord(e0, 0);
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((k_gather<NQ, B>), grid, dim3(256), 0, 0, d_tabs, k, frames, d_out);
+    for (int i = 0; i < iters; ++i) pass();
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -147,10 +154,10 @@ float time_gather(const Tab* d_tabs, int k, uint32_t frames, float* d_out, int i
 extern "C" {
 
 // lens[k]: loop lengths in frames (= packed 32-bit words) of ONE project; n_sets projects (each with its own tables of
-// those lengths, grid.y = n_sets, like a batch launch).  frames: timeline length.  nq: 1 | 2 | 4 (4 * nq consecutive
+// those lengths, `per` of them per launch like a batch submission; 0 = all in one grid).  frames: timeline length.  nq: 1 | 2 | 4 (4 * nq consecutive
 // frames per lane, as the engine's k_sum<loop16> / k_sum16w<2> / k_sum16w<4>).  Returns the best (smallest) average
 // ms per launch over the issue variants (1, 2 or 4 sources' gathers in flight before the first use), < 0 on failure.
-float td_ubench_gather(const uint32_t* lens, int k, uint32_t frames, int nq, int iters, int n_sets) {
+float td_ubench_gather(const uint32_t* lens, int k, uint32_t frames, int nq, int iters, int n_sets, int per) {
     if (k <= 0 || frames == 0 || iters <= 0 || n_sets <= 0) return -1.f;
     std::vector<Tab> tabs((size_t)k * n_sets);
     size_t words_set = 0;
@@ -172,9 +179,9 @@ float td_ubench_gather(const uint32_t* lens, int k, uint32_t frames, int nq, int
             }
         if (hipMemcpy(d_tabs, tabs.data(), sizeof(Tab) * tabs.size(), hipMemcpyHostToDevice) == hipSuccess) {
             float t[3] = {0, 0, 0};
-            if (nq == 4) { t[0] = time_gather<4, 1>(d_tabs, k, frames, d_out, iters, n_sets); t[1] = time_gather<4, 2>(d_tabs, k, frames, d_out, iters, n_sets); t[2] = time_gather<4, 4>(d_tabs, k, frames, d_out, iters, n_sets); }
-            else if (nq == 2) { t[0] = time_gather<2, 1>(d_tabs, k, frames, d_out, iters, n_sets); t[1] = time_gather<2, 2>(d_tabs, k, frames, d_out, iters, n_sets); t[2] = time_gather<2, 4>(d_tabs, k, frames, d_out, iters, n_sets); }
-            else { t[0] = time_gather<1, 1>(d_tabs, k, frames, d_out, iters, n_sets); t[1] = time_gather<1, 2>(d_tabs, k, frames, d_out, iters, n_sets); t[2] = time_gather<1, 4>(d_tabs, k, frames, d_out, iters, n_sets); }
+            if (nq == 4) { t[0] = time_gather<4, 1>(d_tabs, k, frames, d_out, iters, n_sets, per); t[1] = time_gather<4, 2>(d_tabs, k, frames, d_out, iters, n_sets, per); t[2] = time_gather<4, 4>(d_tabs, k, frames, d_out, iters, n_sets, per); }
+            else if (nq == 2) { t[0] = time_gather<2, 1>(d_tabs, k, frames, d_out, iters, n_sets, per); t[1] = time_gather<2, 2>(d_tabs, k, frames, d_out, iters, n_sets, per); t[2] = time_gather<2, 4>(d_tabs, k, frames, d_out, iters, n_sets, per); }
+            else { t[0] = time_gather<1, 1>(d_tabs, k, frames, d_out, iters, n_sets, per); t[1] = time_gather<1, 2>(d_tabs, k, frames, d_out, iters, n_sets, per); t[2] = time_gather<1, 4>(d_tabs, k, frames, d_out, iters, n_sets, per); }
             if (hipDeviceSynchronize() == hipSuccess && hipGetLastError() == hipSuccess) best = std::min(t[0], std::min(t[1], t[2]));
         }
     }
