@@ -299,7 +299,9 @@ bool sample_from(std::vector<float> l, std::vector<float> r, LoadMethod m, Sampl
 // BlackmanHarris2) but its arithmetic, delay and output length are not.  This engine defines its own
 // resampler with those parameters (specification: DESIGN.md "Resampler"); oracle and HIP kernel implement
 // the same specification and must agree bit for bit -- neither is claimed to match rubato.
-//   out[j] = sum_{k=0..255} in[i0 - 127 + k] * c_k,   x = j * from / to = i0 + frac   (zero outside the input)
+//   out[j] = sum_{k=0..255} in[i0 - 255 + k] * c_k,   x = j * from / to = i0 + frac   (zero outside the input):
+//   the filter centre sits sinc_len / 2 = 128 input frames behind x -- rubato's SincFixedIn delays its output by that
+//   much because it only looks at frames it has been handed (state.rs:545-560 feeds it block by block, never flushes)
 //   c_k    = T[p][k] * (1 - a) + T[p+1][k] * a,        p = floor(frac * 256), a = frac * 256 - p  (f32)
 //   T[p][k] = (f32)( fc * sinc(fc * d) * bh(u)^2 ),    d = k - 127 - p/256,  u = (d + 128) / 256,
 //             fc = 0.95 * min(1, to/from),  bh = 4-term Blackman-Harris;  table in f64, rounded once
@@ -339,7 +341,7 @@ void resample_planar(const std::vector<float>& l, const std::vector<float>& r, s
         const float* t1 = &T[(p + 1) * kSincLen];
         float al = 0.0f, ar = 0.0f;
         for (int k = 0; k < kSincLen; ++k) {
-            const int64_t idx = i0 - 127 + k;
+            const int64_t idx = i0 - (127 + 128) + k;   // delayed by sinc_len / 2 input frames (SincFixedIn's output delay)
             if (idx < 0 || idx >= (int64_t)len) continue;
             const float c = t0[k] * (1.0f - a) + t1[k] * a;
             al += l[(size_t)idx] * c;

@@ -293,6 +293,12 @@ struct BandSpecDesc {
 };
 
 // ---- build-defined sinc resampler (stands in for the un-vendored rubato crate; DESIGN.md "Resampler") ----
+// Shaped like the streaming SincFixedIn the reference drives block by block (state.rs:545-560): output j sits at input
+// position j * from / to - sinc_len / 2 (the resampler's documented output delay: the filter only ever looks at frames it
+// has already been handed, history before the first frame is zeros), it is complete -- and in a block-by-block run
+// emitted -- as soon as input frame floor(j * from / to) has arrived, and nothing is flushed at the end, like the
+// reference: ceil(len * to / from) outputs.  One launch over the whole timeline computes exactly what the block-by-block
+// run with carried history would (an FIR has no other state).
 constexpr int kSincLen = 256, kSincOver = 256;
 struct ResampleDesc {
     const float2* in;

@@ -1817,7 +1817,7 @@ __global__ __launch_bounds__(kThreads) void k_resample(ResampleDesc d) {
         const float one_minus_a = 1.0f - a;
         float al = 0.0f, ar = 0.0f;
         for (int k = 0; k < kSincLen; ++k) {
-            const int64_t idx = i0 - 127 + k;
+            const int64_t idx = i0 - (127 + kSincLen / 2) + k;   // (delayed by sinc_len / 2 input frames, see kernels.h)
             if (idx < 0 || idx >= (int64_t)d.len) continue;
             const float c = t0[k] * one_minus_a + t1[k] * a;
             const float2 x = d.in[idx];
