@@ -454,25 +454,31 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
             for (int j = 0; j < 8; ++j)
                 if ((k1 >> j) & 1u) { pl *= rp.ql[j]; ph *= rp.qh[j]; }
             const double wl1 = rp.gl * pl, wl0 = wl1 * rp.ql[0], wh1 = rp.gh * ph, wh0 = wh1 * rp.qh[0];
-            double v[8] = {wl0 * (double)a0.x + wl1 * (double)a0.z, wl0 * (double)a0.y + wl1 * (double)a0.w,
-                           wh0 * (double)a0.x + wh1 * (double)a0.z, wh0 * (double)a0.y + wh1 * (double)a0.w,
-                           wl0 * (double)a1.x + wl1 * (double)a1.z, wl0 * (double)a1.y + wl1 * (double)a1.w,
-                           wh0 * (double)a1.x + wh1 * (double)a1.z, wh0 * (double)a1.y + wh1 * (double)a1.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) v[e] += __shfl_xor(v[e], off, 64);
-            __shared__ double rs[kThreads / 64][8];
-            if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) rs[threadIdx.x >> 6][e] = v[e];
+            // the lane's two frames of each of its two blocks, four chains; then a fixed-order sum over each block's 128 lanes:
+            // partials to LDS (lane-major), 32 threads add 64 of them each, 16 threads add the two halves
+            __shared__ double rs[8][kThreads + 4];
+            rs[0][threadIdx.x] = wl0 * (double)a0.x + wl1 * (double)a0.z;
+            rs[1][threadIdx.x] = wl0 * (double)a0.y + wl1 * (double)a0.w;
+            rs[2][threadIdx.x] = wh0 * (double)a0.x + wh1 * (double)a0.z;
+            rs[3][threadIdx.x] = wh0 * (double)a0.y + wh1 * (double)a0.w;
+            rs[4][threadIdx.x] = wl0 * (double)a1.x + wl1 * (double)a1.z;
+            rs[5][threadIdx.x] = wl0 * (double)a1.y + wl1 * (double)a1.w;
+            rs[6][threadIdx.x] = wh0 * (double)a1.x + wh1 * (double)a1.z;
+            rs[7][threadIdx.x] = wh0 * (double)a1.y + wh1 * (double)a1.w;
+            __syncthreads();
+            __shared__ double rh[8][4];
+            if (threadIdx.x < 32u) {   // e = value index (0..7), q = quarter of the workgroup (64 lanes)
+                const uint32_t e = threadIdx.x >> 2, q = threadIdx.x & 3u;
+                double acc = 0.0;
+                for (uint32_t i = 0; i < 64u; ++i) acc += rs[e][q * 64u + i];
+                rh[e][q] = acc;
             }
             __syncthreads();
             if (threadIdx.x < 16u) {
                 const uint32_t blk_in_tile = threadIdx.x >> 2, chain = threadIdx.x & 3u;   // blocks 0, 1: first pair; 2, 3: second pair
-                const uint32_t w0 = (blk_in_tile & 1u) * 2u, e = (blk_in_tile >> 1) * 4u + chain;
+                const uint32_t q0 = (blk_in_tile & 1u) * 2u, e = (blk_in_tile >> 1) * 4u + chain;
                 const uint32_t blk = blockIdx.x * 4u + blk_in_tile;
-                if (blk * 256u < M) rp.resp[4u * blk + chain] = rs[w0][e] + rs[w0 + 1u][e];
+                if (blk * 256u < M) rp.resp[4u * blk + chain] = rh[e][q0] + rh[e][q0 + 1u];
             }
         }
         // Liveness of the tile's four 256-frame blocks (threads 0..127 / 128..255 x first / second frame pair):

@@ -98,3 +98,40 @@ def test_band_pass_over_f32_loops_on_a_long_timeline(gpu_api, oracle):
     p.connect("bp", "out")
     p.set_output("out")
     assert_bit_exact(p.render(gpu_api), p.render(oracle))
+
+
+@pytest.mark.parametrize("chunk", [0, 50000])
+@pytest.mark.parametrize("lo,hi", [(20.0, 18000.0), (35.0, 0.0), (0.0, 60.0)])
+def test_low_cutoff_band_pass_with_block_response_guess(gpu_api, oracle, lo, hi, chunk):
+    """Cut-offs below ~75 Hz start the speculative warm-up from the block-response guess (quick / medium windows):
+    stationary noise, gated noise (level drops of many decades between bursts) and chunked renders (the guess then
+    chains onto the carried filter state) must all stay bit-exact; the quick windows must not cost repairs on noise."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(20.0)
+    p.assets["a"] = W.Asset(W.noise_int16(5, 77777))
+    p.load_sample("a", "a", "")
+    p.add_sampleloop("l", 0.5, 0.0, "a")
+    p.event_files["g"] = np.array([(0.7 * i + 0.05, 60.0, 0.9) for i in range(28)], np.float32)
+    p.load_midi_floww("g", "g")
+    p.add_adsr("gate", 1.0, 0.0, 1.0, "g", False, True, -1, [0.005, 0.02, 0.3, 0.05, 0.0, 0.01])   # falls to exact zero between hits
+    p.add_bandpass("bp", 1.0, 0.0, 1.0, lo, hi, True)
+    p.add_bandpass("bq", 1.1, 5.0, 1.0, lo, hi, False)
+    p.add_sum("mix", 1.0, 0.0)
+    p.add_normalize("out", 1.0, 0.0)
+    p.connect("l", "bp")
+    p.connect("l", "gate")
+    p.connect("gate", "bq")
+    p.connect("bp", "mix")
+    p.connect("bq", "mix")
+    p.connect("mix", "out")
+    p.set_output("out")
+    built = p.build(gpu_api)
+    if chunk:
+        built[2].set_option("max_chunk_frames", chunk)
+    obuilt = p.build(oracle)
+    for _ in range(2):
+        assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
+    # the same with the guess switched off: same bytes
+    b2 = p.build(gpu_api)
+    b2[2].set_option("band_quick", 0)
+    assert_bit_exact(p.render(gpu_api, built=b2), p.render(oracle))
