@@ -43,7 +43,6 @@ def main(argv=None):
         s.scan_exact()
     s.render(args.output)
     t2 = time.perf_counter()
-    frames = s.cs * 1024
     print("Ok: rendered %d blocks to %s (%d-bit, %d Hz): load %.1f ms, render+write %.1f ms"
           % (s.cs, args.output or s.output_file, s.bd, s.render_sr, (t1 - t0) * 1e3, (t2 - t1) * 1e3))
     return 0
@@ -104,7 +103,9 @@ def stream(s, args, lines=None):
     q = np.nan_to_num(f.astype(np.float32) * np.float32(32767.0), nan=0.0, posinf=32767.0, neginf=-32768.0)
     pcm = np.clip(np.trunc(q), -32768, 32767).astype(np.int16)
     out = args.output or s.output_file
-    write_wav_int16(out, pcm, s.render_sr)
+    # the pulled blocks are at the PROJECT rate (the stream workflow plays them as they are, stream_workflow.rs:92-101):
+    # the header carries that rate, never set_render_samplerate()'s
+    write_wav_int16(out, pcm, sr)
     print("Ok: streamed %d blocks (%.2f s) to %s in %.1f ms" % (len(blocks), len(blocks) * bl / sr, out,
                                                                (time.perf_counter() - t_start) * 1e3))
     return 0
