@@ -935,57 +935,80 @@ __global__ __launch_bounds__(kThreads) void k_debug_sine(const SineDesc* __restr
 // ------------------------------------------------------------------------------------------------
 // k_synth (extensions.rs:460-529, synth.rs:21-34)
 // ------------------------------------------------------------------------------------------------
+// one voice, one frame: oscillators x velocity x envelope x volume (extensions.rs:499-524)
+TD_DEV float synth_voice(const SynthDesc& d, const float4 n, float time, float off) {   // n = (hz, vel, env_t, rel_t)
+    const float hz = n.x, vel = n.y, rel_t = n.w;
+    const float env_time = n.z + off;
+    float s = 0.0f;
+    float sn = 0.0f;
+    float env_sq = 0.0f, env_tf = 0.0f;
+    if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any(time * hz * 2.0f * kPi);
+    if (d.square.volume > 0.0f) {
+        const float z = d.square.param;
+        const float osc = fminf(fmaxf(sn, -z), z) * (1.0f / z);
+        env_sq = rel_t == 0.0f ? apply_ads_fast(d.square.adsr, env_time) : apply_r_rt_fast(d.square.adsr, env_time, rel_t);
+        s += osc * vel * env_sq * d.square.volume;
+    }
+    if (d.topflat.volume > 0.0f) {
+        const float z = d.topflat.param;
+        const float osc = (fminf(sn, z) + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
+        env_tf = d.tf_env_src == 1u ? env_sq
+               : rel_t == 0.0f ? apply_ads_fast(d.topflat.adsr, env_time) : apply_r_rt_fast(d.topflat.adsr, env_time, rel_t);
+        s += osc * vel * env_tf * d.topflat.volume;
+    }
+    if (d.triangle.volume > 0.0f) {
+        const float th = time * hz;
+        const float osc = 4.0f * fabsf(th - floorf(th + 0.5f)) - 1.0f;
+        const float env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf
+                        : rel_t == 0.0f ? apply_ads_fast(d.triangle.adsr, env_time) : apply_r_rt_fast(d.triangle.adsr, env_time, rel_t);
+        s += osc * vel * env * d.triangle.volume;
+    }
+    return s * d.osc_amp_multiplier;
+}
 TD_DEV float synth_frame(const SynthDesc& d, uint32_t m) {
     const uint32_t it = find_interval(d.tab, m);
     const uint32_t v0 = d.tab.ivoff[it], v1 = d.tab.ivoff[it + 1];
     const float time = (float)(d.t0 + m) / (float)d.sr;
     const float off = (float)(m % d.bl) / (float)d.sr;
     float acc = 0.0f;
-    for (uint32_t v = v0; v < v1; ++v) {
-        const float4 n = d.tab.voices[v];   // (hz, vel, env_t, rel_t)
-        const float hz = n.x, vel = n.y, rel_t = n.w;
-        const float env_time = n.z + off;
-        float s = 0.0f;
-        float sn = 0.0f;
-        float env_sq = 0.0f, env_tf = 0.0f;
-        if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any(time * hz * 2.0f * kPi);
-        if (d.square.volume > 0.0f) {
-            const float z = d.square.param;
-            const float osc = fminf(fmaxf(sn, -z), z) * (1.0f / z);
-            env_sq = rel_t == 0.0f ? apply_ads_fast(d.square.adsr, env_time) : apply_r_rt_fast(d.square.adsr, env_time, rel_t);
-            s += osc * vel * env_sq * d.square.volume;
-        }
-        if (d.topflat.volume > 0.0f) {
-            const float z = d.topflat.param;
-            const float osc = (fminf(sn, z) + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
-            env_tf = d.tf_env_src == 1u ? env_sq
-                   : rel_t == 0.0f ? apply_ads_fast(d.topflat.adsr, env_time) : apply_r_rt_fast(d.topflat.adsr, env_time, rel_t);
-            s += osc * vel * env_tf * d.topflat.volume;
-        }
-        if (d.triangle.volume > 0.0f) {
-            const float th = time * hz;
-            const float osc = 4.0f * fabsf(th - floorf(th + 0.5f)) - 1.0f;
-            const float env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf
-                            : rel_t == 0.0f ? apply_ads_fast(d.triangle.adsr, env_time) : apply_r_rt_fast(d.triangle.adsr, env_time, rel_t);
-            s += osc * vel * env * d.triangle.volume;
-        }
-        s *= d.osc_amp_multiplier;
-        acc += s;
-    }
+    for (uint32_t v = v0; v < v1; ++v) acc += synth_voice(d, d.tab.voices[v], time, off);
     return acc;
+}
+// The lane's frame pair m, m + 1.  A wave's 128 frames nearly always lie in ONE interval (intervals start at block
+// starts and event frames): the voice list is then the same for every lane, the voice records come in through scalar
+// loads (constant address space) and both frames share one pass over the voices.  A wave that straddles an interval
+// start takes the per-lane form.
+TD_DEV float2 synth_pair(const SynthDesc& d, uint32_t m, uint32_t M) {
+    const bool two = m + 1u < M;
+    const uint32_t ita = find_interval(d.tab, m), itb = two ? find_interval(d.tab, m + 1u) : ita;
+    const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ita);
+    if (__all((ita == it0 && itb == it0) ? 1 : 0)) {
+        const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
+        const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
+        typedef float f4c __attribute__((ext_vector_type(4)));
+        const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
+        const float ta = (float)(d.t0 + m) / (float)d.sr, tb = (float)(d.t0 + m + 1u) / (float)d.sr;
+        const float oa = (float)(m % d.bl) / (float)d.sr, ob = (float)((m + 1u) % d.bl) / (float)d.sr;
+        float a = 0.0f, b = 0.0f;
+        for (uint32_t v = v0; v < v1; ++v) {
+            const f4c q = vc[v];
+            const float4 n = make_float4(q.x, q.y, q.z, q.w);
+            a += synth_voice(d, n, ta, oa);
+            b += synth_voice(d, n, tb, ob);
+        }
+        return make_float2(a, two ? b : 0.0f);
+    }
+    return make_float2(synth_frame(d, m), two ? synth_frame(d, m + 1u) : 0.0f);
 }
 __global__ __launch_bounds__(kThreads) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
     const SynthDesc& d = descs[blockIdx.y];
     const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
-    if (m0 < M) {
-        float a = synth_frame(d, m0), b = (m0 + 1 < M) ? synth_frame(d, m0 + 1) : 0.0f;
-        store_pair(d.out, m0, M, epilogue4(make_float4(a, a, b, b), d.pg));
-    }
-    if (m1 < M) {
-        float a = synth_frame(d, m1), b = (m1 + 1 < M) ? synth_frame(d, m1 + 1) : 0.0f;
-        store_pair(d.out, m1, M, epilogue4(make_float4(a, a, b, b), d.pg));
-    }
+    // (frames at or beyond M are computed on clamped indices and not stored: the uniform-interval test needs whole waves)
+    const uint32_t mc0 = min(m0, M - 1u), mc1 = min(m1, M - 1u);
+    const float2 p0 = synth_pair(d, mc0, M), p1 = synth_pair(d, mc1, M);
+    if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(p0.x, p0.x, p0.y, p0.y), d.pg));
+    if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(p1.x, p1.x, p1.y, p1.y), d.pg));
 }
 
 // ------------------------------------------------------------------------------------------------
