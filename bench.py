@@ -292,6 +292,12 @@ def main():
         cpu_worker(args.cpu_worker, args.seconds)
         return
 
+    # Everything any library writes to stdout while the bench runs (RCCL prints a version banner through the C runtime)
+    # goes to stderr: stdout carries the ONE JSON line and nothing else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -588,13 +594,14 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    try:
+        ctypes.CDLL(None).fflush(None)   # (what the C runtime still buffers belongs to stderr too)
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if result_line is not None:
-        # RCCL writes its version banner to the C stdout buffer; flush that first so the JSON line is the
-        # last (and only JSON) line on stdout
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except Exception:   # noqa: BLE001
-            pass
         print(result_line, flush=True)
 
 

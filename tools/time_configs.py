@@ -4,20 +4,29 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from termdaw_amd import api, workloads as W
 
-def run(name, p, reps=3):
+def run(name, p, reps=None):
     sb, fb, g = p.build(api)
-    g.render_all(sb, fb, p.cs, 16, want_f32=False, want_pcm=False)
-    t0 = time.perf_counter()
-    for _ in range(reps):   # plain timing first: the per-launch HIP events of profiling mode widen the gaps
+    def render():
         g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
         g.render_all_async(sb, fb, p.cs, 16)
+    render(); g.sync()
+    # steady device clocks first (the first tens of ms after an idle period run slower), then enough renders for >= 50 ms
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < 0.2:
+        render(); n += 1
+        if n % 16 == 0: g.sync()
+    g.sync()
+    per = (time.perf_counter() - t0) / n
+    if reps is None: reps = max(3, min(5000, int(0.05 / per)))
+    t0 = time.perf_counter()
+    for _ in range(reps):   # plain timing first: the per-launch HIP events of profiling mode widen the gaps
+        render()
     g.sync()
     plain = (time.perf_counter() - t0) / reps
     g.set_profiling(True)
     t0 = time.perf_counter()
     for _ in range(reps):
-        g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
-        g.render_all_async(sb, fb, p.cs, 16)
+        render()
     g.sync()
     dt = (time.perf_counter() - t0) / reps
     kt = g.kernel_times()
