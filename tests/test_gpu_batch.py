@@ -111,3 +111,33 @@ def test_batch_peak_table_layout(gpu_api, oracle):
     with pytest.raises(gpu_api.TermdawError):
         batch.peak_table_device(d.value, 8, first=4, stride=2)   # project 2 would land on entry 8
     hip.hipFree(d)
+
+
+def test_batch_with_chunked_members(gpu_api, oracle):
+    """Members whose timelines exceed their chunk cap render chunk after chunk inside the batch (different members finish
+    their chunks at different submissions); scanned and un-scanned, twice."""
+    mk = [lambda: W.drum_project(seconds=1.2), lambda: W.synth_project(seconds=1.2), lambda: W.config2(seconds=1.2, n_src=5),
+          lambda: W.drum_project(seconds=1.2)]
+    caps = [7000, 20000, 0, 3000]
+    exact = [True, False, True, True]
+    projects = [m() for m in mk]
+    cs = projects[0].cs
+    batch = gpu_api.Batch()
+    obuilt = []
+    for p, cap in zip(projects, caps):
+        sb, fb, g = p.build(gpu_api)
+        if cap:
+            g.set_option("max_chunk_frames", cap)
+        batch.add(sb, fb, g)
+        obuilt.append(p.build(oracle))
+    for scan in (False, True, False):
+        if scan:
+            batch.normalize_scan(cs)
+            for osb, ofb, og in obuilt:
+                og.true_normalize_scan(osb, ofb, cs)
+        batch.render_all(cs, 16)
+        for i in range(len(projects)):
+            osb, ofb, og = obuilt[i]
+            ref = og.render_all(osb, ofb, cs, 16)
+            got = (batch.read_pcm(i, cs), _f32_of(gpu_api, batch, i, cs))
+            (assert_bit_exact if exact[i] else assert_close)(got, ref)
