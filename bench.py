@@ -353,7 +353,15 @@ def main():
 
     # ---- config 5 proper beside it: 64 projects per GPU through the same path (skipped when the main region already is that) ----
     c5 = None
-    if not args.no_extras and P != 64 and not args.no_fuse and not args.no_pack:
+    want_c5 = not args.no_extras and P != 64 and not args.no_fuse and not args.no_pack
+    if want_c5:
+        # every rank must take the same branch (the section holds collectives): 64 resident projects need ~6.5 GB
+        ok = torch.tensor([1 if torch.cuda.mem_get_info()[0] > (10 << 30) else 0], dtype=torch.int32,
+                          device="cuda" if backend == "nccl" else "cpu")
+        if use_dist:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        want_c5 = bool(int(ok.item()))
+    if want_c5:
         c5_steps = max(2, min(10, args.steps))
         b64, _ = build_batch(api, workloads, rank, world, 64, args.seconds, False, False)
         dt5, kt5, pk5 = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
