@@ -11,9 +11,14 @@ def family(s):   # "void tdk::k_sum16w<4, true>(args)" -> ("k_sum", "tdk::k_sum1
     if base.startswith("k_sum"): base = "k_sum"
     return base, full
 
+def newest(pattern):
+    """Only the most recent file matching the pattern (a directory may hold the output of several runs)."""
+    fs = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return fs[-1:]
+
 def counters(d):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    for f in newest(d + "/**/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if "tdk::" not in r["Kernel_Name"]: continue
             out[family(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -21,7 +26,7 @@ def counters(d):
 
 def stats(d):
     out = {}
-    for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+    for f in newest(d + "/**/*kernel_stats.csv"):
         for r in csv.DictReader(open(f)):
             if "tdk::" not in r["Name"]: continue
             out[family(r["Name"])] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3, "total_us": float(r["TotalDurationNs"]) / 1e3,
@@ -78,7 +83,8 @@ if __name__ == "__main__":
     valu["_note"] = ("rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES, one pass per config; "
                      "per-launch averages; SQ_INSTS_VALU = wave-level VALU instructions issued")
     json.dump(valu, open("profiles/%s_valu.json" % tag, "w"), indent=1, sort_keys=True)
-    for f in glob.glob("gpurun_out/prof_%s_*/**/*kernel_stats.csv" % tag, recursive=True):
-        mode = re.search(r"prof_%s_([^/]+)" % tag, f).group(1)
-        shutil.copy(f, "profiles/%s_%s_kernel_stats.csv" % (tag, mode))
+    for d in glob.glob("gpurun_out/prof_%s_*/" % tag):
+        mode = re.search(r"prof_%s_([^/]+)" % tag, d).group(1)
+        for f in newest(d + "/**/*kernel_stats.csv"):
+            shutil.copy(f, "profiles/%s_%s_kernel_stats.csv" % (tag, mode))
     print(json.dumps({"pmc": res, "valu": valu}, indent=1)[:6000])
