@@ -188,6 +188,9 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "table_cache" 0|1 (default 1: the compiled event tables of an event-driven vertex stay on the device and are
  * reused while events, FlowwBank cursor, chunk shape and the vertex' carried state at the chunk start are unchanged;
  * identical vertices of one chunk share one set -- 0 replays the events for every vertex and render);
+ * "graph_replay" 0|1 (default 0: when 1, a submission whose uploaded bytes and launch list equal the previous one's replays
+ * the captured HIP graph of that one -- one hipGraphLaunch instead of one call per kernel; measured: host launch time of a
+ * 425-launch project 1.16 -> 0.01 ms, GPU time unchanged, short projects slower by the replay's fixed cost);
  * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
  * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */
 int td_graph_set_option(td_graph* g, const char* key, long value);

@@ -195,6 +195,10 @@ struct Arena {
     bool inflight = false;
     size_t valid = 0;          // bytes of `h` that `d` currently mirrors
     size_t device_bytes = 0;
+    // HIP-graph replay (option "graph_replay"): the launch sequence of the last submission, captured; valid while the
+    // uploaded bytes (descriptors: every pointer and parameter) and the launch list are unchanged
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uint64_t> graph_key;
 };
 
 // HIP-event timing of launch families (bench hook)
@@ -293,6 +297,7 @@ struct td_graph {
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
     bool output_f32 = true;                    // 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames
+    bool graph_replay = false;                 // replay the captured launch sequence of an unchanged submission (measured: no gain)
     bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
