@@ -1071,9 +1071,10 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
         // default.  A smoother slower than 256 blocks' worth keeps the plain warm-up.
         const double depth_nats = (double)g->band_depth;
         auto depth = [depth_nats](float gamma, double* A) -> uint32_t {
-            if (gamma == 0.0f) { *A = 1.0; return 1u; }          // constant chain: the guess is never used for it
+            *A = 0.0;
+            if (gamma == 0.0f || gamma >= 0.05f) return 0u;      // constant chain / fast smoother: no responses, no guess (K = 0)
             const double q = 1.0 - (double)gamma;
-            if (!(q > 0.0)) { *A = 0.0; return 1u; }
+            if (!(q > 0.0)) return 0u;
             *A = pow(q, 256.0);
             const double k = ceil(depth_nats / (-256.0 * log(q)));
             return k < 1.0 ? 1u : (k > 1e6 ? 1000000u : (uint32_t)k);
@@ -1479,8 +1480,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             BandRespParam rp{};
                             double ql = 1.0 - (double)v.lgamma, qh = 1.0 - (double)v.hgamma;
                             for (int j = 0; j < 8; ++j) { rp.ql[j] = ql; rp.qh[j] = qh; ql *= ql; qh *= qh; }
-                            rp.gl = (double)v.lgamma;
-                            rp.gh = (double)v.hgamma;
+                            rp.gl = bp.Kl ? (double)v.lgamma : 0.0;   // (0: no responses for that smoother)
+                            rp.gh = bp.Kh ? (double)v.hgamma : 0.0;
                             bp.rp_off = st.alloc(sizeof rp);
                             memcpy(&st.b[bp.rp_off], &rp, sizeof rp);
                             bp.resp_off = scratch(((M + 255) / 256) * 4 * sizeof(double));

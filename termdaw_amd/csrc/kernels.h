@@ -62,7 +62,8 @@ struct NormState { float max, scan_max; uint32_t violated, ticket; };
 // y <- (1 - gamma)^256 y + resp reproduce the exact-arithmetic state to far below an f32 ulp.
 struct BandRespParam {
     double ql[8], qh[8];   // (1 - gamma)^(2^j), j = 0..7, low / high smoother
-    double gl, gh;         // the two gammas
+    double gl, gh;         // the two gammas; 0 = no responses for that smoother (it is constant, or so fast -- gamma >= 0.05,
+                           // (1 - gamma)^400 < 2^-30 -- that any starting value has converged long before the window ends)
     double* resp;          // [ceil(frames / 256)][4]
 };
 

@@ -449,28 +449,34 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
             const BandRespParam& rp = *d.rp;
             const uint32_t i0 = (2u * threadIdx.x) & 255u;      // in-block index of the lane's first frame (even)
             const uint32_t k1 = 254u - i0;                      // exponent of the second frame; the first has k1 + 1
+            const bool want_l = rp.gl != 0.0, want_h = rp.gh != 0.0;   // (uniform: a smoother without responses costs nothing here)
             double pl = 1.0, ph = 1.0;
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                if ((k1 >> j) & 1u) { pl *= rp.ql[j]; ph *= rp.qh[j]; }
+                if ((k1 >> j) & 1u) { if (want_l) pl *= rp.ql[j]; if (want_h) ph *= rp.qh[j]; }
             const double wl1 = rp.gl * pl, wl0 = wl1 * rp.ql[0], wh1 = rp.gh * ph, wh0 = wh1 * rp.qh[0];
             // the lane's two frames of each of its two blocks, four chains; then a fixed-order sum over each block's 128 lanes:
             // partials to LDS (lane-major), 32 threads add 64 of them each, 16 threads add the two halves
             __shared__ double rs[8][kThreads + 4];
-            rs[0][threadIdx.x] = wl0 * (double)a0.x + wl1 * (double)a0.z;
-            rs[1][threadIdx.x] = wl0 * (double)a0.y + wl1 * (double)a0.w;
-            rs[2][threadIdx.x] = wh0 * (double)a0.x + wh1 * (double)a0.z;
-            rs[3][threadIdx.x] = wh0 * (double)a0.y + wh1 * (double)a0.w;
-            rs[4][threadIdx.x] = wl0 * (double)a1.x + wl1 * (double)a1.z;
-            rs[5][threadIdx.x] = wl0 * (double)a1.y + wl1 * (double)a1.w;
-            rs[6][threadIdx.x] = wh0 * (double)a1.x + wh1 * (double)a1.z;
-            rs[7][threadIdx.x] = wh0 * (double)a1.y + wh1 * (double)a1.w;
+            if (want_l) {
+                rs[0][threadIdx.x] = wl0 * (double)a0.x + wl1 * (double)a0.z;
+                rs[1][threadIdx.x] = wl0 * (double)a0.y + wl1 * (double)a0.w;
+                rs[4][threadIdx.x] = wl0 * (double)a1.x + wl1 * (double)a1.z;
+                rs[5][threadIdx.x] = wl0 * (double)a1.y + wl1 * (double)a1.w;
+            }
+            if (want_h) {
+                rs[2][threadIdx.x] = wh0 * (double)a0.x + wh1 * (double)a0.z;
+                rs[3][threadIdx.x] = wh0 * (double)a0.y + wh1 * (double)a0.w;
+                rs[6][threadIdx.x] = wh0 * (double)a1.x + wh1 * (double)a1.z;
+                rs[7][threadIdx.x] = wh0 * (double)a1.y + wh1 * (double)a1.w;
+            }
             __syncthreads();
             __shared__ double rh[8][4];
             if (threadIdx.x < 32u) {   // e = value index (0..7), q = quarter of the workgroup (64 lanes)
                 const uint32_t e = threadIdx.x >> 2, q = threadIdx.x & 3u;
                 double acc = 0.0;
-                for (uint32_t i = 0; i < 64u; ++i) acc += rs[e][q * 64u + i];
+                if ((e & 2u) ? want_h : want_l)
+                    for (uint32_t i = 0; i < 64u; ++i) acc += rs[e][q * 64u + i];
                 rh[e][q] = acc;
             }
             __syncthreads();
@@ -1354,7 +1360,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     float y;
     if (my_begin == 0u || gam == 0.0f) {
         y = y_true0;
-    } else if (d.resp && (my_begin & 255u) == 0u) {
+    } else if (d.resp && (my_begin & 255u) == 0u && ((c & 2u) ? d.Kh : d.Kl) != 0u) {   // (K == 0: a fast smoother, no responses)
         const double A = (c & 2u) ? d.Ah : d.Al;
         const uint32_t K = (c & 2u) ? d.Kh : d.Kl;
         const uint32_t nblk = my_begin >> 8, first = nblk > K ? nblk - K : 0u;
@@ -1446,6 +1452,16 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         TD_BAND_S1(a.z, "[2,3,2,3]", (J0) + 6) TD_BAND_S1(a.w, "[2,3,2,3]", (J0) + 7)                           \
     }
         float4 a0 = fetchq(start), a1 = fetchq(start + 8u), a2 = fetchq(start + 16u), a3 = fetchq(start + 24u);
+        // (b)'s input frames (interleaved copy) of the lane's eight (segment, frame) slots: loaded a whole 32-frame piece
+        // ahead, like the recurrence's own input -- the eight loads of a piece would otherwise be exposed one L2 round trip
+        // after the other between the dependent chains
+        auto xo_m = [&](uint32_t i, uint32_t p) -> uint32_t {
+            const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u;
+            return min(wave_seg0 + sq, d.nseg - 1u) * d.S + p + j;   // quads past the end mirror the last segment
+        };
+        float2 xo[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) xo[i] = gload2(d.x + xo_m(i, 0u));
         for (uint32_t p = 0; p < d.S; p += 32u) {
             TD_BAND_STEP8W(a0, 0) TD_BAND_STEP8W(a1, 8) TD_BAND_STEP8W(a2, 16) TD_BAND_STEP8W(a3, 24)
             if (p + 32u < d.S) {   // the next 32 frames' input flies during (b)
@@ -1453,12 +1469,13 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
                 a2 = fetchq(start + p + 48u); a3 = fetchq(start + p + 56u);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-#pragma unroll 2
+#pragma unroll
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u;
                 const uint32_t sraw = wave_seg0 + sq;
-                const uint32_t m = min(sraw, d.nseg - 1u) * d.S + p + j;   // quads past the end mirror the last segment
-                const float2 x = gload2(d.x + m);
+                const uint32_t m = min(sraw, d.nseg - 1u) * d.S + p + j;
+                const float2 x = xo[i];
+                if (p + 32u < d.S) xo[i] = gload2(d.x + xo_m(i, p + 32u));
                 const float4 s = *reinterpret_cast<const float4*>(ys_l + (wq0 + sq) * kQStride + j * 4u);
                 const float2 x0 = xf_l[wq0 + sq];
                 const bool sm = __float_as_uint(x.x) == __float_as_uint(x0.x) && __float_as_uint(x.y) == __float_as_uint(x0.y);
