@@ -1204,12 +1204,46 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             inlined[vi] = g->vertices[vi].kind == K_SAMPLE_LOOP && (long)vi != g->output_vertex;
     // ... and so is a Sum vertex with exactly one (materialised) input -- a gain / pan stage: its consumers read
     // the input's buffer and apply `0.0 + x`, pan, gain themselves (term kind 4); one launch and one buffer less
+    // ... and an Adsr vertex with one materialised input and ONE consumer whose kernel sums nothing else (a Sum, a
+    // Normalize, a band-pass -- directly or through one gain / pan stage): that consumer evaluates the envelope itself
+    // (term kind 5); inlined 3 = such an Adsr vertex, 4 = the stage behind one
+    std::vector<std::vector<size_t>> cons(nv);
+    for (size_t vi : g->order)
+        for (size_t u : g->edges[vi]) cons[u].push_back(vi);
+    auto is_stage = [&](size_t vi) {   // a single-input Sum that is not the output
+        return g->vertices[vi].kind == K_SUM && (long)vi != g->output_vertex && g->edges[vi].size() == 1;
+    };
+    auto sums_one_term = [&](size_t c) {   // consumer kernels that take a TERMS_ADSR1 table (the k_sum family, k_band_pass)
+        const Vertex& w = g->vertices[c];
+        if (g->edges[c].size() != 1) return false;
+        if (w.kind == K_NORMALIZE || w.kind == K_BAND_PASS) return true;
+        return w.kind == K_SUM && !is_stage(c);
+    };
     if (g->fuse_sources)
         for (size_t vi : g->order) {   // topological order: the input's own flag is final here
             const Vertex& v = g->vertices[vi];
-            if (v.kind != K_SUM || (long)vi == g->output_vertex || g->edges[vi].size() != 1 || inlined[g->edges[vi][0]]) continue;
-            inlined[vi] = 2;
+            if (v.kind == K_ADSR && g->inline_adsr && !(v.wet < 0.0001f) && (long)vi != g->output_vertex &&
+                g->edges[vi].size() == 1 && !inlined[g->edges[vi][0]] && cons[vi].size() == 1) {
+                const size_t c = cons[vi][0];
+                const bool direct = sums_one_term(c);
+                const bool staged = is_stage(c) && cons[c].size() == 1 && sums_one_term(cons[c][0]);
+                if (direct || staged) {
+                    inlined[vi] = 3;
+                    const size_t u = g->edges[vi][0];
+                    last_use[u] = std::max(last_use[u], last_use[vi]);
+                }
+                continue;
+            }
+            if (!is_stage(vi)) continue;
             const size_t u = g->edges[vi][0];
+            if (inlined[u] == 3) {
+                inlined[vi] = 4;
+                const size_t in = g->edges[u][0];
+                last_use[in] = std::max(last_use[in], last_use[vi]);   // the envelope's input outlives the stage's consumer
+                continue;
+            }
+            if (inlined[u]) continue;
+            inlined[vi] = 2;
             last_use[u] = std::max(last_use[u], last_use[vi]);   // the input must outlive the stage's consumers
         }
 
@@ -1281,11 +1315,21 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::map<size_t, size_t> ins_off;
         std::map<size_t, uint32_t> term_mode;
         for (size_t vi : by_level[lv]) {
-            if (!g->vertices[vi].has_input()) continue;
+            if (!g->vertices[vi].has_input() || inlined[vi]) continue;   // (an inlined vertex' terms belong to its consumers)
             std::vector<InTerm> ins;
+            long adsr_through = -1;   // the Adsr vertex a kind-5 term reads through
             for (size_t u : g->edges[vi]) {
                 InTerm t{};
-                if (inlined[u] == 2) {   // single-input Sum stage, read through
+                if (inlined[u] == 3 || inlined[u] == 4) {   // Adsr vertex (and the stage behind it), evaluated here
+                    const size_t a = inlined[u] == 4 ? g->edges[u][0] : u;
+                    adsr_through = (long)a;
+                    t.p = g->vbuf[g->edges[a][0]];
+                    t.kind = 5u;
+                    if (inlined[u] == 4) {
+                        t.magic = 1u;
+                        t.pg = make_pg(g->vertices[u].gain, g->vertices[u].angle);
+                    }
+                } else if (inlined[u] == 2) {   // single-input Sum stage, read through
                     t.p = g->vbuf[g->edges[u][0]];
                     t.kind = 4u;
                     t.pg = make_pg(g->vertices[u].gain, g->vertices[u].angle);
@@ -1321,6 +1365,28 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             term_mode[vi] = all_edge ? (ins.size() < 8 ? TERMS_EDGE_FEW : TERMS_ALL_EDGE)
                                      : (all_loop16 ? TERMS_ALL_LOOP16 : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED));
             ins_off[vi] = st.put(ins);
+            if (adsr_through >= 0) {   // (the only term: sums_one_term) -- the vertex' descriptor, as k_adsr would get it
+                const size_t a = (size_t)adsr_through;
+                const Vertex& av = g->vertices[a];
+                term_mode[vi] = TERMS_ADSR1;
+                AdsrVDesc x{};
+                x.tab.n_int = vt[a].n_int;
+                x.sr = (uint32_t)sr;
+                x.bl = (uint32_t)bl;
+                x.use_off = av.use_off;
+                x.use_max = av.use_max;
+                x.wet = av.wet;
+                x.conf = av.conf;
+                x.pg = make_pg(av.gain, av.angle);
+                const size_t o = st.alloc(sizeof x);
+                memcpy(&st.b[o], &x, sizeof x);
+                const size_t t = o + offsetof(AdsrVDesc, tab);
+                tab_field(t, offsetof(IntervalTab, istart), vt[a], vt[a].istart_off);
+                tab_field(t, offsetof(IntervalTab, tile_first), vt[a], vt[a].tile_first_off);
+                tab_field(t, offsetof(IntervalTab, ivoff), vt[a], vt[a].ivoff_off);
+                tab_field(t, offsetof(IntervalTab, voices), vt[a], vt[a].voices_off);
+                ptr_field(ins_off[vi], offsetof(InTerm, len), o);
+            }
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
         std::map<size_t, SumDesc> sum_desc_of;                      // Normalize vertices: their k_sum descriptor (k_norm_fix reuses it)
@@ -2702,6 +2768,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
+    if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }
     if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "table_cache") { g->table_cache = value != 0; return 1; }

@@ -296,6 +296,7 @@ struct td_graph {
     size_t device_bytes = 0;
     bool fuse_sources = true;                  // inline sample_loop sources into their consumers
     bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
+    bool inline_adsr = true;                   // a one-input, one-consumer Adsr vertex is evaluated by its consumer's sum
     bool output_f32 = true;                    // 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames
     bool graph_replay = false;                 // replay the captured launch sequence of an unchanged submission (measured: no gain)
     bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk

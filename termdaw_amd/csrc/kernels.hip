@@ -174,12 +174,38 @@ TD_DEV float4 loop_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     return zero_tail(epilogue4(loop_pair32(t[j].p, (uint32_t)t[j].len, t[j].magic, (uint32_t)t[j].t0 + m), term_pg(t, j)), m, M);
 }
 
+// InTerm kind 5: an edge buffer read THROUGH an Adsr vertex with this one input (and, magic != 0, a single-input Sum
+// stage behind it): the consumer does the vertex' own work per frame pair -- `0.0 + x` (its sum_inputs over one input),
+// the envelope (adsr_frame), pan / gain; then the stage's `0.0 + x`, pan, gain -- the same f32 operations in the same
+// order as the materialised vertices, without their launches and buffers.  `len` holds the vertex' AdsrVDesc.
+TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x);
+TD_DEV float4 adsr_term_pair(TermTab t, uint32_t m, uint32_t M) {
+    AdsrVDesc d;
+    __builtin_memcpy(&d, (const AdsrVDesc TD_CONST*)(const TD_CONST char*)(uintptr_t)t[0].len, sizeof d);   // (uniform: scalar loads)
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 x = add4(z, load_pair(t[0].p, m, M));
+    float4 v = z;
+    if (m < M) {
+        const float2 a = adsr_frame(d, m, make_float2(x.x, x.y));
+        const float2 b = (m + 1 < M) ? adsr_frame(d, m + 1, make_float2(x.z, x.w)) : make_float2(0.f, 0.f);
+        v = epilogue4(make_float4(a.x, a.y, b.x, b.y), d.pg);
+        if (t[0].magic) v = epilogue4(add4(z, v), term_pg(t, 0));
+        v = zero_tail(v, m, M);
+    }
+    return v;
+}
+
 // sum_inputs (extensions.rs:310-319): zero, then += each input in edge order.  Terms are fetched four
 // (edge buffers: eight) at a time so that 8-16 x 16 B loads are in flight per lane before the first add;
 // the adds themselves stay strictly sequential per element.
 template <int MODE>
 TD_DEV void sum_terms(TermTab ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_t M, float4& acc0, float4& acc1) {
     uint32_t j = 0;
+    if (MODE == TERMS_ADSR1) {   // exactly one term, kind 5
+        acc0 = add4(acc0, adsr_term_pair(ins, m0, M));
+        acc1 = add4(acc1, adsr_term_pair(ins, m1, M));
+        return;
+    }
     if (MODE == TERMS_ALL_EDGE && k >= 8) {
         // software pipeline over groups of four edge buffers, two register sets (no copies): the eight loads
         // of the next group are in flight while this group's adds retire (counted vmcnt waits)
@@ -374,6 +400,7 @@ TD_DEV void sum_inputs_pairs(const InTerm* ins_generic, uint32_t k, uint32_t ter
     a1 = a0;
     if (term_mode == TERMS_ALL_EDGE) sum_terms<TERMS_ALL_EDGE>(ins, k, m0, m1, M, a0, a1);
     else if (term_mode == TERMS_ALL_LOOP32) sum_terms<TERMS_ALL_LOOP32>(ins, k, m0, m1, M, a0, a1);
+    else if (term_mode == TERMS_ADSR1) sum_terms<TERMS_ADSR1>(ins, k, m0, m1, M, a0, a1);
     else sum_terms<TERMS_MIXED>(ins, k, m0, m1, M, a0, a1);
 }
 
@@ -728,7 +755,8 @@ __global__ __launch_bounds__(kThreads) void k_norm_fix(const SumDesc* __restrict
         for (uint32_t bb = b_lo; bb <= b_hi; ++bb) last = fmaxf(d.peaks[bb], last);
         if (!(last > init)) continue;   // (uniform) every block of this tile was scaled by 1 / init: already right
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
-        sum_terms<TERMS_MIXED>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
+        if (d.term_mode == TERMS_ADSR1) sum_terms<TERMS_ADSR1>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
+        else sum_terms<TERMS_MIXED>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
         auto rscale_of = [&](uint32_t m) -> float {
             float run = upto;
             const uint32_t b = m / bl;
@@ -2001,6 +2029,7 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb);
             break;
         case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_EDGE_FEW>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        case TERMS_ADSR1: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ADSR1>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         default: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_MIXED>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
     }
 }

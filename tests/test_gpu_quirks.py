@@ -320,3 +320,75 @@ def test_graph_replay_is_value_neutral(gpu_api, oracle, project):
         be_g.set_time(3 * p.bl)
         be_fb.set_time(3 * p.bl)
     assert_bit_exact(g.render_all(sb, fb, 9, 24), og.render_all(osb, ofb, 9, 24))
+
+
+@pytest.mark.parametrize("consumer", ["normalize", "sum_out", "band", "band_serial", "band_thru", "two_inputs", "two_consumers", "adsr"])
+@pytest.mark.parametrize("stage", [False, True])
+@pytest.mark.parametrize("chunk", [0, 5000])
+def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage, chunk):
+    """An Adsr vertex with one materialised input and one single-input consumer (directly or through a gain / pan stage)
+    is evaluated inside the consumer's summing kernel (term kind 5, option inline_adsr): every consumer kind, with and
+    without the stage, -0.0 inputs, skipped hits (quirk Q9), the shapes that must NOT be inlined (a second input, a second
+    consumer, an Adsr consumer), single- and multi-chunk, scanned and unscanned -- bit-exact against the oracle and
+    against the materialised form."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(0.6)
+    pcm = W.noise_int16(31, 4001)
+    pcm[100:140] = 0
+    p.assets["a"] = W.Asset(pcm)
+    p.load_sample("a", "a", "")
+    p.add_sampleloop("l", -0.7, 10.0, "a")      # negative gain: zeros of the asset become -0.0
+    p.add_sum("src", 1.0, 0.0)                  # materialised input of the envelope
+    p.connect("l", "src")
+    p.event_files["h"] = np.array([(0.03, 60.0, 0.9), (0.11, 61.0, 0.5), (0.13, 60.0, 0.0), (0.3, 60.0, 0.7), (0.45, 60.0, 0.0)], np.float32)
+    p.load_midi_floww("h", "h")
+    p.add_adsr("env", 0.8, -20.0, 0.7, "h", True, False, 60, [0.01, 0.02, 0.6, 0.03, 0.2, 0.05])
+    p.connect("src", "env")
+    prev = "env"
+    if stage:
+        p.add_sum("st", 1.3, 15.0)
+        p.connect(prev, "st")
+        prev = "st"
+    out = "c"
+    if consumer == "normalize":
+        p.add_normalize("c", 0.9, 3.0)
+    elif consumer == "sum_out":
+        p.add_sum("c", 0.9, 0.0)                # a single-input Sum that IS the output: materialised, reads through
+    elif consumer in ("band", "band_serial"):
+        p.add_bandpass("c", 1.0, 0.0, 0.9, 300.0, 5000.0, True)
+    elif consumer == "band_thru":
+        p.add_bandpass("c", 1.1, 0.0, 0.0, 300.0, 5000.0, True)   # wet 0: the summed input passes through
+    elif consumer == "two_inputs":
+        p.add_normalize("c", 1.0, 0.0)
+        p.connect("src", "c")
+    elif consumer == "two_consumers":
+        p.add_normalize("c", 1.0, 0.0)
+        p.add_sum("side", 0.5, 0.0)
+        p.connect(prev, "side")
+        p.connect("side", "c")
+    else:
+        p.add_adsr("c", 1.0, 0.0, 0.5, "h", False, True, -1, [0.01, 0.02, 0.6, 0.03, 0.2, 0.05])
+    p.connect(prev, "c")
+    if consumer in ("band", "band_serial", "band_thru", "adsr"):
+        p.add_normalize("o", 1.0, 0.0)
+        p.connect("c", "o")
+        out = "o"
+    p.set_output(out)
+    outs = []
+    for inline in (1, 0):
+        built = p.build(gpu_api)
+        obuilt = p.build(oracle)
+        built[2].set_option("inline_adsr", inline)
+        if chunk:
+            built[2].set_option("max_chunk_frames", chunk)
+        if consumer == "band_serial":
+            built[2].set_option("band_parallel", 0)
+        seq = [p.render(gpu_api, built=built)]
+        assert_bit_exact(seq[0], p.render(oracle, built=obuilt))
+        built[2].true_normalize_scan(built[0], built[1], p.cs)
+        obuilt[2].true_normalize_scan(obuilt[0], obuilt[1], p.cs)
+        seq.append(p.render(gpu_api, built=built))
+        assert_bit_exact(seq[1], p.render(oracle, built=obuilt))
+        outs.append(seq)
+    for a, b in zip(*outs):
+        assert_bit_exact(a, b)
