@@ -904,22 +904,36 @@ constexpr float kPi = 3.14159274101257324f;   // core::f32::consts::PI
 
 // sin of an f32 argument of any size, for the tolerance-class kernels (debug_sine, synth: <= 1e-6 RMS against the
 // oracle's glibc sinf).  The argument itself is rounded exactly like the reference rounds it (`time * hz * 2.0 * PI`,
-// extensions.rs:450,501 -- it reaches ~1e6 rad); the range reduction is exact enough in double (|n| <= 2e5 turns, 2 pi
-// to 1e-16: < 1e-10 rad), folded to a quarter turn there, and the quarter is a degree-11 odd polynomial in f32
-// (truncation 6e-8 at pi/2).  ~25 instructions instead of the ~100 of ocml's sinf with its Payne-Hanek path.
-TD_DEV float sin_any(float arg) {
-    const double t = (double)arg * 0.15915494309189533577;   // turns
-    double f = t - rint(t);                                  // [-0.5, 0.5]
-    if (fabs(f) > 0.25) f = copysign(0.5, f) - f;            // sin(pi - x) = sin(x): [-0.25, 0.25], exact
-    const float r = (float)(f * 6.28318530717958647692);     // [-pi/2, pi/2]
-    const float r2 = r * r;
-    float p = -2.5052108385441718775e-8f;                    // -1/11!
-    p = p * r2 + 2.7557319223985890653e-6f;                  //  1/9!
-    p = p * r2 - 1.9841269841269841270e-4f;                  // -1/7!
-    p = p * r2 + 8.3333333333333333333e-3f;                  //  1/5!
-    p = p * r2 - 1.6666666666666666667e-1f;                  // -1/3!
-    return r + r * (r2 * p);
+// extensions.rs:450,501 -- it reaches ~1e6 rad, where an f32 ulp is 0.06 rad: that rounding IS the signal).  Range
+// reduction by half turns in f32 with two fused steps: n = rint(arg / pi); arg - n * fl(pi) is exact in one FMA (the
+// product has 43 bits, the difference is a multiple of ulp(fl(pi)) below 2), the second FMA adds n * (fl(pi) - pi);
+// sin(arg) = (-1)^n sin(r), |r| <= pi/2 (+ 0.2 where rint() saw a misrounded quotient, arguments beyond 1e6), and the
+// quarter is a degree-11 odd polynomial (truncation 6e-8 at pi/2).  Measured against sin() in double over [0, 2e6]:
+// max 3.3e-7, RMS 2.8e-8.  14 instructions, all of them f32 -- and in the two-frame form below all but the rint /
+// convert / sign steps are packed (v_pk_mul_f32, v_pk_fma_f32: both frames of a lane in one issue slot).
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+TD_DEV f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+TD_DEV f2 sin_any2(f2 arg) {
+    const f2 t = arg * 0.318309886f;   // half turns
+    f2 n;
+    n.x = __builtin_rintf(t.x);
+    n.y = __builtin_rintf(t.y);
+    f2 r = fma2(-n, (f2)(3.14159274f), arg);
+    r = fma2(-n, (f2)(-8.74227766e-8f), r);
+    u2 sg;
+    sg.x = (uint32_t)(int)n.x << 31;
+    sg.y = (uint32_t)(int)n.y << 31;
+    const f2 r2 = r * r;
+    f2 p = (f2)(-2.5052108385441718775e-8f);                 // -1/11!
+    p = fma2(p, r2, (f2)(2.7557319223985890653e-6f));        //  1/9!
+    p = fma2(p, r2, (f2)(-1.9841269841269841270e-4f));       // -1/7!
+    p = fma2(p, r2, (f2)(8.3333333333333333333e-3f));        //  1/5!
+    p = fma2(p, r2, (f2)(-1.6666666666666666667e-1f));       // -1/3!
+    const f2 q = fma2(r, r2 * p, r);
+    return __builtin_bit_cast(f2, __builtin_bit_cast(u2, q) ^ sg);
 }
+TD_DEV float sin_any(float arg) { return sin_any2((f2)(arg)).x; }
 // x / y for the same kernels: v_rcp_f32 + multiply (1 ulp) instead of the 10-instruction IEEE division.  0 / 0 is still
 // NaN and t / 0 still +-inf (quirk Q6's cases).
 TD_DEV float fdiv_fast(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
@@ -1008,31 +1022,107 @@ TD_DEV float synth_frame(const SynthDesc& d, uint32_t m) {
     for (uint32_t v = v0; v < v1; ++v) acc += synth_voice(d, d.tab.voices[v], time, off);
     return acc;
 }
-// The lane's frame pair m, m + 1.  A wave's 128 frames nearly always lie in ONE interval (intervals start at block
-// starts and event frames): the voice list is then the same for every lane, the voice records come in through scalar
-// loads (constant address space) and both frames share one pass over the voices.  A wave that straddles an interval
-// start takes the per-lane form.
-TD_DEV float2 synth_pair(const SynthDesc& d, uint32_t m, uint32_t M) {
-    const bool two = m + 1u < M;
-    const uint32_t ita = find_interval(d.tab, m), itb = two ? find_interval(d.tab, m + 1u) : ita;
-    const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ita);
-    if (__all((ita == it0 && itb == it0) ? 1 : 0)) {
+// The same for the two frames of a pair at once, written on 2-vectors: products, sums and the sine's polynomial compile
+// to packed instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- two frames per issue slot; k_synth is bound by
+// VALU issue); min / max / floor / rint and the envelope's piece selection stay per frame.  Same operations in the same
+// order as synth_voice.  `held`: the level a released voice was released at, apply_ads(conf, rel_t) of adsr.rs:89-92 --
+// it depends on the voice only and is computed once per voice, not once per frame.
+struct SynthHeld { float sq, tf, tr; };
+TD_DEV SynthHeld synth_held(const SynthDesc& d, float rel_t) {
+    SynthHeld h{0.0f, 0.0f, 0.0f};
+    if (rel_t != 0.0f) {
+        if (d.square.volume > 0.0f) h.sq = apply_ads_fast(d.square.adsr, rel_t);
+        if (d.topflat.volume > 0.0f) h.tf = d.tf_env_src == 1u ? h.sq : apply_ads_fast(d.topflat.adsr, rel_t);
+        if (d.triangle.volume > 0.0f)
+            h.tr = d.tr_env_src == 1u ? h.sq : d.tr_env_src == 2u ? h.tf : apply_ads_fast(d.triangle.adsr, rel_t);
+    }
+    return h;
+}
+TD_DEV f2 synth_env2(const AdsrConfD& c, f2 env_time, float rel_t, float held) {
+    f2 e;
+    if (rel_t == 0.0f) {
+        e.x = apply_ads_fast(c, env_time.x);
+        e.y = apply_ads_fast(c, env_time.y);
+    } else {   // apply_r (adsr.rs:71-73): lerp(held, release_vel, min(t / release_sec, 1))
+        f2 u = env_time * __builtin_amdgcn_rcpf(c.release_sec);
+        u.x = fminf(u.x, 1.0f);
+        u.y = fminf(u.y, 1.0f);
+        e = held + u * (c.release_vel - held);
+    }
+    return e;
+}
+TD_DEV f2 synth_voice2(const SynthDesc& d, const float4 n, const SynthHeld& h, f2 time, f2 off) {   // n = (hz, vel, env_t, rel_t)
+    const float hz = n.x, vel = n.y, rel_t = n.w;
+    const f2 env_time = n.z + off;
+    f2 s = (f2)(0.0f), sn = (f2)(0.0f), env_sq = (f2)(0.0f), env_tf = (f2)(0.0f);
+    if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any2(time * hz * 2.0f * kPi);
+    if (d.square.volume > 0.0f) {
+        const float z = d.square.param;
+        f2 osc;
+        osc.x = fminf(fmaxf(sn.x, -z), z);
+        osc.y = fminf(fmaxf(sn.y, -z), z);
+        osc = osc * (1.0f / z);
+        env_sq = synth_env2(d.square.adsr, env_time, rel_t, h.sq);
+        s += osc * vel * env_sq * d.square.volume;
+    }
+    if (d.topflat.volume > 0.0f) {
+        const float z = d.topflat.param;
+        f2 m;
+        m.x = fminf(sn.x, z);
+        m.y = fminf(sn.y, z);
+        const f2 osc = (m + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
+        env_tf = d.tf_env_src == 1u ? env_sq : synth_env2(d.topflat.adsr, env_time, rel_t, h.tf);
+        s += osc * vel * env_tf * d.topflat.volume;
+    }
+    if (d.triangle.volume > 0.0f) {
+        const f2 th = time * hz;
+        f2 fl = th + 0.5f;
+        fl.x = floorf(fl.x);
+        fl.y = floorf(fl.y);
+        f2 dd = th - fl;
+        dd.x = fabsf(dd.x);
+        dd.y = fabsf(dd.y);
+        const f2 osc = 4.0f * dd - 1.0f;
+        const f2 env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf : synth_env2(d.triangle.adsr, env_time, rel_t, h.tr);
+        s += osc * vel * env * d.triangle.volume;
+    }
+    return s * d.osc_amp_multiplier;
+}
+// The lane's frame pairs ma, ma + 1 and mb, mb + 1.  A wave's frames nearly always lie in ONE interval (intervals start
+// at block starts and event frames): the voice list is then the same for every lane, the voice records come in through
+// scalar loads (constant address space) and all four frames share one pass over the voices.  A wave that straddles an
+// interval start takes the per-lane form.
+TD_DEV f2 synth_time2(const SynthDesc& d, uint32_t m) {
+    return f2{(float)(d.t0 + m) / (float)d.sr, (float)(d.t0 + m + 1u) / (float)d.sr};
+}
+TD_DEV f2 synth_off2(const SynthDesc& d, uint32_t m) {
+    return f2{(float)(m % d.bl) / (float)d.sr, (float)((m + 1u) % d.bl) / (float)d.sr};
+}
+TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M, float2& pa, float2& pb) {
+    const bool two_a = ma + 1u < M, two_b = mb + 1u < M;
+    const uint32_t i0 = find_interval(d.tab, ma), i1 = two_a ? find_interval(d.tab, ma + 1u) : i0;
+    const uint32_t i2 = find_interval(d.tab, mb), i3 = two_b ? find_interval(d.tab, mb + 1u) : i2;
+    const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+    if (__all((i0 == it0 && i1 == it0 && i2 == it0 && i3 == it0) ? 1 : 0)) {
         const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
         const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
         typedef float f4c __attribute__((ext_vector_type(4)));
         const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
-        const float ta = (float)(d.t0 + m) / (float)d.sr, tb = (float)(d.t0 + m + 1u) / (float)d.sr;
-        const float oa = (float)(m % d.bl) / (float)d.sr, ob = (float)((m + 1u) % d.bl) / (float)d.sr;
-        float a = 0.0f, b = 0.0f;
+        const f2 ta = synth_time2(d, ma), tb = synth_time2(d, mb), oa = synth_off2(d, ma), ob = synth_off2(d, mb);
+        f2 a = (f2)(0.0f), b = (f2)(0.0f);
         for (uint32_t v = v0; v < v1; ++v) {
             const f4c q = vc[v];
             const float4 n = make_float4(q.x, q.y, q.z, q.w);
-            a += synth_voice(d, n, ta, oa);
-            b += synth_voice(d, n, tb, ob);
+            const SynthHeld h = synth_held(d, n.w);
+            a += synth_voice2(d, n, h, ta, oa);
+            b += synth_voice2(d, n, h, tb, ob);
         }
-        return make_float2(a, two ? b : 0.0f);
+        pa = make_float2(a.x, two_a ? a.y : 0.0f);
+        pb = make_float2(b.x, two_b ? b.y : 0.0f);
+        return;
     }
-    return make_float2(synth_frame(d, m), two ? synth_frame(d, m + 1u) : 0.0f);
+    pa = make_float2(synth_frame(d, ma), two_a ? synth_frame(d, ma + 1u) : 0.0f);
+    pb = make_float2(synth_frame(d, mb), two_b ? synth_frame(d, mb + 1u) : 0.0f);
 }
 __global__ __launch_bounds__(kThreads) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
     const SynthDesc& d = descs[blockIdx.y];
@@ -1040,7 +1130,8 @@ __global__ __launch_bounds__(kThreads) void k_synth(const SynthDesc* __restrict_
     const uint32_t m1 = m0 + kTileFrames / 2;
     // (frames at or beyond M are computed on clamped indices and not stored: the uniform-interval test needs whole waves)
     const uint32_t mc0 = min(m0, M - 1u), mc1 = min(m1, M - 1u);
-    const float2 p0 = synth_pair(d, mc0, M), p1 = synth_pair(d, mc1, M);
+    float2 p0, p1;
+    synth_quad(d, mc0, mc1, M, p0, p1);
     if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(p0.x, p0.x, p0.y, p0.y), d.pg));
     if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(p1.x, p1.x, p1.y, p1.y), d.pg));
 }
