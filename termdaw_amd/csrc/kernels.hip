@@ -1022,11 +1022,16 @@ TD_DEV float synth_frame(const SynthDesc& d, uint32_t m) {
     for (uint32_t v = v0; v < v1; ++v) acc += synth_voice(d, d.tab.voices[v], time, off);
     return acc;
 }
-// The same for the two frames of a pair at once, written on 2-vectors: products, sums and the sine's polynomial compile
-// to packed instructions (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 -- two frames per issue slot; k_synth is bound by
-// VALU issue); min / max / floor / rint and the envelope's piece selection stay per frame.  Same operations in the same
-// order as synth_voice.  `held`: the level a released voice was released at, apply_ads(conf, rel_t) of adsr.rs:89-92 --
-// it depends on the voice only and is computed once per voice, not once per frame.
+// The same for the lane's four frames (two pairs) at once, on 2-vectors -- same operations in the same order as
+// synth_voice, organised around what k_synth is bound by, VALU issue (tools/ubench/issue_rate.hip: fma / mul / add issue in
+// ~1.05 ns per wave and SIMD, compares / selects / min / max / conversions and every packed op in ~1.75 ns):
+//  * `held`, the level a released voice was released at (apply_ads(conf, rel_t), adsr.rs:89-92), depends on the voice only:
+//    once per voice, not once per frame;
+//  * the envelope of a held voice: a wave's frames nearly always lie on ONE piece of the curve (attack / decay / sustain
+//    ramp / hold last for thousands of frames, a wave spans 640) -- the piece is found once, from the wave's first and last
+//    envelope time, and all four frames take its lerp as straight packed code; a wave that straddles a breakpoint, or a
+//    conf whose levels could reach the `res <= -1` escape of adsr.rs:62-69, takes the per-frame form;
+//  * products and sums of the two frames of a pair issue packed.
 struct SynthHeld { float sq, tf, tr; };
 TD_DEV SynthHeld synth_held(const SynthDesc& d, float rel_t) {
     SynthHeld h{0.0f, 0.0f, 0.0f};
@@ -1038,23 +1043,50 @@ TD_DEV SynthHeld synth_held(const SynthDesc& d, float rel_t) {
     }
     return h;
 }
-TD_DEV f2 synth_env2(const AdsrConfD& c, f2 env_time, float rel_t, float held) {
-    f2 e;
-    if (rel_t == 0.0f) {
-        e.x = apply_ads_fast(c, env_time.x);
-        e.y = apply_ads_fast(c, env_time.y);
-    } else {   // apply_r (adsr.rs:71-73): lerp(held, release_vel, min(t / release_sec, 1))
-        f2 u = env_time * __builtin_amdgcn_rcpf(c.release_sec);
-        u.x = fminf(u.x, 1.0f);
-        u.y = fminf(u.y, 1.0f);
-        e = held + u * (c.release_vel - held);
-    }
-    return e;
+TD_DEV int ads_piece(const AdsrConfD& c, float t) {   // 0 attack, 1 decay, 2 sustain ramp, 3 beyond (NaN: 3, like adsr.rs:46-60)
+    return t <= c.attack_sec ? 0 : t <= c.attack_sec + c.decay_sec ? 1 : t <= c.attack_sec + c.decay_sec + c.sustain_sec ? 2 : 3;
 }
-TD_DEV f2 synth_voice2(const SynthDesc& d, const float4 n, const SynthHeld& h, f2 time, f2 off) {   // n = (hz, vel, env_t, rel_t)
-    const float hz = n.x, vel = n.y, rel_t = n.w;
-    const f2 env_time = n.z + off;
-    f2 s = (f2)(0.0f), sn = (f2)(0.0f), env_sq = (f2)(0.0f), env_tf = (f2)(0.0f);
+TD_DEV void synth_env4(const AdsrConfD& c, f2 ta, f2 tb, float rel_t, float held, f2& ea, f2& eb) {   // ta, tb: envelope times
+    if (rel_t != 0.0f) {   // apply_r (adsr.rs:71-73): lerp(held, release_vel, min(t / release_sec, 1))
+        const float rs = __builtin_amdgcn_rcpf(c.release_sec), dv = c.release_vel - held;
+        f2 ua = ta * rs, ub = tb * rs;
+        ua.x = fminf(ua.x, 1.0f); ua.y = fminf(ua.y, 1.0f);
+        ub.x = fminf(ub.x, 1.0f); ub.y = fminf(ub.y, 1.0f);
+        ea = held + ua * dv;
+        eb = held + ub * dv;
+        return;
+    }
+    // (times grow with the frame: the wave's first and last; the builtins carry ints)
+    const float lo = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ta.x)));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(tb.y), 63));
+    const int piece = ads_piece(c, lo);
+    const bool tame = fminf(fminf(c.std_vel, c.attack_vel), fminf(c.decay_vel, c.sustain_vel)) > -0.999f;
+    if (tame && lo >= 0.0f && piece == ads_piece(c, hi)) {
+        if (piece == 0) {
+            const float r = __builtin_amdgcn_rcpf(c.attack_sec), dv = c.attack_vel - c.std_vel;
+            ea = c.std_vel + (ta * r) * dv;
+            eb = c.std_vel + (tb * r) * dv;
+        } else if (piece == 1) {
+            const float r = __builtin_amdgcn_rcpf(c.decay_sec), dv = c.decay_vel - c.attack_vel;
+            ea = c.attack_vel + ((ta - c.attack_sec) * r) * dv;
+            eb = c.attack_vel + ((tb - c.attack_sec) * r) * dv;
+        } else if (piece == 2) {
+            const float r = __builtin_amdgcn_rcpf(c.sustain_sec), dv = c.sustain_vel - c.decay_vel;
+            ea = c.decay_vel + (((ta - c.attack_sec) - c.decay_sec) * r) * dv;
+            eb = c.decay_vel + (((tb - c.attack_sec) - c.decay_sec) * r) * dv;
+        } else {
+            ea = eb = (f2)(c.sustain_vel);
+        }
+        return;
+    }
+    ea.x = apply_ads_fast(c, ta.x); ea.y = apply_ads_fast(c, ta.y);
+    eb.x = apply_ads_fast(c, tb.x); eb.y = apply_ads_fast(c, tb.y);
+}
+struct SynthEnv2 { f2 sq, tf, tr; };
+// oscillators x velocity x envelope x volume for the two frames of a pair (extensions.rs:499-524)
+TD_DEV f2 synth_osc2(const SynthDesc& d, const float4 n, const SynthEnv2& e, f2 time) {   // n = (hz, vel, env_t, rel_t)
+    const float hz = n.x, vel = n.y;
+    f2 s = (f2)(0.0f), sn = (f2)(0.0f);
     if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any2(time * hz * 2.0f * kPi);
     if (d.square.volume > 0.0f) {
         const float z = d.square.param;
@@ -1062,8 +1094,7 @@ TD_DEV f2 synth_voice2(const SynthDesc& d, const float4 n, const SynthHeld& h, f
         osc.x = fminf(fmaxf(sn.x, -z), z);
         osc.y = fminf(fmaxf(sn.y, -z), z);
         osc = osc * (1.0f / z);
-        env_sq = synth_env2(d.square.adsr, env_time, rel_t, h.sq);
-        s += osc * vel * env_sq * d.square.volume;
+        s += osc * vel * e.sq * d.square.volume;
     }
     if (d.topflat.volume > 0.0f) {
         const float z = d.topflat.param;
@@ -1071,8 +1102,7 @@ TD_DEV f2 synth_voice2(const SynthDesc& d, const float4 n, const SynthHeld& h, f
         m.x = fminf(sn.x, z);
         m.y = fminf(sn.y, z);
         const f2 osc = (m + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
-        env_tf = d.tf_env_src == 1u ? env_sq : synth_env2(d.topflat.adsr, env_time, rel_t, h.tf);
-        s += osc * vel * env_tf * d.topflat.volume;
+        s += osc * vel * e.tf * d.topflat.volume;
     }
     if (d.triangle.volume > 0.0f) {
         const f2 th = time * hz;
@@ -1083,10 +1113,28 @@ TD_DEV f2 synth_voice2(const SynthDesc& d, const float4 n, const SynthHeld& h, f
         dd.x = fabsf(dd.x);
         dd.y = fabsf(dd.y);
         const f2 osc = 4.0f * dd - 1.0f;
-        const f2 env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf : synth_env2(d.triangle.adsr, env_time, rel_t, h.tr);
-        s += osc * vel * env * d.triangle.volume;
+        s += osc * vel * e.tr * d.triangle.volume;
     }
     return s * d.osc_amp_multiplier;
+}
+// one voice, the lane's four frames: a += voice(pair a), b += voice(pair b)
+TD_DEV void synth_voice4(const SynthDesc& d, const float4 n, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
+    const float rel_t = n.w;
+    const SynthHeld h = synth_held(d, rel_t);
+    const f2 eta = n.z + oa, etb = n.z + ob;
+    SynthEnv2 ea{(f2)(0.0f), (f2)(0.0f), (f2)(0.0f)}, eb = ea;
+    if (d.square.volume > 0.0f) synth_env4(d.square.adsr, eta, etb, rel_t, h.sq, ea.sq, eb.sq);
+    if (d.topflat.volume > 0.0f) {
+        if (d.tf_env_src == 1u) { ea.tf = ea.sq; eb.tf = eb.sq; }
+        else synth_env4(d.topflat.adsr, eta, etb, rel_t, h.tf, ea.tf, eb.tf);
+    }
+    if (d.triangle.volume > 0.0f) {
+        if (d.tr_env_src == 1u) { ea.tr = ea.sq; eb.tr = eb.sq; }
+        else if (d.tr_env_src == 2u) { ea.tr = ea.tf; eb.tr = eb.tf; }
+        else synth_env4(d.triangle.adsr, eta, etb, rel_t, h.tr, ea.tr, eb.tr);
+    }
+    a += synth_osc2(d, n, ea, ta);
+    b += synth_osc2(d, n, eb, tb);
 }
 // The lane's frame pairs ma, ma + 1 and mb, mb + 1.  A wave's frames nearly always lie in ONE interval (intervals start
 // at block starts and event frames): the voice list is then the same for every lane, the voice records come in through
@@ -1113,9 +1161,7 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
         for (uint32_t v = v0; v < v1; ++v) {
             const f4c q = vc[v];
             const float4 n = make_float4(q.x, q.y, q.z, q.w);
-            const SynthHeld h = synth_held(d, n.w);
-            a += synth_voice2(d, n, h, ta, oa);
-            b += synth_voice2(d, n, h, tb, ob);
+            synth_voice4(d, n, ta, tb, oa, ob, a, b);
         }
         pa = make_float2(a.x, two_a ? a.y : 0.0f);
         pb = make_float2(b.x, two_b ? b.y : 0.0f);
