@@ -76,6 +76,8 @@ def ubench():
     L.td_ubench_stream.argtypes = [ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int]
     L.td_ubench_valu_chain_ns.restype = ctypes.c_float
     L.td_ubench_valu_chain_ns.argtypes = []
+    L.td_ubench_fma_issue_ns.restype = ctypes.c_float
+    L.td_ubench_fma_issue_ns.argtypes = [ctypes.c_int]
     return L
 
 
@@ -249,12 +251,15 @@ def other_configs(api, workloads, ub, chain_ns):
                                       "%.1f MB" % (launches, frames * (2 * 4 + 8 + 20) / 1e6)}
         elif dom[0] == "k_synth":
             insts = (valu.get("config3", {}).get("k_synth") or {}).get("SQ_INSTS_VALU")
-            if insts:
-                floor = insts * 2.0 / (SIMDS * CLOCK_HZ) * 1e3   # wave64 on a SIMD-32: 2 cycles of issue per instruction
+            issue_ns = float(ub.td_ubench_fma_issue_ns(SIMDS // 4)) if ub is not None else -1.0
+            if insts and issue_ns > 0:
+                floor = insts * issue_ns / SIMDS * 1e-6
                 entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4),
                                   "SQ_INSTS_VALU_profiled": insts, "profile": "profiles/%s_valu.json" % PROFILE_TAG,
-                                  "note": "wave-level VALU instructions (PMC, committed profile) x 2 cycles / (1024 SIMDs x 2.4 GHz); "
-                                          "transcendental and f32-division sequences issue slower than 2 cycles, so the true floor is higher"}
+                                  "ns_per_fma_per_simd_measured": round(issue_ns, 3),
+                                  "note": "wave-level VALU instructions (PMC, committed profile) x the issue time of the FASTEST class (v_fma_f32, "
+                                          "8 waves per SIMD, measured in this process) / 1024 SIMDs; compares, selects, min / max, conversions "
+                                          "and packed ops issue ~1.7x slower (profiles/r02_issue_rate.txt), so the true floor is higher"}
             else:
                 entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": None, "frac": None, "note": "no committed PMC pass for this round"}
         elif dom[0] == "k_band_spec" and chain_ns and chain_ns > 0:

@@ -116,6 +116,20 @@ __global__ void k_chain(float* out, float g, float x0, int n8) {
     out[threadIdx.x] = y;
 }
 
+// eight independent v_fma_f32 streams per lane: the issue rate of the fastest VALU class (tools/ubench/issue_rate.hip has the rest)
+__global__ __launch_bounds__(256) void k_fma_issue(float* out, float g, int n) {
+    float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+#pragma unroll 1
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            asm volatile("v_fma_f32 %0, %0, %8, %0\n v_fma_f32 %1, %1, %8, %1\n v_fma_f32 %2, %2, %8, %2\n v_fma_f32 %3, %3, %8, %3\n"
+                         " v_fma_f32 %4, %4, %8, %4\n v_fma_f32 %5, %5, %8, %5\n v_fma_f32 %6, %6, %8, %6\n v_fma_f32 %7, %7, %8, %7"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(g));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+}
+
 __global__ void k_fill(uint32_t* p, size_t n, uint32_t salt) {
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t x = (uint32_t)i * 2654435761u + salt;
@@ -243,6 +257,30 @@ float td_ubench_valu_chain_ns(void) {
     hipEventDestroy(e1);
     (void)hipFree(out);
     return ms < 0.f ? -1.f : ms * 1e6f / (float)(n8 * 8 * 3);
+}
+
+// ns per wave-level v_fma_f32 per SIMD with 8 waves per SIMD on every CU (n_cu compute units)
+float td_ubench_fma_issue_ns(int n_cu) {
+    if (n_cu <= 0) return -1.f;
+    const int waves = 8, n = 1000, blocks = n_cu * waves;   // one 256-thread block = one wave on each of a CU's four SIMDs
+    float* out = nullptr;
+    if (hipMalloc(&out, (size_t)blocks * 256 * sizeof(float)) != hipSuccess) return -1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    float ms = -1.f;
+    for (int r = 0; r < 3; ++r) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_fma_issue, dim3(blocks), dim3(256), 0, 0, out, 1.0001f, n);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, e0, e1) == hipSuccess) ms = ms < 0.f ? t : std::min(ms, t);
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    (void)hipFree(out);
+    return ms < 0.f ? -1.f : ms * 1e6f / (64.0f * n * waves);
 }
 
 }  // extern "C"
