@@ -1762,6 +1762,23 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             uint32_t k = 0;
             while (k < cl && !parked && !coalesced) {
+                // A run of bit-identical input frames on which all eight trajectories (the true one and the speculative
+                // twin) stand still -- the silence in front of a hit inside a mixed segment, which no parking covers:
+                // one step proves it for the whole run, the states of the run are filled in by all lanes.
+                if (!flags) {   // (a segment of constant / all-zero input parks instead, below)
+                    const uint2 xk = reinterpret_cast<const uint2*>(xs)[k], xl = reinterpret_cast<const uint2*>(xs)[min(lane, cl - 1u)];
+                    const unsigned long long same = __ballot((lane >= k && lane < cl && xl.x == xk.x && xl.y == xk.y) ? 1 : 0) >> k;
+                    const uint32_t run = same == ~0ull ? 64u : (uint32_t)__ffsll((long long)~same) - 1u;   // (frames k .. k + run - 1)
+                    if (run >= 16u) {
+                        const float yn = yy + gam * (xsf[2u * k + ch] - yy);
+                        if (__all((lane >= 8u || __float_as_uint(yn) == __float_as_uint(yy)) ? 1 : 0)) {
+                            const float yc = __shfl(yy, (int)c, 64);   // the true state of chain c, in every lane
+                            for (uint32_t f = lane >> 2; f < run; f += 16u) ys[(k + f) * 4u + c] = yc;
+                            k += run;
+                            continue;
+                        }
+                    }
+                }
                 const uint32_t nb = min(8u, cl - k);
                 float xv[8];
 #pragma unroll
