@@ -465,6 +465,32 @@ def test_band_pass_repair_storm(gpu_api, oracle, seconds, spacing, lo, hi):
     assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
 
 
+def _soak_case(seed):
+    """One random stutter project: cut-offs from 0 (smoother off) over 30 Hz (block-response guess) to 18 kHz, gap spacings
+    from 4 ms to 0.3 s, lengths 3 - 20 s, sometimes a chunk cap."""
+    rng = np.random.default_rng(1000 + seed)
+    seconds = float(rng.choice([3.0, 8.0, 20.0]))
+    spacing = float(rng.choice([0.004, 0.01, 0.03, 0.08, 0.3]))
+    lo = float(rng.choice([0.0, 30.0, 200.0, 1000.0, 4000.0, 9000.0]))
+    hi = float(rng.choice([0.0, 60.0, 500.0, 3000.0, 12000.0, 18000.0]))
+    if lo == 0.0 and hi == 0.0:
+        hi = 700.0
+    chunk = int(rng.choice([65536, 300000, 1 << 20])) if rng.random() < 0.3 else 0
+    return _stutter_project(seconds, spacing, lo, hi, seed), chunk
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_band_pass_random_soak(gpu_api, oracle, seed):
+    """Randomised soak of the speculative band-pass (k_band_spec / k_band_fix / k_band_fill) against the oracle, bit for
+    bit, fresh and scanned (tools/band_soak.py runs the same cases over any seed range)."""
+    p, chunk = _soak_case(seed)
+    gb, ob = p.build(gpu_api), p.build(oracle)
+    if chunk:
+        gb[2].set_option("max_chunk_frames", chunk)
+    for scan in (False, True):
+        assert_bit_exact(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
+
+
 @pytest.mark.parametrize("bits,seconds,bl", [(16, 40.0, 1000), (24, 40.0, 1000), (16, 58.0, 1024), (24, 58.0, 1024)])
 def test_wide_loop_sums_on_long_timelines(gpu_api, oracle, bits, seconds, bl):
     """Timelines of >= 1800 / >= 2600 tiles switch the all-loop sums to 8 / 16 consecutive frames per lane
