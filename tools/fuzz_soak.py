@@ -1,0 +1,34 @@
+"""The random-project parity test of tests/test_gpu_fuzz.py over any seed range:  python tools/fuzz_soak.py 1000 3000"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from termdaw_amd import api
+from oracle import binding as oracle
+import test_gpu_fuzz as F
+
+lo_seed, hi_seed = int(sys.argv[1]), int(sys.argv[2])
+bad, rejected = [], 0
+for seed in range(lo_seed, hi_seed):
+    p = F.random_project(seed)
+    try:
+        ob = p.build(oracle)
+    except (RuntimeError, KeyError):
+        rejected += 1
+        try:
+            p.build(api)
+            bad.append((seed, "accepted a project the oracle rejects"))
+        except (api.TermdawError, RuntimeError, KeyError):
+            pass
+        continue
+    gb = p.build(api)
+    for scan in (False, True, False):
+        gp, gf = p.render(api, built=gb, scan=scan)
+        op, of = p.render(oracle, built=ob, scan=scan)
+        if (not np.array_equal(np.isnan(gf), np.isnan(of)) or ((F._bits(gf) != F._bits(of)) & ~np.isnan(of)).any()
+                or not np.array_equal(gp, op)):
+            bad.append((seed, scan))
+            break
+print("seeds", lo_seed, hi_seed, "rejected by both:", rejected, "mismatching:", bad)
+sys.exit(1 if bad else 0)
