@@ -180,7 +180,8 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
  * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed
  * only, the bit-wise check and repair keep every result exact);
- * "band_quick" n / "band_medium" n / "band_depth" n (defaults 12 / 30 / 100; band_quick 0 switches the mechanism off):
+ * "band_quick" n / "band_medium" n / "band_depth" n / "band_guess_min" n (defaults 12 / 30 / 100 / 4096 frames: the
+ * guess is used where the short warm-up is at least band_guess_min long; band_quick 0 switches the mechanism off):
  * for cut-offs below ~75 Hz the warm-up starts from the exact-arithmetic state at its first frame (per-256-frame
  * block responses of the two smoothers, chained in double until (1-gamma)^(256 K) <= e^-band_depth) and then only
  * takes n / gamma frames -- again speed only;

@@ -1064,7 +1064,7 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     p.parallel = p.nseg >= 8;        // tiny chunks (block pulls) stay on the serial kernel
     // (the guess pays where the short warm-up is long -- cut-offs below ~75 Hz; elsewhere the walk is a few
     // hundred steps anyway and the block responses would only cost their reduction in the input-sum kernel)
-    if (p.parallel && g->band_quick && p.S == 256 && p.Ws >= 4096u) {
+    if (p.parallel && g->band_quick && p.S == 256 && p.Ws >= g->band_guess_min) {
         // Horner depth: the chained block responses must carry the memory of everything that can still matter.  A deep
         // effect chain swings over tens of decades (84 envelope stages: 25), so "matter" is priced against the whole
         // f32 exponent range a past burst can tower over the present: (1 - gamma)^(256 K) <= e^-band_depth, 100 by
@@ -2765,6 +2765,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
     if (k == "band_quick") { g->band_quick = value > 0 ? (unsigned)value : 0u; return 1; }
     if (k == "band_medium") { g->band_medium = value > 0 ? (unsigned)value : 30u; return 1; }
+    if (k == "band_guess_min") { g->band_guess_min = value > 0 ? (unsigned)value : 0u; return 1; }
     if (k == "band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
