@@ -135,3 +135,33 @@ def test_low_cutoff_band_pass_with_block_response_guess(gpu_api, oracle, lo, hi,
     b2 = p.build(gpu_api)
     b2[2].set_option("band_quick", 0)
     assert_bit_exact(p.render(gpu_api, built=b2), p.render(oracle))
+
+
+def test_timeline_longer_than_the_chunk_cap(gpu_api, oracle):
+    """400 s = 18 751 blocks = 19.2 M frames: more than the 2^24-frame edge-buffer cap, so the render runs as two chunks
+    at the engine's own boundary (no option involved) with every kind of carried state crossing it -- loop cursors beyond
+    2^24, a held sample_lerp voice, envelope clocks, the running normalize peak, the band-pass filter state (speculative
+    segments on both sides) -- fresh and after a normalize scan."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(400.0)
+    assert p.cs * 1024 > (1 << 24)
+    p.assets["a"] = W.Asset(W.noise_int16(3, 50021))
+    p.assets["k"] = W.Asset(W.kick_int16(4, 9000))
+    p.load_sample("a", "a", "")
+    p.load_sample("k", "k", "")
+    hits = [(0.37 * i + 0.011, 60.0, 0.5 + 0.4 * ((i * 7) % 5) / 5.0) for i in range(int(400.0 / 0.37))]
+    p.event_files["h"] = np.array(hits, np.float32)
+    p.load_midi_floww("h", "h")
+    p.add_sampleloop("l", 0.4, 20.0, "a")
+    p.add_sample_lerp("lp", 0.9, -30.0, "k", "h", -1, 64)
+    p.add_adsr("env", 1.0, 0.0, 0.8, "h", False, True, -1, [0.01, 0.05, 0.7, 0.1, 0.3, 0.1])
+    p.add_bandpass("bp", 1.0, 0.0, 1.0, 150.0, 6000.0, True)
+    p.add_normalize("out", 0.9, 0.0)
+    p.connect("l", "env")
+    p.connect("lp", "env")
+    p.connect("env", "bp")
+    p.connect("bp", "out")
+    p.set_output("out")
+    built, obuilt = p.build(gpu_api), p.build(oracle)
+    assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
+    assert_bit_exact(p.render(gpu_api, built=built, scan=True), p.render(oracle, built=obuilt, scan=True))
