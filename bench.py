@@ -185,22 +185,24 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
         step()
     batch.sync()
     batch.host_times(reset=True)             # (the first steps allocate edge buffers: not steady-state host work)
-    exchange()                               # warm the exchange path too (lazy initialisation is not render work)
+    exchange.exchange()                      # warm the exchange path too (lazy initialisation is not render work)
     barrier()
     # HIP events around every launch of every PROF_EVERY-th step, on the engine's stream (the events cost a
     # few microseconds per launch -- a tenth of a single-project step if every render carried them)
-    batch.set_profiling(PROF_EVERY)
+    # (a short timed region -- the driver's K = 20 -- carries two sampled steps, not K / 8 + 1: each costs ~15 us)
+    every = PROF_EVERY if steps >= 64 else max(PROF_EVERY, (steps + 1) // 2)
+    batch.set_profiling(every)
     barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    batch.sync()
-    peaks = exchange()                       # the path's only exchange: one all-reduce(max) of the peak table
+    exchange.exchange()                      # the path's only exchange: one all-reduce(max) of the peak table, on the device
     barrier()
     dt = time.perf_counter() - t0
+    peaks = exchange.host()                  # (the report's copy of the table: outside the timed region, like the PCM it stays in HBM)
     ktimes = batch.kernel_times()
     batch.set_profiling(0)
-    return dt, ktimes, peaks
+    return dt, ktimes, peaks, every
 
 
 def other_configs(api, workloads, ub, chain_ns):
@@ -351,7 +353,7 @@ def main():
     batch, project = build_batch(api, workloads, rank, world, P, args.seconds, args.no_fuse, args.no_pack)
     cs, bl = project.cs, project.bl
     frames = cs * bl
-    dt, ktimes, peaks = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
+    dt, ktimes, peaks, prof_every = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
     dt = reduce_max(dt)
     device_bytes = sum(g.device_bytes() for _, _, g in batch.projects)
     host = batch.host_times()
@@ -369,7 +371,7 @@ def main():
     if want_c5:
         c5_steps = max(2, min(10, args.steps))
         b64, _ = build_batch(api, workloads, rank, world, 64, args.seconds, False, False)
-        dt5, kt5, pk5 = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
+        dt5, kt5, pk5, _ = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
         dt5 = reduce_max(dt5)
         c5 = {"projects_per_gpu": 64, "projects": 64 * world, "steps": c5_steps, "ms_per_step": round(dt5 / c5_steps * 1e3, 4),
               "ms_per_project": round(dt5 / c5_steps / 64 * 1e3, 5),
@@ -517,7 +519,7 @@ def main():
                        "parallelism": "projects sharded across GPUs; RCCL all-reduce(max) of the %d-entry peak table only" % (P * world)},
             "roofline": roofline,
             "rooflines": kernels,
-            "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % PROF_EVERY,
+            "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % prof_every,
             "prewarm": "%.2f s of untimed steps before the W warm-up steps (steady device clocks)" % PREWARM_S,
             "host_ms_per_step": {k: round(v / max(host["steps"], 1), 5) for k, v in host.items() if k != "steps"},
             "peak_table": [round(float(x), 6) for x in peaks[:16]],

@@ -57,24 +57,35 @@ def exchange_peaks(local_peaks, n_projects, dist=None, device="cpu", buf=None):
 class PeakExchange:
     """The per-project peak table of the whole job, kept on the device: the engine writes this rank's entries straight
     into the tensor the collective runs on (td_batch_peak_table_device: own entries at rank + i * world, zeros
-    elsewhere), then ONE all-reduce(max) -- RCCL on device memory, no host round trip.  With a host-side backend
-    (gloo, CPU tests of the N > 1 path) the table takes one D2H copy first."""
+    elsewhere), then ONE all-reduce(max) -- RCCL on device memory, no host round trip.  `exchange()` returns when the
+    table is complete in device memory; `host()` copies it out (the caller's report, not part of the exchange).  With a
+    host-side backend (gloo, CPU tests of the N > 1 path) the collective itself needs the table on the host."""
 
     def __init__(self, batch, per_rank, rank, world, dist=None, on_device=True):
         import torch
         self.batch, self.rank, self.world, self.dist, self.on_device = batch, rank, world, dist, on_device
         self.n_total = per_rank * world
         self.table = torch.zeros(self.n_total, dtype=torch.float32, device="cuda")
+        self._host = None
         torch.cuda.synchronize()
 
-    def __call__(self):
+    def exchange(self):
+        import torch
         self.batch.peak_table_device(self.table.data_ptr(), self.n_total, first=self.rank, stride=self.world)
-        self.batch.sync()
+        self.batch.sync()                 # the engine's stream has written this rank's entries
+        self._host = None
         if self.dist is not None and self.dist.is_initialized():
             if self.on_device:
                 self.dist.all_reduce(self.table, op=self.dist.ReduceOp.MAX)
+                torch.cuda.synchronize()  # the reduced table stands in device memory
             else:
                 t = self.table.cpu()
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-                return t.numpy()
-        return self.table.cpu().numpy()
+                self._host = t.numpy()
+
+    def host(self):
+        return self._host if self._host is not None else self.table.cpu().numpy()
+
+    def __call__(self):
+        self.exchange()
+        return self.host()

@@ -2883,6 +2883,7 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
         b->peaks_cap = 0;
         TD_HIP(hipMalloc(&b->d_peaks, (P + 10) * (sizeof(float) + sizeof(float*))));
         b->peaks_cap = P + 8;
+        b->peak_src.clear();   // (the device copy of the pointer table went with the old allocation)
     }
     const float** d_src = reinterpret_cast<const float**>(b->d_peaks + ((b->peaks_cap + 1) & ~(size_t)1));
     std::vector<const float*> src(P);
@@ -2899,8 +2900,13 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
                 TD_HIP(hipMemsetAsync(b->d_peaks + i, 0, sizeof(float), b->stream));
         }
     }
-    if (P) TD_HIP(hipMemcpyAsync(d_src, src.data(), P * sizeof(float*), hipMemcpyHostToDevice, b->stream));
-    TD_HIP(hipStreamSynchronize(b->stream));   // (src lives on this stack frame)
+    // the pointer table rarely changes (carried normalize states keep their addresses from render to render): the
+    // device copy is reused, and the exchange then costs one small launch and no synchronisation
+    if (src != b->peak_src) {
+        b->peak_src = src;
+        if (P) TD_HIP(hipMemcpyAsync(d_src, b->peak_src.data(), P * sizeof(float*), hipMemcpyHostToDevice, b->stream));
+        TD_HIP(hipStreamSynchronize(b->stream));
+    }
     if (n_total) launch_peak_table(d_src, d_table, (uint32_t)n_total, (uint32_t)P, (uint32_t)first, (uint32_t)stride, b->stream);
     TD_HIP(hipGetLastError());
     return 1;

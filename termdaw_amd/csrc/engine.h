@@ -335,6 +335,7 @@ struct td_batch {
     tde::ProfCtx prof;
     float* d_peaks = nullptr;            // [size] per-project peak scratch + [size] source pointers behind it
     size_t peaks_cap = 0;
+    std::vector<const float*> peak_src;  // the source-pointer table as the device holds it (td_batch_peak_table_device)
     double host_ms[4] = {0, 0, 0, 0};
     size_t host_steps = 0;
 };
