@@ -1156,7 +1156,11 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
         const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
         typedef float f4c __attribute__((ext_vector_type(4)));
         const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
-        const f2 ta = synth_time2(d, ma), tb = synth_time2(d, mb), oa = synth_off2(d, ma), ob = synth_off2(d, mb);
+        f2 ta = synth_time2(d, ma), tb = synth_time2(d, mb), oa = synth_off2(d, ma), ob = synth_off2(d, mb);
+        // a pair's second frame beyond the chunk is never stored: it shadows the first, so that times keep growing with
+        // the lane (its own in-block offset would have wrapped to 0, and synth_env4 reads the wave's last time from lane 63)
+        if (!two_a) { ta.y = ta.x; oa.y = oa.x; }
+        if (!two_b) { tb.y = tb.x; ob.y = ob.x; }
         f2 a = (f2)(0.0f), b = (f2)(0.0f);
         for (uint32_t v = v0; v < v1; ++v) {
             const f4c q = vc[v];

@@ -75,6 +75,29 @@ def test_synth_project(gpu_api, oracle, scan):
     assert_close(p.render(gpu_api, scan=scan), p.render(oracle, scan=scan))
 
 
+@pytest.mark.parametrize("bl,blocks,on_frame", [(1000, 3, 2300), (1000, 3, 2420), (1000, 2, 1300), (1000, 3, 2700), (1024, 3, 2900)])
+def test_synth_envelope_breakpoint_in_the_last_partial_tile(gpu_api, oracle, bl, blocks, on_frame):
+    """k_synth finds the piece of a held voice's envelope once per wave, from the wave's first and last envelope time.
+    With a block length that does not divide the 1024-frame tile the chunk ends inside a tile: the lanes beyond it shadow
+    the last frame, and an attack -> decay breakpoint a few frames before the end (5 ms after the note-on) must still send
+    the wave down the per-frame path -- every frame against the oracle, and the frames around the breakpoint one by one.
+    (The first three cases put both frame pairs of the tile's last wave into the note's interval with the breakpoint
+    between the wave's first frame and the chunk's last.)"""
+    p = W.ProjectScript(48000, bl)
+    p.set_length(blocks * bl / 48000.0 - 1e-4)
+    assert p.cs == blocks
+    p.event_files["n"] = np.array([(0.001, 57.0, 0.7), ((on_frame + 0.5) / 48000.0, 60.0, 0.9)], np.float32)
+    p.load_midi_floww("n", "n")
+    conf = [0.005, 0.05, 0.3, 0.2, 0.1, 0.1]           # attack 240 frames: the breakpoint sits at on_frame + 240
+    p.add_synth("syn", 1.0, 0.0, "n", 0.4, 0.3, conf, 1.0, 0.8, conf, 0.5, [0.004, 0.05, 0.5, 0.2, 0.2, 0.1])
+    p.add_sum("out", 1.0, 0.0)
+    p.connect("syn", "out")
+    p.set_output("out")
+    got, ref = p.render(gpu_api), p.render(oracle)
+    assert_close(got, ref)
+    assert np.abs(got[1].astype(np.float64) - ref[1].astype(np.float64)).max() < 2e-6
+
+
 def test_config3_short(gpu_api, oracle):
     p = W.config3(seconds=4.0)
     assert_close(p.render(gpu_api), p.render(oracle))
