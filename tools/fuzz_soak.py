@@ -1,4 +1,5 @@
-"""The random-project parity test of tests/test_gpu_fuzz.py over any seed range:  python tools/fuzz_soak.py 1000 3000"""
+"""The random-project parity tests of tests/test_gpu_fuzz.py over any seed range:  python tools/fuzz_soak.py 1000 3000
+(bit-exact kinds), python tools/fuzz_soak.py 1000 3000 sinf (projects with debug_sine / synth: <= 1e-6 RMS)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,9 +10,10 @@ from oracle import binding as oracle
 import test_gpu_fuzz as F
 
 lo_seed, hi_seed = int(sys.argv[1]), int(sys.argv[2])
+sinf = len(sys.argv) > 3 and sys.argv[3] == "sinf"
 bad, rejected = [], 0
 for seed in range(lo_seed, hi_seed):
-    p = F.random_project(seed)
+    p = F.random_project(seed, allow_sinf=sinf)
     try:
         ob = p.build(oracle)
     except (RuntimeError, KeyError):
@@ -26,6 +28,14 @@ for seed in range(lo_seed, hi_seed):
     for scan in (False, True, False):
         gp, gf = p.render(api, built=gb, scan=scan)
         op, of = p.render(oracle, built=ob, scan=scan)
+        if sinf:
+            ok = np.isfinite(of)
+            scale = max(1.0, float(np.abs(of[ok]).max()) if ok.any() else 1.0)
+            rms = float(np.sqrt(np.mean(((gf[ok].astype(np.float64) - of[ok].astype(np.float64)) / scale) ** 2))) if ok.any() else 0.0
+            if not np.array_equal(np.isfinite(gf), ok) or rms > 1e-6:
+                bad.append((seed, scan, rms))
+                break
+            continue
         if (not np.array_equal(np.isnan(gf), np.isnan(of)) or ((F._bits(gf) != F._bits(of)) & ~np.isnan(of)).any()
                 or not np.array_equal(gp, op)):
             bad.append((seed, scan))
