@@ -174,8 +174,8 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "packed_samples" 0|1 (default 1: inlined sources gather the packed 16-bit form of samples that came from
  * <= 16-bit integer PCM -- (float)int * scale is how the f32 bank entry was made, so values are identical);
  * "inline_adsr" 0|1 (default 1: an Adsr vertex with one materialised input whose only consumer -- directly or through
- * one single-input Sum -- is a Sum / Normalize / band-pass with no other input is evaluated inside that consumer's
- * summing kernel: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
+ * one single-input Sum -- is a Sum / Normalize / band-pass is evaluated inside that consumer's summing kernel, as one
+ * of its input terms: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
  * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
  * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed

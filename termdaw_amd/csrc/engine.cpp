@@ -1204,18 +1204,17 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             inlined[vi] = g->vertices[vi].kind == K_SAMPLE_LOOP && (long)vi != g->output_vertex;
     // ... and so is a Sum vertex with exactly one (materialised) input -- a gain / pan stage: its consumers read
     // the input's buffer and apply `0.0 + x`, pan, gain themselves (term kind 4); one launch and one buffer less
-    // ... and an Adsr vertex with one materialised input and ONE consumer whose kernel sums nothing else (a Sum, a
-    // Normalize, a band-pass -- directly or through one gain / pan stage): that consumer evaluates the envelope itself
-    // (term kind 5); inlined 3 = such an Adsr vertex, 4 = the stage behind one
+    // ... and an Adsr vertex with one materialised input and ONE consumer whose kernel is of the summing family (a Sum, a
+    // Normalize, a band-pass -- directly or through one gain / pan stage): that consumer evaluates the envelope itself,
+    // as its only term or among others (term kind 5); inlined 3 = such an Adsr vertex, 4 = the stage behind one
     std::vector<std::vector<size_t>> cons(nv);
     for (size_t vi : g->order)
         for (size_t u : g->edges[vi]) cons[u].push_back(vi);
     auto is_stage = [&](size_t vi) {   // a single-input Sum that is not the output
         return g->vertices[vi].kind == K_SUM && (long)vi != g->output_vertex && g->edges[vi].size() == 1;
     };
-    auto sums_one_term = [&](size_t c) {   // consumer kernels that take a TERMS_ADSR1 table (the k_sum family, k_band_pass)
+    auto takes_adsr_terms = [&](size_t c) {   // consumer kernels that take a kind-5 term (the k_sum family, k_band_pass)
         const Vertex& w = g->vertices[c];
-        if (g->edges[c].size() != 1) return false;
         if (w.kind == K_NORMALIZE || w.kind == K_BAND_PASS) return true;
         return w.kind == K_SUM && !is_stage(c);
     };
@@ -1225,8 +1224,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             if (v.kind == K_ADSR && g->inline_adsr && !(v.wet < 0.0001f) && (long)vi != g->output_vertex &&
                 g->edges[vi].size() == 1 && !inlined[g->edges[vi][0]] && cons[vi].size() == 1) {
                 const size_t c = cons[vi][0];
-                const bool direct = sums_one_term(c);
-                const bool staged = is_stage(c) && cons[c].size() == 1 && sums_one_term(cons[c][0]);
+                const bool direct = takes_adsr_terms(c);
+                const bool staged = is_stage(c) && cons[c].size() == 1 && takes_adsr_terms(cons[c][0]);
                 if (direct || staged) {
                     inlined[vi] = 3;
                     const size_t u = g->edges[vi][0];
@@ -1317,12 +1316,12 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         for (size_t vi : by_level[lv]) {
             if (!g->vertices[vi].has_input() || inlined[vi]) continue;   // (an inlined vertex' terms belong to its consumers)
             std::vector<InTerm> ins;
-            long adsr_through = -1;   // the Adsr vertex a kind-5 term reads through
+            std::vector<std::pair<size_t, size_t>> adsr_through;   // (term index, the Adsr vertex a kind-5 term reads through)
             for (size_t u : g->edges[vi]) {
                 InTerm t{};
                 if (inlined[u] == 3 || inlined[u] == 4) {   // Adsr vertex (and the stage behind it), evaluated here
                     const size_t a = inlined[u] == 4 ? g->edges[u][0] : u;
-                    adsr_through = (long)a;
+                    adsr_through.push_back({ins.size(), a});
                     t.p = g->vbuf[g->edges[a][0]];
                     t.kind = 5u;
                     if (inlined[u] == 4) {
@@ -1365,10 +1364,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             term_mode[vi] = all_edge ? (ins.size() < 8 ? TERMS_EDGE_FEW : TERMS_ALL_EDGE)
                                      : (all_loop16 ? TERMS_ALL_LOOP16 : (all_loop ? TERMS_ALL_LOOP32 : TERMS_MIXED));
             ins_off[vi] = st.put(ins);
-            if (adsr_through >= 0) {   // (the only term: sums_one_term) -- the vertex' descriptor, as k_adsr would get it
-                const size_t a = (size_t)adsr_through;
+            if (!adsr_through.empty()) term_mode[vi] = ins.size() == 1 ? TERMS_ADSR1 : TERMS_WITH_ADSR;
+            for (const auto& th : adsr_through) {   // the vertex' descriptor, as k_adsr would get it
+                const size_t a = th.second;
                 const Vertex& av = g->vertices[a];
-                term_mode[vi] = TERMS_ADSR1;
                 AdsrVDesc x{};
                 x.tab.n_int = vt[a].n_int;
                 x.sr = (uint32_t)sr;
@@ -1385,7 +1384,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 tab_field(t, offsetof(IntervalTab, tile_first), vt[a], vt[a].tile_first_off);
                 tab_field(t, offsetof(IntervalTab, ivoff), vt[a], vt[a].ivoff_off);
                 tab_field(t, offsetof(IntervalTab, voices), vt[a], vt[a].voices_off);
-                ptr_field(ins_off[vi], offsetof(InTerm, len), o);
+                ptr_field(ins_off[vi] + th.first * sizeof(InTerm), offsetof(InTerm, len), o);
             }
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)

@@ -42,7 +42,7 @@ struct PanGain {
 //   kind 5: an edge buffer read through an Adsr vertex that has this one input and one consumer (adsr_gen,
 //           extensions.rs:593-651, evaluated per frame by the consumer), optionally followed by a kind-4 stage
 //           (magic != 0, `pg` is then the stage's): `len` = device address of the vertex' AdsrVDesc (tables, envelope, its
-//           own pan / gain).  Always the consumer's only term (TERMS_ADSR1).
+//           own pan / gain).  The consumer's only term (TERMS_ADSR1) or one of several (TERMS_WITH_ADSR).
 struct InTerm {
     const float2* p;   // edge buffer (kind 0) or sample frames (kind 1, 2)
     uint64_t len;      // sample length
@@ -54,7 +54,8 @@ struct InTerm {
 };
 enum TermMode : uint32_t { TERMS_MIXED = 0, TERMS_ALL_EDGE = 1, TERMS_ALL_LOOP32 = 2, TERMS_ALL_LOOP16 = 3,
                            TERMS_EDGE_FEW = 4,     // all edge buffers, fewer than 8: no deep prefetch pipeline (and its registers)
-                           TERMS_ADSR1 = 5 };      // exactly one term, of kind 5
+                           TERMS_ADSR1 = 5,        // exactly one term, of kind 5
+                           TERMS_WITH_ADSR = 6 };  // several terms, at least one of kind 5: summed one term at a time
 
 // Running-peak bookkeeping of normalize_gen (extensions.rs:321-329), carried across chunks / passes.
 // `violated` / `ticket` belong to the speculative single-pass normalize (SumDesc mode 3): both are 0 between launches.

@@ -179,17 +179,17 @@ TD_DEV float4 loop_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
 // the envelope (adsr_frame), pan / gain; then the stage's `0.0 + x`, pan, gain -- the same f32 operations in the same
 // order as the materialised vertices, without their launches and buffers.  `len` holds the vertex' AdsrVDesc.
 TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x);
-TD_DEV float4 adsr_term_pair(TermTab t, uint32_t m, uint32_t M) {
+TD_DEV float4 adsr_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     AdsrVDesc d;
-    __builtin_memcpy(&d, (const AdsrVDesc TD_CONST*)(const TD_CONST char*)(uintptr_t)t[0].len, sizeof d);   // (uniform: scalar loads)
+    __builtin_memcpy(&d, (const AdsrVDesc TD_CONST*)(const TD_CONST char*)(uintptr_t)t[j].len, sizeof d);   // (uniform: scalar loads)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 x = add4(z, load_pair(t[0].p, m, M));
+    const float4 x = add4(z, load_pair(t[j].p, m, M));
     float4 v = z;
     if (m < M) {
         const float2 a = adsr_frame(d, m, make_float2(x.x, x.y));
         const float2 b = (m + 1 < M) ? adsr_frame(d, m + 1, make_float2(x.z, x.w)) : make_float2(0.f, 0.f);
         v = epilogue4(make_float4(a.x, a.y, b.x, b.y), d.pg);
-        if (t[0].magic) v = epilogue4(add4(z, v), term_pg(t, 0));
+        if (t[j].magic) v = epilogue4(add4(z, v), term_pg(t, j));
         v = zero_tail(v, m, M);
     }
     return v;
@@ -202,8 +202,20 @@ template <int MODE>
 TD_DEV void sum_terms(TermTab ins, uint32_t k, uint32_t m0, uint32_t m1, uint32_t M, float4& acc0, float4& acc1) {
     uint32_t j = 0;
     if (MODE == TERMS_ADSR1) {   // exactly one term, kind 5
-        acc0 = add4(acc0, adsr_term_pair(ins, m0, M));
-        acc1 = add4(acc1, adsr_term_pair(ins, m1, M));
+        acc0 = add4(acc0, adsr_term_pair(ins, 0u, m0, M));
+        acc1 = add4(acc1, adsr_term_pair(ins, 0u, m1, M));
+        return;
+    }
+    if (MODE == TERMS_WITH_ADSR) {   // one term at a time (the envelope code once in the loop, not once per unrolled slot)
+        for (; j < k; ++j) {
+            if (ins[j].kind == 5u) {
+                acc0 = add4(acc0, adsr_term_pair(ins, j, m0, M));
+                acc1 = add4(acc1, adsr_term_pair(ins, j, m1, M));
+            } else {
+                acc0 = add4(acc0, term_pair(ins, j, m0, M));
+                acc1 = add4(acc1, term_pair(ins, j, m1, M));
+            }
+        }
         return;
     }
     if (MODE == TERMS_ALL_EDGE && k >= 8) {
@@ -401,6 +413,7 @@ TD_DEV void sum_inputs_pairs(const InTerm* ins_generic, uint32_t k, uint32_t ter
     if (term_mode == TERMS_ALL_EDGE) sum_terms<TERMS_ALL_EDGE>(ins, k, m0, m1, M, a0, a1);
     else if (term_mode == TERMS_ALL_LOOP32) sum_terms<TERMS_ALL_LOOP32>(ins, k, m0, m1, M, a0, a1);
     else if (term_mode == TERMS_ADSR1) sum_terms<TERMS_ADSR1>(ins, k, m0, m1, M, a0, a1);
+    else if (term_mode == TERMS_WITH_ADSR) sum_terms<TERMS_WITH_ADSR>(ins, k, m0, m1, M, a0, a1);
     else sum_terms<TERMS_MIXED>(ins, k, m0, m1, M, a0, a1);
 }
 
@@ -756,6 +769,7 @@ __global__ __launch_bounds__(kThreads) void k_norm_fix(const SumDesc* __restrict
         if (!(last > init)) continue;   // (uniform) every block of this tile was scaled by 1 / init: already right
         float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
         if (d.term_mode == TERMS_ADSR1) sum_terms<TERMS_ADSR1>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
+        else if (d.term_mode == TERMS_WITH_ADSR) sum_terms<TERMS_WITH_ADSR>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
         else sum_terms<TERMS_MIXED>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
         auto rscale_of = [&](uint32_t m) -> float {
             float run = upto;
@@ -2188,6 +2202,7 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
             break;
         case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_EDGE_FEW>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         case TERMS_ADSR1: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ADSR1>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
+        case TERMS_WITH_ADSR: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_WITH_ADSR>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
         default: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_MIXED>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
     }
 }

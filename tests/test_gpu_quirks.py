@@ -322,15 +322,15 @@ def test_graph_replay_is_value_neutral(gpu_api, oracle, project):
     assert_bit_exact(g.render_all(sb, fb, 9, 24), og.render_all(osb, ofb, 9, 24))
 
 
-@pytest.mark.parametrize("consumer", ["normalize", "sum_out", "band", "band_serial", "band_thru", "two_inputs", "two_consumers", "adsr"])
+@pytest.mark.parametrize("consumer", ["normalize", "sum_out", "band", "band_serial", "band_thru", "two_inputs", "three_terms", "two_consumers", "adsr"])
 @pytest.mark.parametrize("stage", [False, True])
 @pytest.mark.parametrize("chunk", [0, 5000])
 def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage, chunk):
-    """An Adsr vertex with one materialised input and one single-input consumer (directly or through a gain / pan stage)
-    is evaluated inside the consumer's summing kernel (term kind 5, option inline_adsr): every consumer kind, with and
-    without the stage, -0.0 inputs, skipped hits (quirk Q9), the shapes that must NOT be inlined (a second input, a second
-    consumer, an Adsr consumer), single- and multi-chunk, scanned and unscanned -- bit-exact against the oracle and
-    against the materialised form."""
+    """An Adsr vertex with one materialised input and one consumer of the summing family (directly or through a gain / pan
+    stage) is evaluated inside the consumer's summing kernel (term kind 5, option inline_adsr): every consumer kind, with
+    and without the stage, as the only term and among others (a second input; two envelopes and an inlined loop source),
+    -0.0 inputs, skipped hits (quirk Q9), the shapes that must NOT be inlined (a second consumer, an Adsr consumer),
+    single- and multi-chunk, scanned and unscanned -- bit-exact against the oracle and against the materialised form."""
     p = W.ProjectScript(48000, 1024)
     p.set_length(0.6)
     pcm = W.noise_int16(31, 4001)
@@ -361,6 +361,16 @@ def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage,
     elif consumer == "two_inputs":
         p.add_normalize("c", 1.0, 0.0)
         p.connect("src", "c")
+    elif consumer == "three_terms":
+        p.add_adsr("env2", 1.2, 10.0, 1.0, "h", False, True, -1, [0.002, 0.03, 0.5, 0.02, 0.1, 0.04])
+        p.connect("src", "env2")
+        p.add_sum("c", 0.9, -5.0)
+        p.add_sum("tail", 1.0, 0.0)             # (keeps "c" from being the output: a materialised inner Sum)
+        p.connect("env2", "c")
+        p.connect("l", "c")                     # an inlined loop source between the two envelopes
+        p.connect(prev, "c")
+        p.connect("src", "tail")
+        p.connect("c", "tail")
     elif consumer == "two_consumers":
         p.add_normalize("c", 1.0, 0.0)
         p.add_sum("side", 0.5, 0.0)
@@ -368,7 +378,10 @@ def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage,
         p.connect("side", "c")
     else:
         p.add_adsr("c", 1.0, 0.0, 0.5, "h", False, True, -1, [0.01, 0.02, 0.6, 0.03, 0.2, 0.05])
-    p.connect(prev, "c")
+    if consumer != "three_terms":
+        p.connect(prev, "c")
+    if consumer == "three_terms":
+        out = "tail"
     if consumer in ("band", "band_serial", "band_thru", "adsr"):
         p.add_normalize("o", 1.0, 0.0)
         p.connect("c", "o")
