@@ -1638,42 +1638,60 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         // (b)'s input frames (interleaved copy) of the lane's eight (segment, frame) slots: loaded a whole 32-frame piece
         // ahead, like the recurrence's own input -- the eight loads of a piece would otherwise be exposed one L2 round trip
         // after the other between the dependent chains
-        auto xo_m = [&](uint32_t i, uint32_t p) -> uint32_t {
-            const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u;
-            return min(wave_seg0 + sq, d.nseg - 1u) * d.S + p + j;   // quads past the end mirror the last segment
-        };
-        float2 xo[8];
+        // A lone wave issues one instruction per ~2.1 ns whatever its kind (tools/ubench/issue_rate.hip), so (b) costs what
+        // it COUNTS: everything that does not change from piece to piece -- the slots' frame offsets, LDS addresses and
+        // first frames, the descriptor's pointers and pan / gain (read through `d` they would be re-fetched by scalar loads
+        // after every global store, which may alias the descriptor for all the compiler knows) -- is worked out once, and
+        // the segments' "constant" / "zero" verdicts are eight ballots after the last piece instead of two per slot.
+        const float2* __restrict__ const x_in = d.x;
+        float2* __restrict__ const out_p = d.out;
+        const PanGain pg = d.pg;
+        const uint32_t S = d.S;
+        uint32_t m0_[8];          // frame of slot i at p = 0 (quads past the end mirror the last segment)
+        const float* ys_rd[8];    // the slot's four states in the wave's LDS staging
+        float2 xo[8], x0r[8];
+        uint32_t live_slots = 0u, not_same = 0u, not_zero = 0u;   // bit i: slot i
 #pragma unroll
-        for (uint32_t i = 0; i < 8u; ++i) xo[i] = gload2(d.x + xo_m(i, 0u));
-        for (uint32_t p = 0; p < d.S; p += 32u) {
+        for (uint32_t i = 0; i < 8u; ++i) {
+            const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u, sraw = wave_seg0 + sq;
+            m0_[i] = min(sraw, d.nseg - 1u) * S + j;
+            ys_rd[i] = ys_l + (wq0 + sq) * kQStride + j * 4u;
+            live_slots |= (sraw < d.nseg ? 1u : 0u) << i;
+            xo[i] = gload2(x_in + m0_[i]);
+        }
+        for (uint32_t p = 0; p < S; p += 32u) {
             TD_BAND_STEP8W(a0, 0) TD_BAND_STEP8W(a1, 8) TD_BAND_STEP8W(a2, 16) TD_BAND_STEP8W(a3, 24)
-            if (p + 32u < d.S) {   // the next 32 frames' input flies during (b)
+            if (p + 32u < S) {   // the next 32 frames' input flies during (b)
                 a0 = fetchq(start + p + 32u); a1 = fetchq(start + p + 40u);
                 a2 = fetchq(start + p + 48u); a3 = fetchq(start + p + 56u);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
             for (uint32_t i = 0; i < 8u; ++i) {
-                const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u;
-                const uint32_t sraw = wave_seg0 + sq;
-                const uint32_t m = min(sraw, d.nseg - 1u) * d.S + p + j;
+                const uint32_t m = m0_[i] + p;
                 const float2 x = xo[i];
-                if (p + 32u < d.S) xo[i] = gload2(d.x + xo_m(i, p + 32u));
-                const float4 s = *reinterpret_cast<const float4*>(ys_l + (wq0 + sq) * kQStride + j * 4u);
-                const float2 x0 = xf_l[wq0 + sq];
+                if (p + 32u < S) xo[i] = gload2(x_in + m + 32u);
+                const float4 s = *reinterpret_cast<const float4*>(ys_rd[i]);
+                if (p == 0u) x0r[i] = xf_l[wq0 + ((i * 64u + lane) >> 5)];
+                const float2 x0 = x0r[i];
                 const bool sm = __float_as_uint(x.x) == __float_as_uint(x0.x) && __float_as_uint(x.y) == __float_as_uint(x0.y);
                 const bool zr = x.x == 0.0f && x.y == 0.0f;
-                const unsigned long long bs = __ballot(sm ? 1 : 0), bz = __ballot(zr ? 1 : 0);
-                if ((uint32_t)bs != 0xFFFFFFFFu) same_mask &= ~(1u << (2u * i));
-                if ((uint32_t)(bs >> 32) != 0xFFFFFFFFu) same_mask &= ~(2u << (2u * i));
-                if ((uint32_t)bz != 0xFFFFFFFFu) zero_mask &= ~(1u << (2u * i));
-                if ((uint32_t)(bz >> 32) != 0xFFFFFFFFu) zero_mask &= ~(2u << (2u * i));
-                if (sraw < d.nseg) gstore2(d.out + m, epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), d.pg));
+                not_same |= (sm ? 0u : 1u) << i;
+                not_zero |= (zr ? 0u : 1u) << i;
+                if ((live_slots >> i) & 1u) gstore2(out_p + m, epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), pg));
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
 #undef TD_BAND_STEP8W
 #undef TD_BAND_S1
+#pragma unroll
+        for (uint32_t i = 0; i < 8u; ++i) {   // slot i: lanes 0..31 hold segment 2 i of the wave, lanes 32..63 segment 2 i + 1
+            const unsigned long long bs = __ballot(((not_same >> i) & 1u) ? 1 : 0), bz = __ballot(((not_zero >> i) & 1u) ? 1 : 0);
+            if ((uint32_t)bs != 0u) same_mask &= ~(1u << (2u * i));
+            if ((uint32_t)(bs >> 32) != 0u) same_mask &= ~(2u << (2u * i));
+            if ((uint32_t)bz != 0u) zero_mask &= ~(1u << (2u * i));
+            if ((uint32_t)(bz >> 32) != 0u) zero_mask &= ~(2u << (2u * i));
+        }
         if (live) d.seg_final[seg * 4u + c] = y;
         if (c == 0u && live) {
             const uint32_t q = quad & 15u;
