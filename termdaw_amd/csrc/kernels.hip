@@ -1760,6 +1760,12 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
     const uint32_t lane = threadIdx.x & 63u, c = lane & 3u, ch = c & 1u;
     const float gam = (c & 2u) ? d.hgamma : d.lgamma;
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
+    // (read once: through `d` they would be re-fetched by scalar loads after every global store of the loops below)
+    const float2* __restrict__ const x_in = d.x;
+    float2* const out_p = d.out;
+    const PanGain pg = d.pg;
+    const uint32_t S = d.S;
+    const uint32_t* const seg_flags = d.seg_flags;
     uint32_t* Su = reinterpret_cast<uint32_t*>(d.seg_start);
     uint32_t* Fu = reinterpret_cast<uint32_t*>(d.seg_final);
     uint4* S4 = reinterpret_cast<uint4*>(d.seg_start);
@@ -1771,9 +1777,9 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
     float y = __shfl(__uint_as_float(Fu[(seg - 1u) * 4u + c]), (int)c, 64);
     bool first_round = true;
     for (;;) {
-        const uint32_t start = seg * d.S, end = min(start + d.S, M), len = end - start;
+        const uint32_t start = seg * S, end = min(start + S, M), len = end - start;
         // everything this round needs from global memory, issued together (one round trip)
-        const uint32_t flags = d.seg_flags[seg];
+        const uint32_t flags = seg_flags[seg];
         const uint2 x0 = X0[seg];
         const uint32_t su = Su[seg * 4u + c];
         const uint32_t fu_old = Fu[seg * 4u + c];
@@ -1794,7 +1800,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
         while (n < len && !parked && !coalesced) {
             // the next 64 frames of input (most repairs park or coalesce within the first few frames)
             const uint32_t cl = min(64u, len - n);
-            if (lane < cl) xs[lane] = gload2(d.x + start + n + lane);
+            if (lane < cl) xs[lane] = gload2(x_in + start + n + lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             uint32_t k = 0;
             while (k < cl && !parked && !coalesced) {
@@ -1846,7 +1852,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
                         const uint32_t s2 = e + lane;
                         bool ok = false;
                         if (s2 < hi && !flagged(s2)) {
-                            const uint32_t f2 = d.seg_flags[s2];
+                            const uint32_t f2 = seg_flags[s2];
                             if (zero_ok) ok = (f2 & 2u) != 0u;
                             else { const uint2 x2 = X0[s2]; ok = (f2 & 1u) && x2.x == x0.x && x2.y == x0.y; }
                         }
@@ -1859,7 +1865,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
                     if (lane == 0u) {
                         BandJob j;
                         j.begin = start + n + k + (uint32_t)u + 1u;
-                        j.end = min(e * d.S, M);
+                        j.end = min(e * S, M);
                         j.y[0] = y0; j.y[1] = y1; j.y[2] = y2; j.y[3] = y3;
                         j.pad[0] = j.pad[1] = 0u;
                         d.jobs[slot] = j;
@@ -1881,7 +1887,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
             if (lane < k) {
                 const float2 x = xs[lane];
                 const float4 s = reinterpret_cast<const float4*>(ys)[lane];
-                d.out[start + n + lane] = epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), d.pg);
+                out_p[start + n + lane] = epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), pg);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             n += k;
