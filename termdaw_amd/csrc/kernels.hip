@@ -1938,6 +1938,7 @@ TD_DEV bool band_fix_range(const BandSpecDesc& d, uint32_t M, uint32_t lo, uint3
     for (;;) {
         if (tid == 0) L.n_events = 0;
         // ---- Phase A: mismatch bitmap (each wave owns two whole words per pass; four passes' loads in flight)
+        bool saw = false;
         for (uint32_t base = lo; base < hi; base += 4u * kFixThreads) {
             uint4 a[4], p[4];
 #pragma unroll
@@ -1950,13 +1951,15 @@ TD_DEV bool band_fix_range(const BandSpecDesc& d, uint32_t M, uint32_t lo, uint3
                 const uint32_t s = base + (uint32_t)u * kFixThreads + tid;
                 const bool mis = s > 0u && s < hi && (a[u].x != p[u].x || a[u].y != p[u].y || a[u].z != p[u].z || a[u].w != p[u].w);
                 const unsigned long long m = __ballot(mis ? 1 : 0);
+                saw = saw || m != 0ull;
                 if (lane == 0u && s < hi) {
                     L.bitmap[(s - lo) >> 5] = (uint32_t)m;
                     L.bitmap[((s - lo) >> 5) + 1u] = (uint32_t)(m >> 32);
                 }
             }
         }
-        __syncthreads();
+        // the all-clear -- nearly every call of nearly every render -- leaves here, without the list's scans and barriers
+        if (!__syncthreads_or(saw ? 1 : 0)) break;
         // ---- ... and the ordered event list: one bitmap word per lane, block-wide exclusive scan of the counts
         for (uint32_t wbase = 0; wbase < nwords; wbase += kFixThreads) {
             const uint32_t wi = wbase + tid;
