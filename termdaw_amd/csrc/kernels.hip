@@ -2059,19 +2059,19 @@ __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __
 // output follows from its own input frame -- fully parallel.  seg_job maps a segment to the job covering it.
 __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __restrict__ descs, uint32_t M) {
     const BandSpecDesc& d = descs[blockIdx.y];
-    if (d.stats[3] == 0u) return;
+    if (d.stats[3] == 0u) return;   // (no job: the usual case -- which is why the grid is a few hundred workgroups, not one per tile)
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
-    const uint32_t tile0 = blockIdx.x * kTileFrames;
-    for (uint32_t f = threadIdx.x; f < (uint32_t)kTileFrames; f += kThreads) {
-        const uint32_t m = tile0 + f;
-        if (m >= M) break;
-        const uint32_t j = d.seg_job[m / d.S];
-        if (j == kNoJob) continue;
-        const BandJob jb = d.jobs[j];
-        if (m < jb.begin || m >= jb.end) continue;
-        const float2 x = d.x[m];
-        d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
-    }
+    for (uint32_t tile0 = blockIdx.x * kTileFrames; tile0 < M; tile0 += gridDim.x * kTileFrames)
+        for (uint32_t f = threadIdx.x; f < (uint32_t)kTileFrames; f += kThreads) {
+            const uint32_t m = tile0 + f;
+            if (m >= M) break;
+            const uint32_t j = d.seg_job[m / d.S];
+            if (j == kNoJob) continue;
+            const BandJob jb = d.jobs[j];
+            if (m < jb.begin || m >= jb.end) continue;
+            const float2 x = d.x[m];
+            d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2294,7 +2294,7 @@ void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max
 }
 void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
-    TD_BATCHED(k_band_fill, tiles(frames), kThreads, d, n, frames);
+    TD_BATCHED(k_band_fill, std::min(tiles(frames), 1024u), kThreads, d, n, frames);
 }
 #undef TD_BATCHED
 static inline uint32_t grid_for(uint32_t n) { return max(1u, min((n + kThreads - 1) / kThreads, 2048u)); }
