@@ -173,7 +173,7 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders);
  * "packed_samples" 0|1 (default 1: inlined sources gather the packed 16-bit form of samples that came from
  * <= 16-bit integer PCM -- (float)int * scale is how the f32 bank entry was made, so values are identical);
- * "inline_adsr" 0|1 (default 1: an Adsr vertex with one materialised input whose only consumer -- directly or through
+ * "inline_adsr" 0|1 (default 1: an Adsr vertex with one input (not itself such a vertex) whose only consumer -- directly or through
  * one single-input Sum -- is a Sum / Normalize / band-pass is evaluated inside that consumer's summing kernel, as one
  * of its input terms: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);

@@ -1218,18 +1218,24 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         if (w.kind == K_NORMALIZE || w.kind == K_BAND_PASS) return true;
         return w.kind == K_SUM && !is_stage(c);
     };
+    // the buffer behind input u (read directly, or through a gain / pan stage) must live until level lv
+    auto outlive = [&](size_t u, int lv) {
+        if (inlined[u] == 2) u = g->edges[u][0];
+        else if (inlined[u]) return;   // (a loop source has no buffer)
+        last_use[u] = std::max(last_use[u], lv);
+    };
     if (g->fuse_sources)
         for (size_t vi : g->order) {   // topological order: the input's own flag is final here
             const Vertex& v = g->vertices[vi];
             if (v.kind == K_ADSR && g->inline_adsr && !(v.wet < 0.0001f) && (long)vi != g->output_vertex &&
-                g->edges[vi].size() == 1 && !inlined[g->edges[vi][0]] && cons[vi].size() == 1) {
+                g->edges[vi].size() == 1 && inlined[g->edges[vi][0]] < 3 && cons[vi].size() == 1) {
+                // (its input: an edge buffer, an inlined loop source or a gain / pan stage -- anything but another envelope)
                 const size_t c = cons[vi][0];
                 const bool direct = takes_adsr_terms(c);
                 const bool staged = is_stage(c) && cons[c].size() == 1 && takes_adsr_terms(cons[c][0]);
                 if (direct || staged) {
                     inlined[vi] = 3;
-                    const size_t u = g->edges[vi][0];
-                    last_use[u] = std::max(last_use[u], last_use[vi]);
+                    outlive(g->edges[vi][0], last_use[vi]);
                 }
                 continue;
             }
@@ -1237,8 +1243,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             const size_t u = g->edges[vi][0];
             if (inlined[u] == 3) {
                 inlined[vi] = 4;
-                const size_t in = g->edges[u][0];
-                last_use[in] = std::max(last_use[in], last_use[vi]);   // the envelope's input outlives the stage's consumer
+                outlive(g->edges[u][0], last_use[vi]);   // the envelope's input outlives the stage's consumer
                 continue;
             }
             if (inlined[u]) continue;
@@ -1317,18 +1322,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             if (!g->vertices[vi].has_input() || inlined[vi]) continue;   // (an inlined vertex' terms belong to its consumers)
             std::vector<InTerm> ins;
             std::vector<std::pair<size_t, size_t>> adsr_through;   // (term index, the Adsr vertex a kind-5 term reads through)
-            for (size_t u : g->edges[vi]) {
+            // a term of kind 0 .. 4: vertex u as an edge buffer, through a gain / pan stage, or as an inlined loop source
+            auto plain_term = [&](size_t u) {
                 InTerm t{};
-                if (inlined[u] == 3 || inlined[u] == 4) {   // Adsr vertex (and the stage behind it), evaluated here
-                    const size_t a = inlined[u] == 4 ? g->edges[u][0] : u;
-                    adsr_through.push_back({ins.size(), a});
-                    t.p = g->vbuf[g->edges[a][0]];
-                    t.kind = 5u;
-                    if (inlined[u] == 4) {
-                        t.magic = 1u;
-                        t.pg = make_pg(g->vertices[u].gain, g->vertices[u].angle);
-                    }
-                } else if (inlined[u] == 2) {   // single-input Sum stage, read through
+                if (inlined[u] == 2) {   // single-input Sum stage, read through
                     t.p = g->vbuf[g->edges[u][0]];
                     t.kind = 4u;
                     t.pg = make_pg(g->vertices[u].gain, g->vertices[u].angle);
@@ -1351,6 +1348,21 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 } else {
                     t.p = g->vbuf[u];
                 }
+                return t;
+            };
+            for (size_t u : g->edges[vi]) {
+                InTerm t{};
+                if (inlined[u] == 3 || inlined[u] == 4) {   // Adsr vertex (and the stage behind it), evaluated here
+                    const size_t a = inlined[u] == 4 ? g->edges[u][0] : u;
+                    adsr_through.push_back({ins.size(), a});
+                    t.kind = 5u;
+                    if (inlined[u] == 4) {
+                        t.magic = 1u;
+                        t.pg = make_pg(g->vertices[u].gain, g->vertices[u].angle);
+                    }
+                } else {
+                    t = plain_term(u);
+                }
                 ins.push_back(t);
             }
             bool all_edge = true, all_loop = !ins.empty(), all_loop16 = !ins.empty();
@@ -1370,6 +1382,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 const Vertex& av = g->vertices[a];
                 AdsrVDesc x{};
                 x.tab.n_int = vt[a].n_int;
+                x.k = 1u;   // its one input, as a term table of its own (kind 0 .. 4)
                 x.sr = (uint32_t)sr;
                 x.bl = (uint32_t)bl;
                 x.use_off = av.use_off;
@@ -1377,8 +1390,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 x.wet = av.wet;
                 x.conf = av.conf;
                 x.pg = make_pg(av.gain, av.angle);
+                const size_t in_off = st.put(std::vector<InTerm>{plain_term(g->edges[a][0])});
                 const size_t o = st.alloc(sizeof x);
                 memcpy(&st.b[o], &x, sizeof x);
+                ptr_field(o, offsetof(AdsrVDesc, ins), in_off);
                 const size_t t = o + offsetof(AdsrVDesc, tab);
                 tab_field(t, offsetof(IntervalTab, istart), vt[a], vt[a].istart_off);
                 tab_field(t, offsetof(IntervalTab, tile_first), vt[a], vt[a].tile_first_off);

@@ -174,16 +174,17 @@ TD_DEV float4 loop_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     return zero_tail(epilogue4(loop_pair32(t[j].p, (uint32_t)t[j].len, t[j].magic, (uint32_t)t[j].t0 + m), term_pg(t, j)), m, M);
 }
 
-// InTerm kind 5: an edge buffer read THROUGH an Adsr vertex with this one input (and, magic != 0, a single-input Sum
-// stage behind it): the consumer does the vertex' own work per frame pair -- `0.0 + x` (its sum_inputs over one input),
-// the envelope (adsr_frame), pan / gain; then the stage's `0.0 + x`, pan, gain -- the same f32 operations in the same
-// order as the materialised vertices, without their launches and buffers.  `len` holds the vertex' AdsrVDesc.
+// InTerm kind 5: an input read THROUGH an Adsr vertex that has this one input (and, magic != 0, a single-input Sum
+// stage behind it): the consumer does the vertex' own work per frame pair -- `0.0 + x` (its sum_inputs over one input,
+// itself a term of kind 0 .. 4: AdsrVDesc::ins), the envelope (adsr_frame), pan / gain; then the stage's `0.0 + x`, pan,
+// gain -- the same f32 operations in the same order as the materialised vertices, without their launches and buffers.
+// `len` holds the vertex' AdsrVDesc.
 TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x);
 TD_DEV float4 adsr_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
     AdsrVDesc d;
     __builtin_memcpy(&d, (const AdsrVDesc TD_CONST*)(const TD_CONST char*)(uintptr_t)t[j].len, sizeof d);   // (uniform: scalar loads)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 x = add4(z, load_pair(t[j].p, m, M));
+    const float4 x = add4(z, term_pair(term_tab(d.ins), 0u, m, M));   // the vertex' own input: an edge buffer, a stage, a loop source
     float4 v = z;
     if (m < M) {
         const float2 a = adsr_frame(d, m, make_float2(x.x, x.y));

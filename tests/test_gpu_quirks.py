@@ -325,7 +325,8 @@ def test_graph_replay_is_value_neutral(gpu_api, oracle, project):
 @pytest.mark.parametrize("consumer", ["normalize", "sum_out", "band", "band_serial", "band_thru", "two_inputs", "three_terms", "two_consumers", "adsr"])
 @pytest.mark.parametrize("stage", [False, True])
 @pytest.mark.parametrize("chunk", [0, 5000])
-def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage, chunk):
+@pytest.mark.parametrize("inp", ["sum", "loop", "stage"])
+def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage, chunk, inp):
     """An Adsr vertex with one materialised input and one consumer of the summing family (directly or through a gain / pan
     stage) is evaluated inside the consumer's summing kernel (term kind 5, option inline_adsr): every consumer kind, with
     and without the stage, as the only term and among others (a second input; two envelopes and an inlined loop source),
@@ -338,12 +339,22 @@ def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage,
     p.assets["a"] = W.Asset(pcm)
     p.load_sample("a", "a", "")
     p.add_sampleloop("l", -0.7, 10.0, "a")      # negative gain: zeros of the asset become -0.0
-    p.add_sum("src", 1.0, 0.0)                  # materialised input of the envelope
+    p.add_sum("src", 1.0, 0.0)                  # a materialised vertex (two inputs: no gain / pan stage)
     p.connect("l", "src")
+    p.connect("l", "src")
+    # the envelope's own input: that edge buffer, an inlined loop source, or a gain / pan stage over the buffer
+    env_in = "src"
+    if inp == "loop":
+        p.add_sampleloop("l2", 0.6, -25.0, "a")
+        env_in = "l2"
+    elif inp == "stage":
+        p.add_sum("pre", 0.8, 33.0)
+        p.connect("src", "pre")
+        env_in = "pre"
     p.event_files["h"] = np.array([(0.03, 60.0, 0.9), (0.11, 61.0, 0.5), (0.13, 60.0, 0.0), (0.3, 60.0, 0.7), (0.45, 60.0, 0.0)], np.float32)
     p.load_midi_floww("h", "h")
     p.add_adsr("env", 0.8, -20.0, 0.7, "h", True, False, 60, [0.01, 0.02, 0.6, 0.03, 0.2, 0.05])
-    p.connect("src", "env")
+    p.connect(env_in, "env")
     prev = "env"
     if stage:
         p.add_sum("st", 1.3, 15.0)
