@@ -975,10 +975,10 @@ static void free_arena(Arena& ar) {
     ar = Arena{};
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_QUANT, F_COUNT };
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
                                            "k_synth",       "k_sampsyn", "k_sum",          "k_scale",       "k_norm_fix",
-                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_quantise"};
+                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise"};
 
 static hipEvent_t get_event(ProfCtx& pc) {
     if (!pc.free_ev.empty()) {
@@ -1089,6 +1089,32 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
         }
     }
     return p;
+}
+
+// Tolerance-class band-pass (engine option "band_mode" 1, kernels.h BandScanDesc): tile = nf * 256 frames, look-back depth
+// K = tiles after which (1 - gamma)^(tile K) <= e^-band_depth for the slower smoother.  Not usable (-> the exact kernels)
+// when that takes more than kScanMaxK tiles (cut-offs below ~1.5 Hz) or the chunk is too long for 32-bit tile frames.
+struct ScanPlan {
+    int nf = 16;
+    uint32_t n_tiles = 0, K = 1;
+    size_t pw_off = 0;
+};
+static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPlan* sp) {
+    if (M >= 0x7FFF0000ull) return false;
+    sp->nf = g->band_scan_nf == 8 ? 8 : 16;
+    const double tile = (double)band_scan_tile_frames(sp->nf);
+    sp->n_tiles = (uint32_t)((M + (size_t)tile - 1) / (size_t)tile);
+    double kmax = 1.0;
+    for (float gamma : {v.lgamma, v.hgamma}) {
+        if (gamma == 0.0f) continue;            // constant chain: no look-back (kernels.hip k_band_scan)
+        const double q = 1.0 - (double)gamma;
+        if (!(q > 0.0)) continue;               // gamma = 1: the state is the last input frame
+        const double per_tile = -tile * log(q); // nats of decay per tile
+        kmax = std::max(kmax, ceil((double)g->band_depth / per_tile));
+    }
+    if (!(kmax <= (double)kScanMaxK)) return false;
+    sp->K = (uint32_t)kmax;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1253,6 +1279,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
 
     std::vector<std::vector<size_t>> by_level(g->n_levels);
     for (size_t vi : g->order) by_level[g->level[vi]].push_back(vi);
+    std::map<std::string, size_t> scan_pw_off;   // k_band_scan power tables of this chunk, by (gammas, nf)
     auto add_launch = [&](int fam, size_t off, int n, uint32_t aux, int level) {
         cb.launches.push_back({fam, off, n, aux, level, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0});
     };
@@ -1275,6 +1302,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::vector<size_t> fam_v[F_COUNT];
         std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
         std::map<size_t, BandPlan> band_plan;
+        std::map<size_t, ScanPlan> scan_plan;
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
             if (inlined[vi]) continue;
@@ -1297,6 +1325,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 case K_BAND_PASS:
                     if (v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) {
                         fam_v[F_SUM].push_back(vi);   // extensions.rs:657-658: the summed input passes through
+                    } else if (ScanPlan sp; g->band_mode == 1 && plan_band_scan(g, v, M, &sp)) {
+                        scan_plan[vi] = sp;
+                        fam_v[F_BAND_SCAN].push_back(vi);
                     } else {
                         BandPlan bp = plan_band(g, v, M);
                         if (bp.parallel) {
@@ -1734,6 +1765,63 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 } break;
                 case F_BAND_FIX:
                 case F_BAND_FILL: off = band_desc_off; break;   // reuse the k_band_spec descriptors
+                case F_BAND_SCAN: {
+                    for (size_t vi : vs)
+                        if (term_mode[vi] == TERMS_ALL_LOOP16 || term_mode[vi] == TERMS_ALL_LOOP32) term_mode[vi] = TERMS_MIXED;
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[a] < term_mode[b]; });
+                    std::vector<BandScanDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        ScanPlan& sp = scan_plan[vi];
+                        BandScanDesc x{};
+                        x.out = g->vbuf[vi];
+                        x.state = &g->dstate[v.state_slot].band;
+                        x.k = (uint32_t)g->edges[vi].size();
+                        x.term_mode = term_mode[vi];
+                        x.pass = v.pass;
+                        x.n_tiles = sp.n_tiles;
+                        x.K = sp.K;
+                        x.flags = g->band_scan_debug ? 1u : 0u;
+                        x.lgamma = v.lgamma;
+                        x.hgamma = v.hgamma;
+                        x.pg = make_pg(v.gain, v.angle);
+                        const double nf = (double)sp.nf;
+                        const double q[2] = {1.0 - (double)v.lgamma, 1.0 - (double)v.hgamma};
+                        for (int c = 0; c < 2; ++c) {
+                            for (int s2 = 0; s2 < 6; ++s2) x.ap[c][s2] = pow(q[c], nf * (double)(1 << s2));
+                            x.aw[c] = pow(q[c], nf * 64.0);
+                            x.at[c] = pow(q[c], nf * 256.0);
+                        }
+                        std::string key;
+                        put_pod(key, v.lgamma); put_pod(key, v.hgamma); put_pod(key, sp.nf);
+                        auto it = scan_pw_off.find(key);
+                        if (it == scan_pw_off.end()) {
+                            std::vector<double> pw(128);
+                            for (int c = 0; c < 2; ++c)
+                                for (int l = 0; l < 64; ++l) pw[c * 64 + l] = pow(q[c], nf * (double)l);
+                            it = scan_pw_off.emplace(key, st.put(pw)).first;
+                        }
+                        sp.pw_off = it->second;
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const size_t o = off + i * sizeof(BandScanDesc);
+                        ptr_field(o, offsetof(BandScanDesc, ins), ins_off[vs[i]]);
+                        ptr_field(o, offsetof(BandScanDesc, pw), scan_plan[vs[i]].pw_off);
+                        cb.sync_fix.push_back({o + offsetof(BandScanDesc, sync), cb.sync_bytes});
+                        cb.sync_bytes += (size_t)scan_plan[vs[i]].n_tiles * 64;
+                    }
+                    size_t b = 0;   // one launch per term mode (vs is sorted by it)
+                    while (b < vs.size()) {
+                        size_t e2 = b;
+                        while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) ++e2;
+                        add_launch(fam, off + b * sizeof(BandScanDesc), (int)(e2 - b),
+                                   term_mode[vs[b]] | ((uint32_t)scan_plan[vs[b]].nf << 8), lv);
+                        b = e2;
+                    }
+                    continue;
+                }
                 default: continue;
             }
             if (fam == F_SUM || fam == F_ADSR) {   // split at term-mode boundaries (vs is sorted by it)
@@ -1793,6 +1881,7 @@ static size_t desc_size(int fam) {
         case F_BAND_SPEC:
         case F_BAND_FIX:
         case F_BAND_FILL: return sizeof(BandSpecDesc);
+        case F_BAND_SCAN: return sizeof(BandScanDesc);
         case F_QUANT: return sizeof(QuantDesc);
         default: return 0;
     }
@@ -1854,7 +1943,12 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     }
     // ---- 3. upload
     const size_t upload = (st.b.size() + 255) & ~(size_t)255;
-    if (!ensure_arena(ar, upload + cb.scratch_bytes + 256, stream)) return 0;
+    const size_t sync_at = upload + ((cb.scratch_bytes + 255) & ~(size_t)255);
+    if (!ensure_arena(ar, sync_at + cb.sync_bytes + 256, stream)) return 0;
+    for (auto& f : cb.sync_fix) {
+        uint64_t p = (uint64_t)(uintptr_t)(ar.d + sync_at + f.off);
+        memcpy(&st.b[f.at], &p, 8);
+    }
     for (auto& f : cb.table_fix) {
         uint64_t p = (uint64_t)(uintptr_t)(ar.d + f.off);
         memcpy(&st.b[f.at], &p, 8);
@@ -1886,6 +1980,8 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     if (want_graph) {
         gkey.reserve(launches.size() * 4 + cb.zero.size() * 2 + 2);
         gkey.push_back(upload);
+        gkey.push_back(sync_at);
+        gkey.push_back(cb.sync_bytes);
         for (auto& z : cb.zero) { gkey.push_back(z.off); gkey.push_back(z.bytes); }
         for (auto& L : launches) {
             gkey.push_back(((uint64_t)(uint32_t)L.fam << 32) | (uint32_t)L.n);
@@ -1905,6 +2001,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         TD_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     }
     for (auto& z : cb.zero) TD_HIP(hipMemsetAsync(ar.d + upload + z.off, 0, z.bytes, stream));
+    if (cb.sync_bytes) TD_HIP(hipMemsetAsync(ar.d + sync_at, 0, cb.sync_bytes, stream));
 
     // ---- 4. launch, level by level
     const auto tp3 = std::chrono::steady_clock::now();
@@ -1944,6 +2041,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, L.M, s); break;
+                case F_BAND_SCAN: launch_band_scan((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)(L.aux >> 8), s); break;
                 case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, L.M, s); break;
             }
         }
@@ -2775,6 +2873,17 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
+    if (k == "band_mode") {   // 0: exact (default, the parity mode), 1: blocked affine scan (tolerance class)
+        if (value != 0 && value != 1) return fail("band_mode must be 0 (exact) or 1 (scan)");
+        g->band_mode = (int)value;
+        return 1;
+    }
+    if (k == "band_scan_nf") {
+        if (value != 8 && value != 16) return fail("band_scan_nf must be 8 or 16");
+        g->band_scan_nf = (int)value;
+        return 1;
+    }
+    if (k == "band_scan_debug") { g->band_scan_debug = value != 0; return 1; }
     if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
     if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
     if (k == "band_quick") { g->band_quick = value > 0 ? (unsigned)value : 0u; return 1; }

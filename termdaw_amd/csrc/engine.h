@@ -233,6 +233,10 @@ struct ChunkBuild {
     std::vector<Fix> table_fix;     // pointer fields -> uploaded tables
     struct Zero { size_t off, bytes; };
     std::vector<Zero> zero;         // scratch ranges that need a memset before the launches
+    // hand-off words of the in-launch scans (k_band_scan's granules): one region behind the scratch, zeroed by ONE
+    // memset per submission
+    size_t sync_bytes = 0;
+    std::vector<Fix> sync_fix;
     std::vector<Launch> launches;
     size_t n_graphs = 0;
     void clear() {
@@ -241,6 +245,8 @@ struct ChunkBuild {
         scratch_fix.clear();
         table_fix.clear();
         zero.clear();
+        sync_bytes = 0;
+        sync_fix.clear();
         launches.clear();
         n_graphs = 0;
     }
@@ -309,6 +315,10 @@ struct td_graph {
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
+    int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
+                                               //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex)
+    int band_scan_nf = 16;                     // frames per lane of k_band_scan (8 | 16): tile = 256 x that
+    bool band_scan_debug = false;              // (tests) every k_band_scan poll times out: predecessors are recomputed
     std::vector<size_t> band_stats_off;        // scratch offsets of the last chunk's k_band_fix counters
     const uint8_t* band_stats_base = nullptr;  // device scratch base those offsets refer to
     size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)

@@ -299,6 +299,38 @@ struct BandSpecDesc {
     uint32_t pad2[3];
 };
 
+// band_pass_gen, TOLERANCE class (engine option "band_mode" 1; <= 1e-6 RMS against the exact forms above): the four
+// one-pole recurrences  y <- y + gamma (x - y)  =  (1 - gamma) y + gamma x  as a blocked affine scan, ONE launch per
+// vertex that also evaluates the vertex' input terms (no materialised input sum).
+//   A workgroup owns a tile of NF * 256 consecutive frames, a lane NF consecutive frames.  Per lane the zero-state
+//   response b of its run (double), a wave / workgroup scan of the (a^NF, b) pairs gives the tile's response B, which
+//   is published as eight 8-byte {tag, value} granules (agent-scope atomic stores).  The state entering the tile is
+//   the Horner chain  C = sum_j a_tile^(j-1) B_(tile-j)  over the K preceding tiles (a_tile^K <= e^-depth: what is
+//   dropped is below the f32 denormal floor), read back with agent-scope atomic loads; then every lane starts from its
+//   exact-arithmetic entry state rounded to f32 and runs the REFERENCE's expression over its NF frames, so what
+//   differs from the exact kernels is only the entry state's last bits (the f32 trajectory's own accumulated rounding).
+//   Waiting is bounded: a predecessor (lower blockIdx.x) that has not published in time is recomputed by the waiting
+//   workgroup itself -- same arithmetic, same values -- so nothing depends on dispatch order; only tile 0, which
+//   depends on nobody, is waited for without bound.
+constexpr uint32_t kScanMaxK = 128;   // look-back depth limit (tiles); slower smoothers take the exact kernels
+struct BandScanDesc {
+    const InTerm* ins;          // the vertex' input terms, in connect() order
+    float2* out;
+    BandState* state;           // carried across chunks (same slot the exact kernels use)
+    unsigned long long* sync;   // [n_tiles][8] granules, zeroed before the launch: chain c's B as (lo, hi) halves of the double
+    const double* pw;           // [2][64]: (1 - gamma)^(NF * lane), low / high smoother
+    double ap[2][6];            // (1 - gamma)^(NF * 2^s), s = 0..5: the wave scan's step factors
+    double aw[2];               // (1 - gamma)^(NF * 64): one wave
+    double at[2];               // (1 - gamma)^(NF * 256): one tile
+    uint32_t k, term_mode, pass, n_tiles;
+    uint32_t K;                 // look-back depth in tiles (1 .. kScanMaxK)
+    uint32_t flags;             // bit 0: (tests) every poll times out at once -> all predecessors recomputed
+    float lgamma, hgamma;
+    PanGain pg;
+};
+void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
+inline uint32_t band_scan_tile_frames(int nf) { return (uint32_t)nf * (uint32_t)kThreads; }
+
 // ---- build-defined sinc resampler (stands in for the un-vendored rubato crate; DESIGN.md "Resampler") ----
 // Shaped like the streaming SincFixedIn the reference drives block by block (state.rs:545-560): output j sits at input
 // position j * from / to - sinc_len / 2 (the resampler's documented output delay: the filter only ever looks at frames it

@@ -2076,6 +2076,268 @@ __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_band_scan: band_pass_gen as a blocked affine scan -- tolerance class, one launch per vertex (BandScanDesc, kernels.h)
+// ------------------------------------------------------------------------------------------------
+// Inter-workgroup hand-off: 8-byte {tag = 1, value} granules, one agent-scope atomic store each, read back with
+// agent-scope atomic loads (global_store / global_load ... sc1: L1 bypassed, the data word carries its own validity, so
+// no fence on either side); the granule words are zeroed by the engine before every launch.
+typedef unsigned long long TD_GLOBAL* gu64;
+TD_DEV void granule_store(unsigned long long* p, uint32_t value) {
+    __hip_atomic_store((gu64)(TD_GLOBAL char*)p, (1ull << 32) | (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+TD_DEV unsigned long long granule_load(const unsigned long long* p) {
+    return __hip_atomic_load((gu64)(TD_GLOBAL char*)const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+TD_DEV double dsel4(const double v[4], uint32_t c) { return c == 0u ? v[0] : c == 1u ? v[1] : c == 2u ? v[2] : v[3]; }
+constexpr uint32_t kScanSpinLimit = 4096;   // polls (~1 us each) before a predecessor is recomputed instead of awaited
+
+template <int TMODE, int NF>
+__global__ __launch_bounds__(kThreads) void k_band_scan(const BandScanDesc* __restrict__ descs, uint32_t M) {
+    constexpr int NP = NF / 2;                          // frame pairs (16-byte words) per lane
+    constexpr uint32_t TILE = (uint32_t)NF * kThreads;  // frames per workgroup
+    const BandScanDesc& d = descs[blockIdx.y];
+    const uint32_t tile = blockIdx.x;
+    if (tile >= d.n_tiles) return;
+    // tile staging, lane-major with one pad word per lane run: the coalesced side (word q * 256 + tid) and the lane side
+    // (words tid * NP .. + NP - 1) are both conflict-free
+    __shared__ float4 xt[kThreads * (NP + 1)];
+    __shared__ double wtot[kThreads / 64][4];
+    __shared__ double carry_s[4];
+    __shared__ float yinit_s[4];
+    __shared__ uint32_t first_s;
+    __shared__ uint32_t pb[kScanMaxK * 8];          // the predecessors' granule values, oldest first
+    __shared__ uint32_t have_s[kScanMaxK / 32];     // bit p: predecessor p's eight granules are in pb
+    __shared__ uint32_t all_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const float lgam = d.lgamma, hgam = d.hgamma;
+    const double al = 1.0 - (double)lgam, ah = 1.0 - (double)hgam, gl = (double)lgam, gh = (double)hgam;
+    const double awl = d.aw[0], awh = d.aw[1];
+    const TermTab ins = term_tab(d.ins);
+    const uint32_t k = d.k;
+    auto slot = [](uint32_t p) { return p + p / (uint32_t)NP; };
+
+    float4 x[NP];             // the lane's NF consecutive input frames
+    double excl[4], xw[4], B[4];
+    // Input terms -> lane-consecutive frames -> zero-state responses: of the lane's run (b), of the wave up to the lane
+    // (excl), of the tile up to the wave (xw), of the whole tile (B).  Used for the workgroup's own tile and, should a
+    // predecessor fail to publish in time, for that predecessor's tile: identical arithmetic, identical values.
+    auto compute = [&](uint32_t tt) {
+        const uint32_t tile0 = tt * TILE;
+#pragma unroll
+        for (int r = 0; r < NP / 2; ++r) {
+            const uint32_t m0 = tile0 + (uint32_t)(2 * r) * 512u + 2u * tid, m1 = m0 + 512u;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            sum_terms<TMODE>(ins, k, m0, m1, M, a0, a1);   // sum_inputs (extensions.rs:310-319): zero, += in edge order
+            xt[slot((uint32_t)(2 * r) * 256u + tid)] = a0;
+            xt[slot((uint32_t)(2 * r + 1) * 256u + tid)] = a1;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NP; ++j) x[j] = xt[tid * (uint32_t)(NP + 1) + (uint32_t)j];
+        double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const float4 v = x[j];
+            b0 = __builtin_fma(b0, al, gl * (double)v.x);
+            b1 = __builtin_fma(b1, al, gl * (double)v.y);
+            b2 = __builtin_fma(b2, ah, gh * (double)v.x);
+            b3 = __builtin_fma(b3, ah, gh * (double)v.y);
+            b0 = __builtin_fma(b0, al, gl * (double)v.z);
+            b1 = __builtin_fma(b1, al, gl * (double)v.w);
+            b2 = __builtin_fma(b2, ah, gh * (double)v.z);
+            b3 = __builtin_fma(b3, ah, gh * (double)v.w);
+        }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {   // inclusive scan over the wave: b_i += a^(NF * 2^s) b_(i - 2^s)
+            const uint32_t dd = 1u << s;
+            const double pl = d.ap[0][s], ph = d.ap[1][s];
+            const double t0 = __shfl_up(b0, dd, 64), t1 = __shfl_up(b1, dd, 64), t2 = __shfl_up(b2, dd, 64), t3 = __shfl_up(b3, dd, 64);
+            if (lane >= dd) {
+                b0 = __builtin_fma(t0, pl, b0);
+                b1 = __builtin_fma(t1, pl, b1);
+                b2 = __builtin_fma(t2, ph, b2);
+                b3 = __builtin_fma(t3, ph, b3);
+            }
+        }
+        excl[0] = __shfl_up(b0, 1u, 64); excl[1] = __shfl_up(b1, 1u, 64);
+        excl[2] = __shfl_up(b2, 1u, 64); excl[3] = __shfl_up(b3, 1u, 64);
+        if (lane == 0u) excl[0] = excl[1] = excl[2] = excl[3] = 0.0;
+        if (lane == 63u) { wtot[wave][0] = b0; wtot[wave][1] = b1; wtot[wave][2] = b2; wtot[wave][3] = b3; }
+        if (tt == 0u && tid == 0u) {
+            // state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670).  Only tile 0's own
+            // workgroup ever computes tile 0 (it is the one predecessor that is never recomputed).
+            const uint32_t first = d.state->first;
+            const float* sf = reinterpret_cast<const float*>(d.state);
+            first_s = first;
+            yinit_s[0] = first ? x[0].x : sf[0];
+            yinit_s[1] = first ? x[0].y : sf[1];
+            yinit_s[2] = first ? x[0].x : sf[2];
+            yinit_s[3] = first ? x[0].y : sf[3];
+        }
+        __syncthreads();
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (uint32_t w = 0; w < (uint32_t)(kThreads / 64); ++w) {
+            if (w == wave) { xw[0] = acc[0]; xw[1] = acc[1]; xw[2] = acc[2]; xw[3] = acc[3]; }
+            acc[0] = __builtin_fma(acc[0], awl, wtot[w][0]);
+            acc[1] = __builtin_fma(acc[1], awl, wtot[w][1]);
+            acc[2] = __builtin_fma(acc[2], awh, wtot[w][2]);
+            acc[3] = __builtin_fma(acc[3], awh, wtot[w][3]);
+        }
+        B[0] = acc[0]; B[1] = acc[1]; B[2] = acc[2]; B[3] = acc[3];
+    };
+    auto half_of = [&](uint32_t q) -> uint32_t {   // granule q of a tile: chain q / 2, low / high word of its double
+        const unsigned long long u = (unsigned long long)__double_as_longlong(dsel4(B, q >> 1));
+        return (q & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u;
+    };
+
+    const uint32_t n_pred = min(tile, d.K), first_pred = tile - n_pred;
+    // Work list: the own tile; then -- only if a predecessor did not publish in time -- the missing predecessors and the
+    // own tile once more (its frames were dropped to make room).  One inlined copy of compute().
+    uint32_t cur = tile, p_cur = 0u, p_next = 0u;
+    int phase = 0;
+    for (;;) {
+        compute(cur);
+        if (phase == 2) break;
+        if (phase == 0) {
+            if (tid < 8u) {   // publish: the state this tile leaves behind when entered with zero state (tile 0: with the true state)
+                const uint32_t c = tid >> 1;
+                if (tile == 0u) {
+                    const double v = __builtin_fma((double)yinit_s[c], d.at[c >> 1], dsel4(B, c));
+                    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+                    granule_store(d.sync + tid, (tid & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
+                } else {
+                    granule_store(d.sync + (size_t)tile * 8u + tid, half_of(tid));
+                }
+            }
+            if (tile == 0u && tid == 0u && first_s) {   // a constant chain (gamma 0) keeps its seed for good
+                float* sf = reinterpret_cast<float*>(d.state);
+                if (lgam == 0.0f) { sf[0] = yinit_s[0]; sf[1] = yinit_s[1]; }
+                if (hgam == 0.0f) { sf[2] = yinit_s[2]; sf[3] = yinit_s[3]; }
+            }
+            if (n_pred == 0u) break;
+            if (wave == 0u) {
+                const unsigned long long* g0 = d.sync + (size_t)first_pred * 8u;
+                const uint32_t n8 = n_pred * 8u;
+                if (lane < kScanMaxK / 32u) have_s[lane] = 0u;
+                bool done = false;
+                if (!(d.flags & 1u)) {
+                    for (uint32_t spin = 0;; ++spin) {
+                        bool ok = true;
+                        for (uint32_t idx = lane; idx < n8; idx += 64u) {
+                            const unsigned long long g = granule_load(g0 + idx);
+                            const bool t = (uint32_t)(g >> 32) == 1u;
+                            if (t) pb[idx] = (uint32_t)g;
+                            ok = ok && t;
+                        }
+                        if (__all(ok ? 1 : 0)) { done = true; break; }
+                        if (spin >= kScanSpinLimit) break;
+                        __builtin_amdgcn_s_sleep(4);
+                    }
+                }
+                if (!done) {
+                    // which predecessors are complete (lanes 8 j .. 8 j + 7 read tile j of a group of eight)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    if (!(d.flags & 1u))
+                        for (uint32_t base = 0; base < n8; base += 64u) {
+                            const uint32_t idx = base + lane;
+                            bool t = false;
+                            if (idx < n8) {
+                                const unsigned long long g = granule_load(g0 + idx);
+                                t = (uint32_t)(g >> 32) == 1u;
+                                if (t) pb[idx] = (uint32_t)g;
+                            }
+                            const unsigned long long bal = __ballot(t ? 1 : 0);
+                            const uint32_t p = base / 8u + lane;
+                            if (lane < 8u && p < n_pred && ((bal >> (8u * lane)) & 0xFFull) == 0xFFull)
+                                atomicOr(&have_s[p >> 5], 1u << (p & 31u));
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    // tile 0 depends on nobody and is the one tile nobody else can compute (it folds the carried state,
+                    // which the last tile overwrites once tile 0 has published): waited for without bound
+                    if (first_pred == 0u && !(have_s[0] & 1u)) {
+                        for (;;) {
+                            bool t = true;
+                            if (lane < 8u) {
+                                const unsigned long long g = granule_load(g0 + lane);
+                                t = (uint32_t)(g >> 32) == 1u;
+                                if (t) pb[lane] = (uint32_t)g;
+                            }
+                            if (__all(t ? 1 : 0)) break;
+                            __builtin_amdgcn_s_sleep(8);
+                        }
+                        if (lane == 0u) atomicOr(&have_s[0], 1u);
+                    }
+                }
+                if (lane == 0u) all_s = done ? 1u : 0u;
+            }
+            __syncthreads();
+            if (all_s) break;
+            phase = 1;
+        } else {   // phase 1: a predecessor's response, computed here
+            if (tid < 8u) pb[p_cur * 8u + tid] = half_of(tid);
+        }
+        // next missing predecessor (uniform), or back to the own tile
+        while (p_next < n_pred && ((have_s[p_next >> 5] >> (p_next & 31u)) & 1u)) ++p_next;
+        if (p_next < n_pred) { p_cur = p_next++; cur = first_pred + p_cur; }
+        else { phase = 2; cur = tile; }
+    }
+    __syncthreads();   // pb complete
+    if (tid < 4u) {
+        // state entering the tile: C = sum_j a_tile^(j-1) B_(tile-j), oldest first (tile 0: the carried / seeded state)
+        const double a = d.at[tid >> 1];
+        double C = 0.0;
+        if (tile == 0u) C = (double)yinit_s[tid];
+        else
+            for (uint32_t p = 0; p < n_pred; ++p) {
+                const unsigned long long u = (unsigned long long)pb[p * 8u + 2u * tid] | ((unsigned long long)pb[p * 8u + 2u * tid + 1u] << 32);
+                C = __builtin_fma(C, a, __longlong_as_double((long long)u));
+            }
+        carry_s[tid] = C;
+    }
+    __syncthreads();
+    // entry state of the lane's run, exact arithmetic rounded once: excl + a^(NF lane) (xw + a_wave^wave C)
+    double awpl = 1.0, awph = 1.0;
+    for (uint32_t w = 0; w < wave; ++w) { awpl *= awl; awph *= awh; }
+    const double pl = d.pw[lane], ph = d.pw[64u + lane];
+    float y0 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[0], xw[0]), excl[0]);
+    float y1 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[1], xw[1]), excl[1]);
+    float y2 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[2], xw[2]), excl[2]);
+    float y3 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[3], xw[3]), excl[3]);
+    // the lane's frames in the reference's own arithmetic (extensions.rs:671-688), outputs back through the staging
+    const BandCoef kf = band_coef(lgam, hgam, d.pass);
+    const PanGain pg = d.pg;
+    const uint32_t tile0 = tile * TILE, mlast = M - 1u, mf = tile0 + (uint32_t)NF * tid;
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+    bool has_fin = false;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const float4 v = x[j];
+        y0 = y0 + lgam * (v.x - y0); y1 = y1 + lgam * (v.y - y1);
+        y2 = y2 + hgam * (v.x - y2); y3 = y3 + hgam * (v.y - y3);
+        const float2 oa = epilogue(band_out(kf, v.x, v.y, y0, y1, y2, y3), pg);
+        if (mf + 2u * (uint32_t)j == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
+        y0 = y0 + lgam * (v.z - y0); y1 = y1 + lgam * (v.w - y1);
+        y2 = y2 + hgam * (v.z - y2); y3 = y3 + hgam * (v.w - y3);
+        const float2 ob = epilogue(band_out(kf, v.z, v.w, y0, y1, y2, y3), pg);
+        if (mf + 2u * (uint32_t)j + 1u == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
+        xt[tid * (uint32_t)(NP + 1) + (uint32_t)j] = make_float4(oa.x, oa.y, ob.x, ob.y);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NP; ++q) store_pair(d.out, tile0 + 2u * ((uint32_t)q * 256u + tid), M, xt[slot((uint32_t)q * 256u + tid)]);
+    if (has_fin) {   // the lane that holds the chunk's last frame carries the state over (constant chains: see above)
+        if (first_pred != 0u) {   // tile 0 was not among the polled predecessors: it must have read the old state first
+            while ((uint32_t)(granule_load(d.sync) >> 32) != 1u) __builtin_amdgcn_s_sleep(8);
+        }
+        float* sf = reinterpret_cast<float*>(d.state);
+        if (lgam != 0.0f) { sf[0] = f0; sf[1] = f1; }
+        if (hgam != 0.0f) { sf[2] = f2; sf[3] = f3; }
+        d.state->first = 0u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_resample: build-defined windowed-sinc resampler (specification in DESIGN.md "Resampler"; the oracle
 // implements the same arithmetic: taps in order k = 0..255, coefficient T0*(1-a) + T1*a, f32 accumulate)
 // ------------------------------------------------------------------------------------------------
@@ -2296,6 +2558,24 @@ void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max
 void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
     TD_BATCHED(k_band_fill, std::min(tiles(frames), 1024u), kThreads, d, n, frames);
+}
+template <int MODE>
+static void launch_band_scan_mode(const BandScanDesc* d, int n, uint32_t frames, uint32_t gx, int nf, hipStream_t s) {
+    static const auto k16 = &k_band_scan<MODE, 16>;   // (names without a comma for the launch macro)
+    static const auto k8 = &k_band_scan<MODE, 8>;
+    if (nf == 16) TD_BATCHED(k16, gx, kThreads, d, n, frames);
+    else TD_BATCHED(k8, gx, kThreads, d, n, frames);
+}
+void launch_band_scan(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s) {
+    if (!n || !frames) return;
+    const uint32_t tile = band_scan_tile_frames(nf), gx = (frames + tile - 1u) / tile;
+    switch (term_mode) {
+        case TERMS_EDGE_FEW: launch_band_scan_mode<TERMS_EDGE_FEW>(d, n, frames, gx, nf, s); break;
+        case TERMS_ALL_EDGE: launch_band_scan_mode<TERMS_ALL_EDGE>(d, n, frames, gx, nf, s); break;
+        case TERMS_ADSR1: launch_band_scan_mode<TERMS_ADSR1>(d, n, frames, gx, nf, s); break;
+        case TERMS_WITH_ADSR: launch_band_scan_mode<TERMS_WITH_ADSR>(d, n, frames, gx, nf, s); break;
+        default: launch_band_scan_mode<TERMS_MIXED>(d, n, frames, gx, nf, s); break;
+    }
 }
 #undef TD_BATCHED
 static inline uint32_t grid_for(uint32_t n) { return max(1u, min((n + kThreads - 1) / kThreads, 2048u)); }

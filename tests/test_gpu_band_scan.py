@@ -1,0 +1,147 @@
+"""GPU parity of the TOLERANCE-class band-pass (`band_mode` 1, k_band_scan): band_pass_gen
+(/root/reference/src/extensions.rs:654-689) evaluated as a blocked affine scan, one launch per vertex.
+
+Bar (BASELINE.json north_star, filter paths): <= 1e-6 RMS on the f32 output and +-1 LSB on the PCM against the
+oracle's serial f32 recurrence.  The exact kernels (`band_mode` 0, the default) stay the bit-exact parity mode and are
+tested in test_gpu_parity.py / test_gpu_full_size.py; this file runs the same projects through the scan.
+"""
+import numpy as np
+import pytest
+
+from termdaw_amd import workloads as W
+from test_gpu_parity import _bits, _gappy_project, _soak_case, _stutter_project, assert_bit_exact, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan_build(p, api, **opts):
+    built = p.build(api)
+    built[2].set_option("band_mode", 1)
+    for k, v in opts.items():
+        built[2].set_option(k, v)
+    return built
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+@pytest.mark.parametrize("nf", [16, 8])
+def test_config3_short_scan(gpu_api, oracle, nf):
+    p = W.config3(seconds=4.0)
+    got = p.render(gpu_api, built=_scan_build(p, gpu_api, band_scan_nf=nf))
+    assert_close(got, p.render(oracle))
+
+
+@pytest.mark.parametrize("lo,hi,pass_", [(200.0, 4000.0, True), (20.0, 18000.0, False), (0.0, 50.0, True),
+                                         (1000.0, 0.0, True), (5.0, 9000.0, True), (1.0, 300.0, True)])
+@pytest.mark.parametrize("scan", [False, True])
+def test_gappy_inputs_scan(gpu_api, oracle, lo, hi, pass_, scan):
+    """Silent and held-constant stretches (where the exact kernels park), cut-offs from 0 (constant chain) and 1 Hz
+    (beyond the scan's look-back depth: the vertex then takes the exact kernels) to 18 kHz; two band-pass vertices in a
+    row, fresh and after a normalize scan (which carries the filter state into the render, quirk Q4)."""
+    p = _gappy_project(lo, hi, pass_)
+    built = _scan_build(p, gpu_api)
+    assert_close(p.render(gpu_api, built=built, scan=scan), p.render(oracle, scan=scan))
+
+
+def test_scan_matches_exact_mode_closely(gpu_api):
+    """The two modes of one engine on one project: the scan differs from the exact kernels by the f32 trajectory's own
+    rounding only (a few 1e-8 relative)."""
+    p = _gappy_project(200.0, 4000.0, True, seconds=3.0)
+    exact = p.render(gpu_api)
+    scan = p.render(gpu_api, built=_scan_build(p, gpu_api))
+    assert _rms(exact[1], scan[1]) <= 3e-7
+    assert np.abs(exact[0].astype(np.int64) - scan[0].astype(np.int64)).max() <= 1
+
+
+@pytest.mark.parametrize("nf", [16, 8])
+def test_recomputed_predecessors_give_the_same_bits(gpu_api, nf):
+    """`band_scan_debug`: every poll of a predecessor's granules times out at once, so every tile recomputes the
+    responses of its look-back window itself (the bounded-wait fallback).  Same arithmetic -> the same bits as the
+    published values give."""
+    p = _gappy_project(20.0, 9000.0, True, seconds=3.0)
+    normal = p.render(gpu_api, built=_scan_build(p, gpu_api, band_scan_nf=nf))
+    forced = p.render(gpu_api, built=_scan_build(p, gpu_api, band_scan_nf=nf, band_scan_debug=1))
+    assert np.array_equal(_bits(normal[1]), _bits(forced[1]))
+    assert np.array_equal(normal[0], forced[0])
+
+
+@pytest.mark.parametrize("chunk", [1024, 5000, 30000])
+def test_chunked_scan_carries_the_filter_state(gpu_api, oracle, chunk):
+    """Chunks of one block (a block pull's size), of a few blocks and of a few tiles: the state crosses chunk borders in
+    the same f32 slot the exact kernels use."""
+    p = _gappy_project(300.0, 3000.0, True, seconds=3.0)
+    built = _scan_build(p, gpu_api, max_chunk_frames=chunk)
+    assert_close(p.render(gpu_api, built=built, scan=True), p.render(oracle, scan=True))
+
+
+def test_render_twice_and_mode_switch(gpu_api, oracle):
+    """Second render of the same handles (carried state), then the same handles switched back to the exact kernels:
+    the state slot is shared, so the exact render continues from the scan's state -- still within tolerance."""
+    p = _stutter_project(6.0, 0.05, 1500.0, 12000.0, seed=3)
+    gb, ob = _scan_build(p, gpu_api), p.build(oracle)
+    for _ in range(2):
+        assert_close(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
+    gb[2].set_option("band_mode", 0)
+    assert_close(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
+
+
+def test_block_pulls_in_scan_mode(gpu_api, oracle):
+    """td_graph_render_block (Graph::render, graph.rs:182-193) with a band-pass in scan mode: one-tile launches."""
+    p = _gappy_project(250.0, 5000.0, True, seconds=0.4)
+    gsb, gfb, gg = _scan_build(p, gpu_api)
+    osb, ofb, og = p.build(oracle)
+    for b in range(p.cs):
+        gl, gr = gg.render(gsb, gfb)
+        ol, orr = og.render(osb, ofb)
+        scale = max(1e-30, float(np.abs(ol).max()), float(np.abs(orr).max()))
+        assert _rms(gl, ol) <= 1e-6 * scale and _rms(gr, orr) <= 1e-6 * scale, "block %d" % b
+        gfb.set_time_to_next_block()
+        ofb.set_time_to_next_block()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soak_scan(gpu_api, oracle, seed):
+    p, chunk = _soak_case(seed)
+    gb, ob = _scan_build(p, gpu_api), p.build(oracle)
+    if chunk:
+        gb[2].set_option("max_chunk_frames", chunk)
+    for scan in (False, True):
+        assert_close(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
+
+
+def test_config4_deep_chain_short_scan(gpu_api, oracle):
+    """The 256-vertex chain: 84 scan launches, each evaluating `sum stage -> adsr` of its input as terms."""
+    p = W.config4(seconds=3.0)
+    built = _scan_build(p, gpu_api)
+    assert_close(p.render(gpu_api, built=built), p.render(oracle))
+
+
+@pytest.mark.parametrize("depth", [12, 84, 252])
+def test_rms_per_chain_depth(gpu_api, oracle, depth):
+    """Error growth along the chain (reported by tools/band_scan_rms.py for DESIGN.md): within budget at every depth of
+    config 4."""
+    p = W.config4(seconds=4.0, depth=depth)
+    got, ref = p.render(gpu_api, built=_scan_build(p, gpu_api)), p.render(oracle)
+    assert_close(got, ref)
+
+
+def test_config3_full_60s_scan(gpu_api, oracle):
+    p = W.config3()
+    assert p.cs == 2813
+    assert_close(p.render(gpu_api, built=_scan_build(p, gpu_api)), p.render(oracle))
+
+
+def test_config4_full_60s_scan(gpu_api, oracle):
+    p = W.config4()
+    assert p.cs == 2813
+    assert_close(p.render(gpu_api, built=_scan_build(p, gpu_api)), p.render(oracle))
+
+
+def test_scan_mode_leaves_bit_exact_kinds_alone(gpu_api, oracle):
+    """`band_mode` only changes band-pass vertices: a project without one is bit-exact in either mode."""
+    p = W.drum_project(seconds=1.0)
+    has_band = len(p.calls.get("add_bandpass", [])) > 0
+    got = p.render(gpu_api, built=_scan_build(p, gpu_api))
+    (assert_close if has_band else assert_bit_exact)(got, p.render(oracle))

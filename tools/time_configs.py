@@ -6,6 +6,9 @@ from termdaw_amd import api, workloads as W
 
 def run(name, p, reps=None):
     sb, fb, g = p.build(api)
+    for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=band_mode=1,band_scan_nf=8
+        k, v = kv.split("=")
+        g.set_option(k, int(v))
     def render():
         g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
         g.render_all_async(sb, fb, p.cs, 16)
