@@ -975,9 +975,9 @@ static void free_arena(Arena& ar) {
     ar = Arena{};
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT, F_COUNT };
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_ENV, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
-                                           "k_synth",       "k_sampsyn", "k_sum",          "k_scale",       "k_norm_fix",
+                                           "k_synth",       "k_sampsyn", "k_adsr_env", "k_sum",          "k_scale",       "k_norm_fix",
                                            "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise"};
 
 static hipEvent_t get_event(ProfCtx& pc) {
@@ -1280,9 +1280,136 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     std::vector<std::vector<size_t>> by_level(g->n_levels);
     for (size_t vi : g->order) by_level[g->level[vi]].push_back(vi);
     std::map<std::string, size_t> scan_pw_off;   // k_band_scan power tables of this chunk, by (gammas, nf)
+    // gain buffers of the Adsr vertices that are read through by their consumers (InTerm kind 5): one per distinct
+    // (event tables, conf, wet, flags) of the chunk -- the 84 envelope stages of a deep chain share one -- filled by
+    // k_adsr_env at the vertex' own level, held until the chunk has been compiled
+    std::map<std::string, float*> env_of_key;
+    std::vector<float*> env_of(nv, nullptr);
+    std::vector<float2*> env_bufs;
     auto add_launch = [&](int fam, size_t off, int n, uint32_t aux, int level) {
         cb.launches.push_back({fam, off, n, aux, level, (uint32_t)M, (uint32_t)bl, is_scan ? 1 : 0});
     };
+    // the buffer vertex u's output is read from: behind a gain / pan stage, an inlined Adsr vertex or both; npos: a loop source
+    auto buffer_behind = [&](size_t u) -> size_t {
+        if (inlined[u] == 4) u = g->edges[u][0];
+        if (inlined[u] == 3) u = g->edges[u][0];
+        if (inlined[u] == 2) u = g->edges[u][0];
+        return inlined[u] ? (size_t)-1 : u;
+    };
+    // ---- chains of band-pass vertices in scan mode (kernels.h BandScanDesc): vertex b follows vertex a when b's only input
+    // is a, directly or through up to three single-input, single-consumer links (gain / pan stage, Adsr vertex read
+    // through, stage) -- the shape of a chain of effect stages.  All vertices of a chain but the last are never
+    // materialised (inlined 5); the launch sits at the last vertex' level and evaluates the FIRST vertex' input terms.
+    struct ChainLink { size_t vertex; bool adsr; };
+    std::map<size_t, ScanPlan> scan_plan;                        // band-pass vertices that take k_band_scan
+    std::map<size_t, std::vector<size_t>> chain_of;              // last vertex of a launch -> its vertices, first to last
+    std::map<size_t, std::vector<ChainLink>> links_before;       // band-pass vertex -> the links between its predecessor and it
+    if (g->band_mode == 1) {
+        for (size_t vi : g->order) {
+            const Vertex& v = g->vertices[vi];
+            if (v.kind != K_BAND_PASS || v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) continue;
+            ScanPlan sp;
+            if (plan_band_scan(g, v, M, &sp)) scan_plan[vi] = sp;
+        }
+        std::map<size_t, size_t> prev_of, next_of;
+        if (g->fuse_sources && g->band_chain)
+            for (auto& kv : scan_plan) {
+                const size_t b = kv.first;
+                if (g->edges[b].size() != 1) continue;
+                std::vector<ChainLink> links;
+                size_t u = g->edges[b][0];
+                bool ok = true;
+                while (ok && links.size() < 3 && (inlined[u] == 2 || inlined[u] == 3 || inlined[u] == 4)) {
+                    ok = cons[u].size() == 1;
+                    links.insert(links.begin(), ChainLink{u, inlined[u] == 3});
+                    u = g->edges[u][0];
+                }
+                if (!ok || inlined[u] || !scan_plan.count(u) || cons[u].size() != 1 || (long)u == g->output_vertex) continue;
+                prev_of[b] = u;
+                next_of[u] = b;
+                links_before[b] = links;
+            }
+        for (auto& kv : scan_plan) {
+            const size_t head = kv.first;
+            if (prev_of.count(head)) continue;   // not the first vertex of its chain
+            std::vector<size_t> piece{head};
+            size_t b = head;
+            for (;;) {
+                auto nx = next_of.find(b);
+                const bool more = nx != next_of.end();
+                if (!more || piece.size() == kScanMaxStages) {   // (longer chains are cut: the cut vertex is materialised)
+                    if (piece.size() > 1) {
+                        const size_t last = piece.back();
+                        for (size_t i = 0; i + 1 < piece.size(); ++i) inlined[piece[i]] = 5;
+                        for (size_t u : g->edges[piece[0]]) {   // the first vertex' inputs are read at the LAST vertex' level
+                            const size_t bu = buffer_behind(u);
+                            if (bu != (size_t)-1) last_use[bu] = std::max(last_use[bu], g->level[last]);
+                        }
+                        chain_of[last] = piece;
+                    }
+                    if (!more) break;
+                    piece.clear();
+                }
+                b = nx->second;
+                piece.push_back(b);
+            }
+        }
+    }
+    // ---- gain buffers of the Adsr vertices that are read through (k_adsr_env), before everything else: they depend on
+    // the event tables only, and a chain launch needs those of its links however deep they sit in the graph
+    {
+        std::vector<size_t> envs;
+        for (size_t vi : g->order) {
+            if (inlined[vi] != 3) continue;
+            const Vertex& v = g->vertices[vi];
+            std::string key;
+            put_pod(key, (uint64_t)(uintptr_t)vt[vi].dev);
+            put_pod(key, (uint64_t)vt[vi].istart_off); put_pod(key, (uint64_t)vt[vi].ivoff_off);
+            put_pod(key, (uint64_t)vt[vi].voices_off); put_pod(key, (uint64_t)vt[vi].tile_first_off);
+            put_pod(key, vt[vi].n_int);
+            put_pod(key, v.conf); put_pod(key, v.wet);
+            put_pod(key, (uint8_t)v.use_off); put_pod(key, (uint8_t)v.use_max);
+            auto it = env_of_key.find(key);
+            if (it == env_of_key.end()) {
+                float2* b = take_buffer(g);
+                if (!b) return fail("termdaw_amd: out of device memory for edge buffers");
+                env_bufs.push_back(b);
+                it = env_of_key.emplace(key, reinterpret_cast<float*>(b)).first;
+                envs.push_back(vi);
+            }
+            env_of[vi] = it->second;
+        }
+        if (!envs.empty()) {   // the vertex' tables and envelope, as k_adsr would get them; output: its gain buffer
+            std::vector<AdsrVDesc> d;
+            for (size_t vi : envs) {
+                const Vertex& v = g->vertices[vi];
+                AdsrVDesc x{};
+                x.tab.n_int = vt[vi].n_int;
+                x.sr = (uint32_t)sr;
+                x.bl = (uint32_t)bl;
+                x.use_off = v.use_off;
+                x.use_max = v.use_max;
+                x.wet = v.wet;
+                x.conf = v.conf;
+                adsr_fill_run_consts(&x);
+                x.env = env_of[vi];
+                d.push_back(x);
+            }
+            const size_t off = st.put(d);
+            for (size_t i = 0; i < envs.size(); ++i) {
+                const size_t t = off + i * sizeof(AdsrVDesc) + offsetof(AdsrVDesc, tab);
+                const auto tf = [&](size_t field_off, size_t o2) {
+                    const uint64_t p = (uint64_t)(uintptr_t)(vt[envs[i]].dev + o2);
+                    memcpy(&st.b[t + field_off], &p, 8);
+                };
+                tf(offsetof(IntervalTab, istart), vt[envs[i]].istart_off);
+                tf(offsetof(IntervalTab, tile_first), vt[envs[i]].tile_first_off);
+                tf(offsetof(IntervalTab, ivoff), vt[envs[i]].ivoff_off);
+                tf(offsetof(IntervalTab, voices), vt[envs[i]].voices_off);
+            }
+            add_launch(F_ENV, off, (int)envs.size(), 0u, -1);
+        }
+    }
 
     // scratch (device-only) region is laid out after the uploaded region
     auto scratch = [&](size_t n) { size_t o = cb.scratch_bytes; cb.scratch_bytes += (n + 255) & ~(size_t)255; return o; };
@@ -1302,7 +1429,6 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::vector<size_t> fam_v[F_COUNT];
         std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
         std::map<size_t, BandPlan> band_plan;
-        std::map<size_t, ScanPlan> scan_plan;
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
             if (inlined[vi]) continue;
@@ -1325,8 +1451,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 case K_BAND_PASS:
                     if (v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) {
                         fam_v[F_SUM].push_back(vi);   // extensions.rs:657-658: the summed input passes through
-                    } else if (ScanPlan sp; g->band_mode == 1 && plan_band_scan(g, v, M, &sp)) {
-                        scan_plan[vi] = sp;
+                    } else if (scan_plan.count(vi)) {
                         fam_v[F_BAND_SCAN].push_back(vi);
                     } else {
                         BandPlan bp = plan_band(g, v, M);
@@ -1349,8 +1474,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         // input term tables: an edge buffer, or an inlined sample_loop source gathered by the consumer
         std::map<size_t, size_t> ins_off;
         std::map<size_t, uint32_t> term_mode;
-        for (size_t vi : by_level[lv]) {
-            if (!g->vertices[vi].has_input() || inlined[vi]) continue;   // (an inlined vertex' terms belong to its consumers)
+        for (size_t vl : by_level[lv]) {
+            if (!g->vertices[vl].has_input() || inlined[vl]) continue;   // (an inlined vertex' terms belong to its consumers)
+            // (the launch of a band-pass chain sits at its last vertex and evaluates the first vertex' input terms)
+            const size_t vi = chain_of.count(vl) ? chain_of[vl][0] : vl;
             std::vector<InTerm> ins;
             std::vector<std::pair<size_t, size_t>> adsr_through;   // (term index, the Adsr vertex a kind-5 term reads through)
             // a term of kind 0 .. 4: vertex u as an edge buffer, through a gain / pan stage, or as an inlined loop source
@@ -1421,6 +1548,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 x.wet = av.wet;
                 x.conf = av.conf;
                 x.pg = make_pg(av.gain, av.angle);
+                adsr_fill_run_consts(&x);
+                x.env = env_of[a];
                 const size_t in_off = st.put(std::vector<InTerm>{plain_term(g->edges[a][0])});
                 const size_t o = st.alloc(sizeof x);
                 memcpy(&st.b[o], &x, sizeof x);
@@ -1677,6 +1806,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.wet = v.wet;
                         x.conf = v.conf;
                         x.pg = make_pg(v.gain, v.angle);
+                        adsr_fill_run_consts(&x);
                         d.push_back(x);
                     }
                     off = st.put(d);
@@ -1766,58 +1896,88 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 case F_BAND_FIX:
                 case F_BAND_FILL: off = band_desc_off; break;   // reuse the k_band_spec descriptors
                 case F_BAND_SCAN: {
-                    for (size_t vi : vs)
-                        if (term_mode[vi] == TERMS_ALL_LOOP16 || term_mode[vi] == TERMS_ALL_LOOP32) term_mode[vi] = TERMS_MIXED;
-                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[a] < term_mode[b]; });
-                    std::vector<BandScanDesc> d;
+                    // vs: the vertices whose launch sits here -- single band-pass vertices and the LAST vertices of chains
+                    auto first_of = [&](size_t vi) { return chain_of.count(vi) ? chain_of[vi][0] : vi; };
                     for (size_t vi : vs) {
-                        const Vertex& v = g->vertices[vi];
-                        ScanPlan& sp = scan_plan[vi];
+                        uint32_t& tm = term_mode[first_of(vi)];
+                        if (tm == TERMS_ALL_LOOP16 || tm == TERMS_ALL_LOOP32) tm = TERMS_MIXED;
+                    }
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[first_of(a)] < term_mode[first_of(b)]; });
+                    std::vector<BandScanDesc> d;
+                    std::vector<size_t> stages_off;
+                    for (size_t vi : vs) {
+                        const std::vector<size_t> piece = chain_of.count(vi) ? chain_of[vi] : std::vector<size_t>{vi};
+                        const ScanPlan& sp0 = scan_plan[piece[0]];
+                        std::vector<BandStageDesc> sd;
+                        for (size_t i = 0; i < piece.size(); ++i) {
+                            const Vertex& v = g->vertices[piece[i]];
+                            ScanPlan& sp = scan_plan[piece[i]];
+                            BandStageDesc x{};
+                            x.state = &g->dstate[v.state_slot].band;
+                            x.lgamma = v.lgamma;
+                            x.hgamma = v.hgamma;
+                            x.pass = v.pass;
+                            x.K = sp.K;
+                            x.pg = make_pg(v.gain, v.angle);
+                            const double nf = (double)sp.nf;
+                            const double q[2] = {1.0 - (double)v.lgamma, 1.0 - (double)v.hgamma};
+                            for (int c = 0; c < 2; ++c) {
+                                for (int s2 = 0; s2 < 6; ++s2) x.ap[c][s2] = pow(q[c], nf * (double)(1 << s2));
+                                x.aw[c] = pow(q[c], nf * 64.0);
+                                x.at[c] = pow(q[c], nf * 256.0);
+                            }
+                            std::string key;
+                            put_pod(key, v.lgamma); put_pod(key, v.hgamma); put_pod(key, sp.nf);
+                            auto it = scan_pw_off.find(key);
+                            if (it == scan_pw_off.end()) {
+                                std::vector<double> pw(128);
+                                for (int c = 0; c < 2; ++c)
+                                    for (int l = 0; l < 64; ++l) pw[c * 64 + l] = pow(q[c], nf * (double)l);
+                                it = scan_pw_off.emplace(key, st.put(pw)).first;
+                            }
+                            sp.pw_off = it->second;
+                            if (i + 1 < piece.size()) {   // the links to the next vertex of the chain
+                                const std::vector<ChainLink>& links = links_before[piece[i + 1]];
+                                x.n_post = (uint32_t)links.size();
+                                for (size_t l = 0; l < links.size(); ++l) {
+                                    const Vertex& lv2 = g->vertices[links[l].vertex];
+                                    x.post[l].env = links[l].adsr ? env_of[links[l].vertex] : nullptr;
+                                    x.post[l].pg = make_pg(lv2.gain, lv2.angle);
+                                }
+                            }
+                            sd.push_back(x);
+                        }
+                        const size_t so = st.put(sd);
+                        stages_off.push_back(so);
+                        for (size_t i = 0; i < piece.size(); ++i) {
+                            const size_t o = so + i * sizeof(BandStageDesc);
+                            ptr_field(o, offsetof(BandStageDesc, pw), scan_plan[piece[i]].pw_off);
+                            cb.sync_fix.push_back({o + offsetof(BandStageDesc, sync), cb.sync_bytes});
+                            cb.sync_bytes += (size_t)sp0.n_tiles * 64;
+                        }
                         BandScanDesc x{};
                         x.out = g->vbuf[vi];
-                        x.state = &g->dstate[v.state_slot].band;
-                        x.k = (uint32_t)g->edges[vi].size();
-                        x.term_mode = term_mode[vi];
-                        x.pass = v.pass;
-                        x.n_tiles = sp.n_tiles;
-                        x.K = sp.K;
-                        x.flags = g->band_scan_debug ? 1u : 0u;
-                        x.lgamma = v.lgamma;
-                        x.hgamma = v.hgamma;
-                        x.pg = make_pg(v.gain, v.angle);
-                        const double nf = (double)sp.nf;
-                        const double q[2] = {1.0 - (double)v.lgamma, 1.0 - (double)v.hgamma};
-                        for (int c = 0; c < 2; ++c) {
-                            for (int s2 = 0; s2 < 6; ++s2) x.ap[c][s2] = pow(q[c], nf * (double)(1 << s2));
-                            x.aw[c] = pow(q[c], nf * 64.0);
-                            x.at[c] = pow(q[c], nf * 256.0);
-                        }
-                        std::string key;
-                        put_pod(key, v.lgamma); put_pod(key, v.hgamma); put_pod(key, sp.nf);
-                        auto it = scan_pw_off.find(key);
-                        if (it == scan_pw_off.end()) {
-                            std::vector<double> pw(128);
-                            for (int c = 0; c < 2; ++c)
-                                for (int l = 0; l < 64; ++l) pw[c * 64 + l] = pow(q[c], nf * (double)l);
-                            it = scan_pw_off.emplace(key, st.put(pw)).first;
-                        }
-                        sp.pw_off = it->second;
+                        x.n_stages = (uint32_t)piece.size();
+                        x.k = (uint32_t)g->edges[piece[0]].size();
+                        x.term_mode = term_mode[piece[0]];
+                        x.n_tiles = sp0.n_tiles;
+                        x.flags = (uint32_t)g->band_scan_debug;
                         d.push_back(x);
                     }
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(BandScanDesc);
-                        ptr_field(o, offsetof(BandScanDesc, ins), ins_off[vs[i]]);
-                        ptr_field(o, offsetof(BandScanDesc, pw), scan_plan[vs[i]].pw_off);
-                        cb.sync_fix.push_back({o + offsetof(BandScanDesc, sync), cb.sync_bytes});
-                        cb.sync_bytes += (size_t)scan_plan[vs[i]].n_tiles * 64;
+                        ptr_field(o, offsetof(BandScanDesc, ins), ins_off[first_of(vs[i])]);
+                        ptr_field(o, offsetof(BandScanDesc, stages), stages_off[i]);
+                        cb.sync_fix.push_back({o + offsetof(BandScanDesc, ticket), cb.sync_bytes});   // {tile counter, "states read"}
+                        cb.sync_bytes += 64;
                     }
                     size_t b = 0;   // one launch per term mode (vs is sorted by it)
                     while (b < vs.size()) {
                         size_t e2 = b;
-                        while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) ++e2;
+                        while (e2 < vs.size() && term_mode[first_of(vs[e2])] == term_mode[first_of(vs[b])]) ++e2;
                         add_launch(fam, off + b * sizeof(BandScanDesc), (int)(e2 - b),
-                                   term_mode[vs[b]] | ((uint32_t)scan_plan[vs[b]].nf << 8), lv);
+                                   term_mode[first_of(vs[b])] | ((uint32_t)scan_plan[first_of(vs[b])].nf << 8), lv);
                         b = e2;
                     }
                     continue;
@@ -1852,6 +2012,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 last_use[vi] = -2;
             }
     }
+    for (float2* b : env_bufs) g->free_bufs.push_back(b);
     // un-fused quantise when the output vertex is not a Normalize
     const Vertex& outv = g->vertices[(size_t)g->output_vertex];
     if (pcm_dst && qmode && outv.kind != K_NORMALIZE) {
@@ -1873,6 +2034,7 @@ static size_t desc_size(int fam) {
         case F_SINE: return sizeof(SineDesc);
         case F_SYNTH: return sizeof(SynthDesc);
         case F_SAMPSYN: return sizeof(SampsynDesc);
+        case F_ENV: return sizeof(AdsrVDesc);
         case F_SUM: return sizeof(SumDesc);
         case F_SCALE: return sizeof(ScaleDesc);
         case F_NORMFIX: return sizeof(SumDesc);
@@ -2033,6 +2195,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_SINE: launch_debug_sine((const SineDesc*)d, L.n, L.M, L.bl, s); break;
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, L.M, s); break;
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
+                case F_ENV: launch_adsr_env((const AdsrVDesc*)d, L.n, L.M, s); break;
                 case F_SUM: launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, L.M, L.bl, L.is_scan, s); break;
                 case F_NORMFIX: launch_norm_fix((const SumDesc*)d, L.n, L.M, L.bl, s); break;
@@ -2883,7 +3046,8 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
         g->band_scan_nf = (int)value;
         return 1;
     }
-    if (k == "band_scan_debug") { g->band_scan_debug = value != 0; return 1; }
+    if (k == "band_scan_debug") { g->band_scan_debug = (int)value; return 1; }
+    if (k == "band_chain") { g->band_chain = value != 0; return 1; }   // scan mode: chains of band-pass vertices in one launch
     if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
     if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
     if (k == "band_quick") { g->band_quick = value > 0 ? (unsigned)value : 0u; return 1; }

@@ -317,8 +317,9 @@ struct td_graph {
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
     int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
                                                //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex)
+    bool band_chain = true;                    // scan mode: a chain of band-pass vertices (linked by stages / Adsr vertices) is ONE launch
     int band_scan_nf = 16;                     // frames per lane of k_band_scan (8 | 16): tile = 256 x that
-    bool band_scan_debug = false;              // (tests) every k_band_scan poll times out: predecessors are recomputed
+    int band_scan_debug = 0;                   // (tests) bit 0: every k_band_scan poll times out: predecessors are recomputed
     std::vector<size_t> band_stats_off;        // scratch offsets of the last chunk's k_band_fix counters
     const uint8_t* band_stats_base = nullptr;  // device scratch base those offsets refer to
     size_t max_chunk_frames = (size_t)1 << 24;   // edge-buffer chunk cap (16.7 M frames = 128 MiB per buffer)

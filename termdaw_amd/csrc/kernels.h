@@ -41,8 +41,11 @@ struct PanGain {
 //           stage is never materialised.
 //   kind 5: an edge buffer read through an Adsr vertex that has this one input and one consumer (adsr_gen,
 //           extensions.rs:593-651, evaluated per frame by the consumer), optionally followed by a kind-4 stage
-//           (magic != 0, `pg` is then the stage's): `len` = device address of the vertex' AdsrVDesc (tables, envelope, its
-//           own pan / gain).  The consumer's only term (TERMS_ADSR1) or one of several (TERMS_WITH_ADSR).
+//           (magic != 0, `pg` is then the stage's): `len` = device address of the vertex' AdsrVDesc (its input term, its
+//           own pan / gain, and `env`: the vertex' per-frame gain `lerp(1.0, adsr_vel, wet)` for this chunk, made once
+//           per distinct envelope by k_adsr_env -- the gain depends on the frame and the event tables only, so the 84
+//           envelope stages of a deep chain share one).  The consumer's only term (TERMS_ADSR1) or one of several
+//           (TERMS_WITH_ADSR).
 struct InTerm {
     const float2* p;   // edge buffer (kind 0) or sample frames (kind 1, 2)
     uint64_t len;      // sample length
@@ -239,7 +242,16 @@ struct AdsrVDesc {
     float wet;
     AdsrConfD conf;
     PanGain pg;
+    // for the run form of the envelope (adsr_run, kernels.hip): 1.0 / (double)x of attack_sec, decay_sec, sustain_sec,
+    // release_sec and of (float)sr -- (float)((double)n * rcp) is the IEEE f32 quotient n / x -- and whether every level an
+    // attack / decay / sustain piece can return stays above the `res <= -1.0` escape of adsr.rs:62-69,75-86
+    double rcp[5];
+    uint32_t tame, pad2;
+    // the vertex' gain per frame of the chunk (>= frames + 1 floats): written by k_adsr_env, read by consumers of a kind-5 term
+    float* env;
 };
+void adsr_fill_run_consts(AdsrVDesc* d);   // host: rcp[], tame from conf / sr
+void launch_adsr_env(const AdsrVDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 
 // band_pass_gen (extensions.rs:654-689), exact sequential form.
 struct BandState { float lprevl, lprevr, hprevl, hprevr; uint32_t first; uint32_t pad[3]; };
@@ -301,7 +313,8 @@ struct BandSpecDesc {
 
 // band_pass_gen, TOLERANCE class (engine option "band_mode" 1; <= 1e-6 RMS against the exact forms above): the four
 // one-pole recurrences  y <- y + gamma (x - y)  =  (1 - gamma) y + gamma x  as a blocked affine scan, ONE launch per
-// vertex that also evaluates the vertex' input terms (no materialised input sum).
+// vertex -- or per CHAIN of band-pass vertices -- that also evaluates the first vertex' input terms (no materialised
+// input sum).
 //   A workgroup owns a tile of NF * 256 consecutive frames, a lane NF consecutive frames.  Per lane the zero-state
 //   response b of its run (double), a wave / workgroup scan of the (a^NF, b) pairs gives the tile's response B, which
 //   is published as eight 8-byte {tag, value} granules (agent-scope atomic stores).  The state entering the tile is
@@ -309,24 +322,46 @@ struct BandSpecDesc {
 //   dropped is below the f32 denormal floor), read back with agent-scope atomic loads; then every lane starts from its
 //   exact-arithmetic entry state rounded to f32 and runs the REFERENCE's expression over its NF frames, so what
 //   differs from the exact kernels is only the entry state's last bits (the f32 trajectory's own accumulated rounding).
-//   Waiting is bounded: a predecessor (lower blockIdx.x) that has not published in time is recomputed by the waiting
-//   workgroup itself -- same arithmetic, same values -- so nothing depends on dispatch order; only tile 0, which
-//   depends on nobody, is waited for without bound.
+//   One vertex (n_stages 1): tiles are numbered by blockIdx.x and waiting is bounded -- a predecessor that has not
+//   published in time is recomputed by the waiting workgroup itself, same arithmetic, same values -- so nothing depends on
+//   dispatch order; only tile 0, which depends on nobody, is waited for without bound.
+//   A chain (n_stages > 1: band-pass vertices linked by single-input, single-consumer gain / pan stages and Adsr
+//   vertices -- the shape of BASELINE config 4's 252 effect stages): the tile's frames stay in registers from stage to
+//   stage, the links (`0.0 + x`, envelope gain, pan / gain: BandPost) are applied in between, and every stage has its own
+//   granules.  A workgroup cannot recompute a predecessor's stage s > 0, so tiles are numbered by a ticket drawn at start
+//   (a workgroup only ever waits for lower tickets, whose holders are running), and waits are unbounded.
 constexpr uint32_t kScanMaxK = 128;   // look-back depth limit (tiles); slower smoothers take the exact kernels
-struct BandScanDesc {
-    const InTerm* ins;          // the vertex' input terms, in connect() order
-    float2* out;
+constexpr uint32_t kScanMaxStages = 128;   // band-pass vertices per launch (the engine cuts longer chains)
+struct BandPost {               // one link between two band-pass vertices of a chain
+    const float* env;           // an Adsr vertex (its gain buffer, AdsrVDesc::env), or nullptr: a single-input Sum (gain / pan stage)
+    PanGain pg;                 // the link vertex' own pan / gain
+    uint32_t pad[2];
+};
+struct BandStageDesc {          // one band-pass vertex
     BandState* state;           // carried across chunks (same slot the exact kernels use)
     unsigned long long* sync;   // [n_tiles][8] granules, zeroed before the launch: chain c's B as (lo, hi) halves of the double
     const double* pw;           // [2][64]: (1 - gamma)^(NF * lane), low / high smoother
     double ap[2][6];            // (1 - gamma)^(NF * 2^s), s = 0..5: the wave scan's step factors
     double aw[2];               // (1 - gamma)^(NF * 64): one wave
     double at[2];               // (1 - gamma)^(NF * 256): one tile
-    uint32_t k, term_mode, pass, n_tiles;
-    uint32_t K;                 // look-back depth in tiles (1 .. kScanMaxK)
-    uint32_t flags;             // bit 0: (tests) every poll times out at once -> all predecessors recomputed
     float lgamma, hgamma;
-    PanGain pg;
+    uint32_t pass;
+    uint32_t K;                 // look-back depth in tiles (1 .. kScanMaxK)
+    PanGain pg;                 // the vertex' own epilogue
+    // what lies between this vertex' output and the next stage's input, in graph order (unused by the last stage);
+    // each link first does its own sum_inputs `0.0 + x`, and so does the next band-pass vertex
+    uint32_t n_post, pad;
+    BandPost post[3];
+};
+struct BandScanDesc {
+    const InTerm* ins;          // the (first) vertex' input terms, in connect() order
+    float2* out;                // the (last) vertex' output
+    const BandStageDesc* stages;
+    uint32_t* ticket;           // n_stages > 1: tile counter, zeroed before the launch
+    uint32_t n_stages;
+    uint32_t k, term_mode, n_tiles;
+    uint32_t flags;             // bit 0: (tests) every poll times out at once -> all predecessors recomputed (n_stages 1)
+    uint32_t pad[3];
 };
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
 inline uint32_t band_scan_tile_frames(int nf) { return (uint32_t)nf * (uint32_t)kThreads; }

@@ -179,17 +179,18 @@ TD_DEV float4 loop_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
 // itself a term of kind 0 .. 4: AdsrVDesc::ins), the envelope (adsr_frame), pan / gain; then the stage's `0.0 + x`, pan,
 // gain -- the same f32 operations in the same order as the materialised vertices, without their launches and buffers.
 // `len` holds the vertex' AdsrVDesc.
-TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x);
 TD_DEV float4 adsr_term_pair(TermTab t, uint32_t j, uint32_t m, uint32_t M) {
-    AdsrVDesc d;
-    __builtin_memcpy(&d, (const AdsrVDesc TD_CONST*)(const TD_CONST char*)(uintptr_t)t[j].len, sizeof d);   // (uniform: scalar loads)
+    const AdsrVDesc TD_CONST* d = (const AdsrVDesc TD_CONST*)(const TD_CONST char*)(uintptr_t)t[j].len;   // (uniform: scalar loads)
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 x = add4(z, term_pair(term_tab(d.ins), 0u, m, M));   // the vertex' own input: an edge buffer, a stage, a loop source
+    const float4 x = add4(z, term_pair(term_tab(d->ins), 0u, m, M));   // the vertex' own input: an edge buffer, a stage, a loop source
     float4 v = z;
     if (m < M) {
-        const float2 a = adsr_frame(d, m, make_float2(x.x, x.y));
-        const float2 b = (m + 1 < M) ? adsr_frame(d, m + 1, make_float2(x.z, x.w)) : make_float2(0.f, 0.f);
-        v = epilogue4(make_float4(a.x, a.y, b.x, b.y), d.pg);
+        // `buf[i] *= vel` (extensions.rs:646-647) with the vertex' gain of this frame from its envelope buffer (k_adsr_env:
+        // adsr_vel(), the same f32 operations adsr_frame does; 1.0 where the reference leaves the frame untouched)
+        const float2 e = gload2(d->env + m);   // (m is even; the buffer holds frames + 1 gains)
+        PanGain pg;
+        pg.l_amp = d->pg.l_amp; pg.r_amp = d->pg.r_amp; pg.gain = d->pg.gain; pg.flags = d->pg.flags;
+        v = epilogue4(make_float4(x.x * e.x, x.y * e.x, x.z * e.y, x.w * e.y), pg);
         if (t[j].magic) v = epilogue4(add4(z, v), term_pg(t, j));
         v = zero_tail(v, m, M);
     }
@@ -1257,10 +1258,12 @@ __global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restr
 // ------------------------------------------------------------------------------------------------
 // k_adsr: envelope-follower vertex (extensions.rs:593-651)
 // ------------------------------------------------------------------------------------------------
-TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
+// the vertex' gain for frame m: lerp(1.0, adsr_vel, wet) (extensions.rs:636-645); 1.0 for a frame the reference leaves
+// untouched (the `continue` at extensions.rs:632-635: x * 1.0f == x bit for bit)
+TD_DEV float adsr_vel(const AdsrVDesc& d, uint32_t m) {
     const uint32_t it = find_interval(d.tab, m);
     const float4 p = d.tab.voices[2 * it], g = d.tab.voices[2 * it + 1];   // (t_off, vel, release_val, skip)
-    if (p.w != 0.0f) return x;   // extensions.rs:632-635: `continue` leaves this frame untouched
+    if (p.w != 0.0f) return 1.0f;
     const float offset = (float)(m % d.bl) / (float)d.sr;
     float pvel, gvel;
     if (d.use_off) {
@@ -1272,10 +1275,145 @@ TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
     }
     const float maxmul = d.use_max ? 1.0f : 0.0f;
     const float minmul = 1.0f - maxmul;
-    const float adsr_vel = fmaxf(pvel, gvel) * maxmul + fminf(pvel, gvel) * minmul;
-    const float vel = lerpf(1.0f, adsr_vel, d.wet);
+    const float av = fmaxf(pvel, gvel) * maxmul + fminf(pvel, gvel) * minmul;
+    return lerpf(1.0f, av, d.wet);
+}
+TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
+    const float vel = adsr_vel(d, m);
     return make_float2(x.x * vel, x.y * vel);
 }
+// ------------------------------------------------------------------------------------------------
+// k_adsr_env: the per-frame gain of an Adsr vertex that is read through by its consumer (InTerm kind 5)
+// ------------------------------------------------------------------------------------------------
+// env[m] = adsr_vel(d, m) for every frame of the chunk -- a function of the frame and the vertex' event tables only, so
+// vertices with identical tables and parameters (the 84 envelope stages of a deep chain) share ONE buffer and ONE launch,
+// and their consumers multiply by a 4-byte load instead of evaluating ~150 instructions per frame.
+// A lane owns kEnvRun consecutive frames.  What adsr_vel pays per frame -- the interval walk, two voice records, IEEE
+// divisions -- is paid once per run where the run lies in one interval (intervals start at block starts and event
+// frames, so nearly always):
+//  * divisions by the conf's segment lengths and by (float)sr as (float)((double)n * rcp), rcp = 1.0 / (double)x from the
+//    host.  That IS the IEEE f32 quotient: the product is within 1.5 * 2^-53 of n / x, and the quotient of two f32 is
+//    never closer than 2^-49 (relative) to a rounding boundary of a normal f32 result; quotients too small for that
+//    argument (below 1e-30: envelope times never get there) take the division.  n / 0 and 0 / 0 give +-inf / NaN as the
+//    division does.
+//  * the piece of the curve (attack / decay / sustain ramp / release) is found for the run's first and last envelope time
+//    and, if the same, applied as straight code.
+// Confs whose levels could reach the `res <= -1.0` escape (adsr.rs:62-69,75-86), negative or NaN times and runs that
+// straddle an interval start take adsr_vel frame by frame.  Same f32 operations in the same order either way: bit-exact.
+constexpr int kEnvRun = 16;
+TD_DEV float fdiv_rcp(float n, float x, double rcp) {
+    const float q = (float)((double)n * rcp);
+    if (fabsf(q) < 1.0e-30f && q != 0.0f) return n / x;
+    return q;
+}
+// The conf's scalars as opaque registers: read through the descriptor, the per-lane piece selects below are folded by
+// the compiler into INDEXED loads of a copy in scratch memory.
+TD_DEV float opaque_s(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+TD_DEV double opaque_s(double x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+struct AdsrRunConsts {
+    float A, D, S, R, AD, ADS, std_v, att_v, dec_v, sus_v, rel_v, dv0, dv1, dv2, dv3, srf;
+    double rA, rD, rS, rR, rsr;
+};
+TD_DEV AdsrRunConsts adsr_run_consts(const AdsrVDesc& d) {
+    const AdsrConfD& c = d.conf;
+    AdsrRunConsts u;
+    u.A = opaque_s(c.attack_sec); u.D = opaque_s(c.decay_sec); u.S = opaque_s(c.sustain_sec); u.R = opaque_s(c.release_sec);
+    u.AD = opaque_s(c.attack_sec + c.decay_sec);
+    u.ADS = opaque_s(c.attack_sec + c.decay_sec + c.sustain_sec);
+    u.std_v = opaque_s(c.std_vel); u.att_v = opaque_s(c.attack_vel); u.dec_v = opaque_s(c.decay_vel);
+    u.sus_v = opaque_s(c.sustain_vel); u.rel_v = opaque_s(c.release_vel);
+    u.dv0 = opaque_s(c.attack_vel - c.std_vel); u.dv1 = opaque_s(c.decay_vel - c.attack_vel);
+    u.dv2 = opaque_s(c.sustain_vel - c.decay_vel); u.dv3 = opaque_s(c.release_vel - c.sustain_vel);
+    u.srf = opaque_s((float)d.sr);
+    u.rA = opaque_s(d.rcp[0]); u.rD = opaque_s(d.rcp[1]); u.rS = opaque_s(d.rcp[2]); u.rR = opaque_s(d.rcp[3]);
+    u.rsr = opaque_s(d.rcp[4]);
+    return u;
+}
+struct AdsrPiece { float a, dv, s1, s2, s3, x; double rcp; int k; };   // value = a + q dv, q = (((t - s1) - s2) - s3) / x [min 1: k == 3]
+TD_DEV int adsr_piece_index(const AdsrRunConsts& u, float t) {   // the `t <= ...` chain of adsr.rs:46-60 (NaN: 3)
+    return t <= u.A ? 0 : t <= u.AD ? 1 : t <= u.ADS ? 2 : 3;
+}
+TD_DEV AdsrPiece adsr_piece(const AdsrRunConsts& u, int k) {
+    AdsrPiece p;
+    p.k = k;
+    p.s1 = 0.0f; p.s2 = 0.0f; p.s3 = 0.0f;
+    p.a = u.std_v; p.dv = u.dv0; p.x = u.A; p.rcp = u.rA;
+    if (k >= 1) { p.s1 = u.A; p.a = u.att_v; p.dv = u.dv1; p.x = u.D; p.rcp = u.rD; }
+    if (k >= 2) { p.s2 = u.D; p.a = u.dec_v; p.dv = u.dv2; p.x = u.S; p.rcp = u.rS; }
+    if (k >= 3) { p.s3 = u.S; p.a = u.sus_v; p.dv = u.dv3; p.x = u.R; p.rcp = u.rR; }
+    return p;
+}
+// mode 0: apply_adsr (adsr.rs:75-86), 1: apply_ads (adsr.rs:62-69): beyond the sustain ramp the level is sustain_vel
+TD_DEV float adsr_piece_value(const AdsrPiece& p, float t, int mode, float sustain_vel) {
+    if (mode == 1 && p.k == 3) return sustain_vel;
+    float q = fdiv_rcp(((t - p.s1) - p.s2) - p.s3, p.x, p.rcp);
+    if (p.k == 3) q = fminf(q, 1.0f);
+    return p.a + q * p.dv;
+}
+struct AdsrVoiceRun { float t0, vel, rel; int mode; bool same; AdsrPiece pc; };   // mode 2: apply_r from `rel` (adsr.rs:71-73)
+TD_DEV AdsrVoiceRun adsr_voice_run(const AdsrRunConsts& u, bool use_off, float4 v, float off_first, float off_last, bool& ok) {
+    AdsrVoiceRun r;
+    r.t0 = v.x; r.vel = v.y; r.rel = v.z;
+    r.mode = use_off ? (v.z == 0.0f ? 1 : 2) : 0;
+    const float tf = v.x + off_first, tl = v.x + off_last;
+    ok = ok && tf >= 0.0f && tl >= tf;   // (NaN fails both)
+    const int kf = adsr_piece_index(u, tf), kl = adsr_piece_index(u, tl);
+    r.same = kf == kl;
+    r.pc = adsr_piece(u, kf);
+    return r;
+}
+TD_DEV float adsr_voice_value(const AdsrRunConsts& u, const AdsrVoiceRun& r, float offset) {
+    const float t = r.t0 + offset;
+    if (r.mode == 2) return (r.rel + fminf(fdiv_rcp(t, u.R, u.rR), 1.0f) * (u.rel_v - r.rel)) * r.vel;
+    if (r.same) return adsr_piece_value(r.pc, t, r.mode, u.sus_v) * r.vel;
+    return adsr_piece_value(adsr_piece(u, adsr_piece_index(u, t)), t, r.mode, u.sus_v) * r.vel;
+}
+__global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restrict__ descs, uint32_t M) {
+    const AdsrVDesc& d = descs[blockIdx.y];
+    const uint32_t m0 = (blockIdx.x * kThreads + threadIdx.x) * (uint32_t)kEnvRun;
+    if (m0 >= M) return;
+    float* const out = d.env;
+    const uint32_t mlast = min(m0 + (uint32_t)kEnvRun - 1u, M - 1u);
+    const uint32_t it = find_interval(d.tab, m0);
+    const uint32_t TD_GLOBAL* st = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)d.tab.istart);
+    bool fast = d.tame != 0u && mlast - m0 == (uint32_t)kEnvRun - 1u && (it + 1u >= d.tab.n_int || st[it + 1u] > mlast);
+    const uint32_t i0 = m0 % d.bl;
+    fast = fast && i0 + (uint32_t)kEnvRun <= d.bl;   // (no block start inside the run: intervals begin there anyway)
+    const AdsrRunConsts u = adsr_run_consts(d);
+    AdsrVoiceRun pr{}, gr{};
+    if (fast) {
+        const float4 p = d.tab.voices[2u * it], g = d.tab.voices[2u * it + 1u];   // (t_off, vel, release_val, skip)
+        fast = p.w == 0.0f;
+        const float of = fdiv_rcp((float)i0, u.srf, u.rsr), ol = fdiv_rcp((float)(i0 + (uint32_t)kEnvRun - 1u), u.srf, u.rsr);
+        pr = adsr_voice_run(u, d.use_off != 0u, p, of, ol, fast);
+        gr = adsr_voice_run(u, d.use_off != 0u, g, of, ol, fast);
+    }
+    if (fast) {
+        const float maxmul = d.use_max ? 1.0f : 0.0f, minmul = 1.0f - maxmul;
+#pragma unroll 1
+        for (uint32_t q = 0; q < (uint32_t)kEnvRun; q += 4u) {
+            float v[4];
+#pragma unroll
+            for (uint32_t e = 0; e < 4u; ++e) {
+                const float offset = fdiv_rcp((float)(i0 + q + e), u.srf, u.rsr);   // (float)(i % bl) / (float)sr
+                const float pvel = adsr_voice_value(u, pr, offset), gvel = adsr_voice_value(u, gr, offset);
+                const float av = fmaxf(pvel, gvel) * maxmul + fminf(pvel, gvel) * minmul;
+                v[e] = lerpf(1.0f, av, d.wet);
+            }
+            gstore4(out + m0 + q, make_float4(v[0], v[1], v[2], v[3]));
+        }
+    } else {
+#pragma unroll 1
+        for (uint32_t m = m0; m <= mlast; ++m) out[m] = adsr_vel(d, m);
+    }
+}
+
 template <int TMODE>
 __global__ __launch_bounds__(kThreads) void k_adsr(const AdsrVDesc* __restrict__ descs, uint32_t M) {
     const AdsrVDesc& d = descs[blockIdx.y];
@@ -2076,12 +2214,14 @@ __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_band_scan: band_pass_gen as a blocked affine scan -- tolerance class, one launch per vertex (BandScanDesc, kernels.h)
+// k_band_scan: band_pass_gen as a blocked affine scan -- tolerance class; one launch per vertex or per chain of
+// band-pass vertices (BandScanDesc, kernels.h)
 // ------------------------------------------------------------------------------------------------
 // Inter-workgroup hand-off: 8-byte {tag = 1, value} granules, one agent-scope atomic store each, read back with
 // agent-scope atomic loads (global_store / global_load ... sc1: L1 bypassed, the data word carries its own validity, so
 // no fence on either side); the granule words are zeroed by the engine before every launch.
 typedef unsigned long long TD_GLOBAL* gu64;
+typedef uint32_t TD_GLOBAL* gu32;
 TD_DEV void granule_store(unsigned long long* p, uint32_t value) {
     __hip_atomic_store((gu64)(TD_GLOBAL char*)p, (1ull << 32) | (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2092,40 +2232,58 @@ TD_DEV double dsel4(const double v[4], uint32_t c) { return c == 0u ? v[0] : c =
 constexpr uint32_t kScanSpinLimit = 4096;   // polls (~1 us each) before a predecessor is recomputed instead of awaited
 
 template <int TMODE, int NF>
-__global__ __launch_bounds__(kThreads) void k_band_scan(const BandScanDesc* __restrict__ descs, uint32_t M) {
+__global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const BandScanDesc* __restrict__ descs, uint32_t M) {
     constexpr int NP = NF / 2;                          // frame pairs (16-byte words) per lane
     constexpr uint32_t TILE = (uint32_t)NF * kThreads;  // frames per workgroup
     const BandScanDesc& d = descs[blockIdx.y];
-    const uint32_t tile = blockIdx.x;
-    if (tile >= d.n_tiles) return;
+    if (blockIdx.x >= d.n_tiles) return;
     // tile staging, lane-major with one pad word per lane run: the coalesced side (word q * 256 + tid) and the lane side
     // (words tid * NP .. + NP - 1) are both conflict-free
     __shared__ float4 xt[kThreads * (NP + 1)];
     __shared__ double wtot[kThreads / 64][4];
     __shared__ double carry_s[4];
+    __shared__ float st_l[kScanMaxStages][5];       // tile 0: every stage's carried state {y[4], first} as the launch found it
     __shared__ float yinit_s[4];
-    __shared__ uint32_t first_s;
     __shared__ uint32_t pb[kScanMaxK * 8];          // the predecessors' granule values, oldest first
     __shared__ uint32_t have_s[kScanMaxK / 32];     // bit p: predecessor p's eight granules are in pb
-    __shared__ uint32_t all_s;
+    __shared__ uint32_t all_s, tile_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const float lgam = d.lgamma, hgam = d.hgamma;
-    const double al = 1.0 - (double)lgam, ah = 1.0 - (double)hgam, gl = (double)lgam, gh = (double)hgam;
-    const double awl = d.aw[0], awh = d.aw[1];
+    const uint32_t n_stages = d.n_stages;
+    const bool chain = n_stages > 1u;
+    const BandStageDesc TD_CONST* const stages = (const BandStageDesc TD_CONST*)(const TD_CONST char*)d.stages;   // (uniform: scalar loads)
+    // Tile number.  A chain's workgroups draw tickets: a workgroup only ever waits for LOWER tiles, and whoever drew a
+    // lower ticket is running -- no assumption about the order workgroups are dispatched in.  (A single vertex uses
+    // blockIdx.x and bounded waits instead: the ticket counter would serialise the start of a ~15 us kernel.)
+    uint32_t tile = blockIdx.x;
+    if (chain) {
+        if (tid == 0u) tile_s = atomicAdd(d.ticket, 1u);
+        __syncthreads();
+        tile = tile_s;
+    }
+    if (tile == 0u) {
+        // The carried states, before any workgroup can have replaced them: the last tile stores a stage's new state only
+        // after it has seen the word set below.
+        for (uint32_t i = tid; i < n_stages * 5u; i += kThreads) {
+            const uint32_t s = i / 5u, e = i - 5u * s;
+            const uint32_t TD_GLOBAL* sw = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)stages[s].state);
+            st_l[s][e] = __uint_as_float(sw[e]);
+        }
+        __syncthreads();
+        if (tid == 0u) __hip_atomic_store((gu32)(TD_GLOBAL char*)(d.ticket + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const TermTab ins = term_tab(d.ins);
     const uint32_t k = d.k;
     auto slot = [](uint32_t p) { return p + p / (uint32_t)NP; };
+    const uint32_t tile0 = tile * TILE, mlast = M - 1u, mf = tile0 + (uint32_t)NF * tid;
 
-    float4 x[NP];             // the lane's NF consecutive input frames
+    float4 x[NP];             // the lane's NF consecutive frames: a stage's input, then its output
     double excl[4], xw[4], B[4];
-    // Input terms -> lane-consecutive frames -> zero-state responses: of the lane's run (b), of the wave up to the lane
-    // (excl), of the tile up to the wave (xw), of the whole tile (B).  Used for the workgroup's own tile and, should a
-    // predecessor fail to publish in time, for that predecessor's tile: identical arithmetic, identical values.
-    auto compute = [&](uint32_t tt) {
-        const uint32_t tile0 = tt * TILE;
+    // ---- the first vertex' input terms for tile tt -> lane-consecutive frames
+    auto load_tile = [&](uint32_t tt) {
+        const uint32_t t0 = tt * TILE;
 #pragma unroll
         for (int r = 0; r < NP / 2; ++r) {
-            const uint32_t m0 = tile0 + (uint32_t)(2 * r) * 512u + 2u * tid, m1 = m0 + 512u;
+            const uint32_t m0 = t0 + (uint32_t)(2 * r) * 512u + 2u * tid, m1 = m0 + 512u;
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
             sum_terms<TMODE>(ins, k, m0, m1, M, a0, a1);   // sum_inputs (extensions.rs:310-319): zero, += in edge order
             xt[slot((uint32_t)(2 * r) * 256u + tid)] = a0;
@@ -2134,6 +2292,21 @@ __global__ __launch_bounds__(kThreads) void k_band_scan(const BandScanDesc* __re
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < NP; ++j) x[j] = xt[tid * (uint32_t)(NP + 1) + (uint32_t)j];
+    };
+    // ---- stage parameters (uniform)
+    const BandStageDesc TD_CONST* sp = stages;
+    float lgam = 0.f, hgam = 0.f;
+    double al = 0.0, ah = 0.0, gl = 0.0, gh = 0.0, awl = 0.0, awh = 0.0;
+    auto set_stage = [&](uint32_t s) {
+        sp = stages + s;
+        lgam = sp->lgamma; hgam = sp->hgamma;
+        al = 1.0 - (double)lgam; ah = 1.0 - (double)hgam; gl = (double)lgam; gh = (double)hgam;
+        awl = sp->aw[0]; awh = sp->aw[1];
+    };
+    // ---- zero-state responses of x: of the lane's run (b), of the wave up to the lane (excl), of the tile up to the
+    // wave (xw), of the whole tile (B).  Used for the workgroup's own tile and, should a predecessor of a single vertex
+    // fail to publish in time, for that predecessor's tile: identical arithmetic, identical values.
+    auto pass1 = [&](uint32_t s, bool is_tile0) {
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -2148,9 +2321,9 @@ __global__ __launch_bounds__(kThreads) void k_band_scan(const BandScanDesc* __re
             b3 = __builtin_fma(b3, ah, gh * (double)v.w);
         }
 #pragma unroll
-        for (int s = 0; s < 6; ++s) {   // inclusive scan over the wave: b_i += a^(NF * 2^s) b_(i - 2^s)
-            const uint32_t dd = 1u << s;
-            const double pl = d.ap[0][s], ph = d.ap[1][s];
+        for (int q = 0; q < 6; ++q) {   // inclusive scan over the wave: b_i += a^(NF * 2^q) b_(i - 2^q)
+            const uint32_t dd = 1u << q;
+            const double pl = sp->ap[0][q], ph = sp->ap[1][q];
             const double t0 = __shfl_up(b0, dd, 64), t1 = __shfl_up(b1, dd, 64), t2 = __shfl_up(b2, dd, 64), t3 = __shfl_up(b3, dd, 64);
             if (lane >= dd) {
                 b0 = __builtin_fma(t0, pl, b0);
@@ -2163,16 +2336,19 @@ __global__ __launch_bounds__(kThreads) void k_band_scan(const BandScanDesc* __re
         excl[2] = __shfl_up(b2, 1u, 64); excl[3] = __shfl_up(b3, 1u, 64);
         if (lane == 0u) excl[0] = excl[1] = excl[2] = excl[3] = 0.0;
         if (lane == 63u) { wtot[wave][0] = b0; wtot[wave][1] = b1; wtot[wave][2] = b2; wtot[wave][3] = b3; }
-        if (tt == 0u && tid == 0u) {
+        if (is_tile0 && tid == 0u) {
             // state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670).  Only tile 0's own
             // workgroup ever computes tile 0 (it is the one predecessor that is never recomputed).
-            const uint32_t first = d.state->first;
-            const float* sf = reinterpret_cast<const float*>(d.state);
-            first_s = first;
-            yinit_s[0] = first ? x[0].x : sf[0];
-            yinit_s[1] = first ? x[0].y : sf[1];
-            yinit_s[2] = first ? x[0].x : sf[2];
-            yinit_s[3] = first ? x[0].y : sf[3];
+            const bool first = __float_as_uint(st_l[s][4]) != 0u;
+            yinit_s[0] = first ? x[0].x : st_l[s][0];
+            yinit_s[1] = first ? x[0].y : st_l[s][1];
+            yinit_s[2] = first ? x[0].x : st_l[s][2];
+            yinit_s[3] = first ? x[0].y : st_l[s][3];
+            if (first) {   // a constant chain (gamma 0) keeps its seed for good
+                float* sf = reinterpret_cast<float*>(sp->state);
+                if (lgam == 0.0f) { sf[0] = yinit_s[0]; sf[1] = yinit_s[1]; }
+                if (hgam == 0.0f) { sf[2] = yinit_s[2]; sf[3] = yinit_s[3]; }
+            }
         }
         __syncthreads();
         double acc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -2190,151 +2366,186 @@ __global__ __launch_bounds__(kThreads) void k_band_scan(const BandScanDesc* __re
         const unsigned long long u = (unsigned long long)__double_as_longlong(dsel4(B, q >> 1));
         return (q & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u;
     };
+    bool state_may_be_written = tile == 0u;   // (this workgroup has seen "tile 0 has read the carried states")
 
-    const uint32_t n_pred = min(tile, d.K), first_pred = tile - n_pred;
-    // Work list: the own tile; then -- only if a predecessor did not publish in time -- the missing predecessors and the
-    // own tile once more (its frames were dropped to make room).  One inlined copy of compute().
-    uint32_t cur = tile, p_cur = 0u, p_next = 0u;
-    int phase = 0;
-    for (;;) {
-        compute(cur);
-        if (phase == 2) break;
-        if (phase == 0) {
-            if (tid < 8u) {   // publish: the state this tile leaves behind when entered with zero state (tile 0: with the true state)
-                const uint32_t c = tid >> 1;
-                if (tile == 0u) {
-                    const double v = __builtin_fma((double)yinit_s[c], d.at[c >> 1], dsel4(B, c));
-                    const unsigned long long u = (unsigned long long)__double_as_longlong(v);
-                    granule_store(d.sync + tid, (tid & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
-                } else {
-                    granule_store(d.sync + (size_t)tile * 8u + tid, half_of(tid));
-                }
-            }
-            if (tile == 0u && tid == 0u && first_s) {   // a constant chain (gamma 0) keeps its seed for good
-                float* sf = reinterpret_cast<float*>(d.state);
-                if (lgam == 0.0f) { sf[0] = yinit_s[0]; sf[1] = yinit_s[1]; }
-                if (hgam == 0.0f) { sf[2] = yinit_s[2]; sf[3] = yinit_s[3]; }
-            }
-            if (n_pred == 0u) break;
-            if (wave == 0u) {
-                const unsigned long long* g0 = d.sync + (size_t)first_pred * 8u;
-                const uint32_t n8 = n_pred * 8u;
-                if (lane < kScanMaxK / 32u) have_s[lane] = 0u;
-                bool done = false;
-                if (!(d.flags & 1u)) {
-                    for (uint32_t spin = 0;; ++spin) {
-                        bool ok = true;
-                        for (uint32_t idx = lane; idx < n8; idx += 64u) {
-                            const unsigned long long g = granule_load(g0 + idx);
-                            const bool t = (uint32_t)(g >> 32) == 1u;
-                            if (t) pb[idx] = (uint32_t)g;
-                            ok = ok && t;
-                        }
-                        if (__all(ok ? 1 : 0)) { done = true; break; }
-                        if (spin >= kScanSpinLimit) break;
-                        __builtin_amdgcn_s_sleep(4);
+    for (uint32_t s = 0; s < n_stages; ++s) {
+        set_stage(s);
+        unsigned long long* const sync = sp->sync;
+        const uint32_t n_pred = min(tile, sp->K), first_pred = tile - n_pred;
+        // Work list of the stage: the own tile; then -- a single vertex only, and only if a predecessor did not publish
+        // in time -- the missing predecessors and the own tile once more (its frames were dropped to make room).
+        uint32_t cur = tile, p_cur = 0u, p_next = 0u;
+        int phase = 0;
+        for (;;) {
+            if (s == 0u) load_tile(cur);   // (later stages of a chain: the frames are in registers)
+            pass1(s, cur == 0u);
+            if (phase == 2) break;
+            if (phase == 0) {
+                if (tid < 8u) {   // publish: the state this tile leaves behind when entered with zero state (tile 0: with the true state)
+                    const uint32_t c = tid >> 1;
+                    if (tile == 0u) {
+                        const double v = __builtin_fma((double)yinit_s[c], sp->at[c >> 1], dsel4(B, c));
+                        const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+                        granule_store(sync + tid, (tid & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
+                    } else {
+                        granule_store(sync + (size_t)tile * 8u + tid, half_of(tid));
                     }
                 }
-                if (!done) {
-                    // which predecessors are complete (lanes 8 j .. 8 j + 7 read tile j of a group of eight)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    if (!(d.flags & 1u))
-                        for (uint32_t base = 0; base < n8; base += 64u) {
-                            const uint32_t idx = base + lane;
-                            bool t = false;
-                            if (idx < n8) {
+                if (n_pred == 0u) break;
+                if (wave == 0u) {
+                    const unsigned long long* g0 = sync + (size_t)first_pred * 8u;
+                    const uint32_t n8 = n_pred * 8u;
+                    if (lane < kScanMaxK / 32u) have_s[lane] = 0u;
+                    const bool forced = !chain && (d.flags & 1u) != 0u;
+                    bool done = false;
+                    if (!forced) {
+                        for (uint32_t spin = 0;; ++spin) {
+                            bool ok = true;
+                            for (uint32_t idx = lane; idx < n8; idx += 64u) {
                                 const unsigned long long g = granule_load(g0 + idx);
-                                t = (uint32_t)(g >> 32) == 1u;
+                                const bool t = (uint32_t)(g >> 32) == 1u;
                                 if (t) pb[idx] = (uint32_t)g;
+                                ok = ok && t;
                             }
-                            const unsigned long long bal = __ballot(t ? 1 : 0);
-                            const uint32_t p = base / 8u + lane;
-                            if (lane < 8u && p < n_pred && ((bal >> (8u * lane)) & 0xFFull) == 0xFFull)
-                                atomicOr(&have_s[p >> 5], 1u << (p & 31u));
+                            if (__all(ok ? 1 : 0)) { done = true; break; }
+                            if (!chain && spin >= kScanSpinLimit) break;   // (a chain's waits are safe without bound: tickets)
+                            __builtin_amdgcn_s_sleep(2);
                         }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    // tile 0 depends on nobody and is the one tile nobody else can compute (it folds the carried state,
-                    // which the last tile overwrites once tile 0 has published): waited for without bound
-                    if (first_pred == 0u && !(have_s[0] & 1u)) {
-                        for (;;) {
-                            bool t = true;
-                            if (lane < 8u) {
-                                const unsigned long long g = granule_load(g0 + lane);
-                                t = (uint32_t)(g >> 32) == 1u;
-                                if (t) pb[lane] = (uint32_t)g;
-                            }
-                            if (__all(t ? 1 : 0)) break;
-                            __builtin_amdgcn_s_sleep(8);
-                        }
-                        if (lane == 0u) atomicOr(&have_s[0], 1u);
                     }
+                    if (!done) {
+                        // which predecessors are complete (lanes 8 j .. 8 j + 7 read tile j of a group of eight)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        if (!forced)
+                            for (uint32_t base = 0; base < n8; base += 64u) {
+                                const uint32_t idx = base + lane;
+                                bool t = false;
+                                if (idx < n8) {
+                                    const unsigned long long g = granule_load(g0 + idx);
+                                    t = (uint32_t)(g >> 32) == 1u;
+                                    if (t) pb[idx] = (uint32_t)g;
+                                }
+                                const unsigned long long bal = __ballot(t ? 1 : 0);
+                                const uint32_t p = base / 8u + lane;
+                                if (lane < 8u && p < n_pred && ((bal >> (8u * lane)) & 0xFFull) == 0xFFull)
+                                    atomicOr(&have_s[p >> 5], 1u << (p & 31u));
+                            }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                        // tile 0 depends on nobody and is the one tile nobody else can compute (it folds the carried
+                        // state): waited for without bound
+                        if (first_pred == 0u && !(have_s[0] & 1u)) {
+                            for (;;) {
+                                bool t = true;
+                                if (lane < 8u) {
+                                    const unsigned long long g = granule_load(g0 + lane);
+                                    t = (uint32_t)(g >> 32) == 1u;
+                                    if (t) pb[lane] = (uint32_t)g;
+                                }
+                                if (__all(t ? 1 : 0)) break;
+                                __builtin_amdgcn_s_sleep(8);
+                            }
+                            if (lane == 0u) atomicOr(&have_s[0], 1u);
+                        }
+                    }
+                    if (lane == 0u) all_s = done ? 1u : 0u;
                 }
-                if (lane == 0u) all_s = done ? 1u : 0u;
+                __syncthreads();
+                if (all_s) break;
+                phase = 1;
+            } else {   // phase 1: a predecessor's response, computed here
+                if (tid < 8u) pb[p_cur * 8u + tid] = half_of(tid);
             }
-            __syncthreads();
-            if (all_s) break;
-            phase = 1;
-        } else {   // phase 1: a predecessor's response, computed here
-            if (tid < 8u) pb[p_cur * 8u + tid] = half_of(tid);
+            // next missing predecessor (uniform), or back to the own tile
+            while (p_next < n_pred && ((have_s[p_next >> 5] >> (p_next & 31u)) & 1u)) ++p_next;
+            if (p_next < n_pred) { p_cur = p_next++; cur = first_pred + p_cur; }
+            else { phase = 2; cur = tile; }
         }
-        // next missing predecessor (uniform), or back to the own tile
-        while (p_next < n_pred && ((have_s[p_next >> 5] >> (p_next & 31u)) & 1u)) ++p_next;
-        if (p_next < n_pred) { p_cur = p_next++; cur = first_pred + p_cur; }
-        else { phase = 2; cur = tile; }
-    }
-    __syncthreads();   // pb complete
-    if (tid < 4u) {
-        // state entering the tile: C = sum_j a_tile^(j-1) B_(tile-j), oldest first (tile 0: the carried / seeded state)
-        const double a = d.at[tid >> 1];
-        double C = 0.0;
-        if (tile == 0u) C = (double)yinit_s[tid];
-        else
-            for (uint32_t p = 0; p < n_pred; ++p) {
-                const unsigned long long u = (unsigned long long)pb[p * 8u + 2u * tid] | ((unsigned long long)pb[p * 8u + 2u * tid + 1u] << 32);
-                C = __builtin_fma(C, a, __longlong_as_double((long long)u));
-            }
-        carry_s[tid] = C;
-    }
-    __syncthreads();
-    // entry state of the lane's run, exact arithmetic rounded once: excl + a^(NF lane) (xw + a_wave^wave C)
-    double awpl = 1.0, awph = 1.0;
-    for (uint32_t w = 0; w < wave; ++w) { awpl *= awl; awph *= awh; }
-    const double pl = d.pw[lane], ph = d.pw[64u + lane];
-    float y0 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[0], xw[0]), excl[0]);
-    float y1 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[1], xw[1]), excl[1]);
-    float y2 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[2], xw[2]), excl[2]);
-    float y3 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[3], xw[3]), excl[3]);
-    // the lane's frames in the reference's own arithmetic (extensions.rs:671-688), outputs back through the staging
-    const BandCoef kf = band_coef(lgam, hgam, d.pass);
-    const PanGain pg = d.pg;
-    const uint32_t tile0 = tile * TILE, mlast = M - 1u, mf = tile0 + (uint32_t)NF * tid;
-    float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
-    bool has_fin = false;
+        __syncthreads();   // pb complete
+        if (tid < 4u) {
+            // state entering the tile: C = sum_j a_tile^(j-1) B_(tile-j), oldest first (tile 0: the carried / seeded state)
+            const double a = sp->at[tid >> 1];
+            double C = 0.0;
+            if (tile == 0u) C = (double)yinit_s[tid];
+            else
+                for (uint32_t p = 0; p < n_pred; ++p) {
+                    const unsigned long long u = (unsigned long long)pb[p * 8u + 2u * tid] | ((unsigned long long)pb[p * 8u + 2u * tid + 1u] << 32);
+                    C = __builtin_fma(C, a, __longlong_as_double((long long)u));
+                }
+            carry_s[tid] = C;
+        }
+        __syncthreads();
+        // entry state of the lane's run, exact arithmetic rounded once: excl + a^(NF lane) (xw + a_wave^wave C)
+        double awpl = 1.0, awph = 1.0;
+        for (uint32_t w = 0; w < wave; ++w) { awpl *= awl; awph *= awh; }
+        const double pl = sp->pw[lane], ph = sp->pw[64u + lane];
+        float y0 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[0], xw[0]), excl[0]);
+        float y1 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[1], xw[1]), excl[1]);
+        float y2 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[2], xw[2]), excl[2]);
+        float y3 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[3], xw[3]), excl[3]);
+        // the lane's frames in the reference's own arithmetic (extensions.rs:671-688); x becomes the vertex' output
+        const BandCoef kf = band_coef(lgam, hgam, sp->pass);
+        PanGain pg;
+        pg.l_amp = sp->pg.l_amp; pg.r_amp = sp->pg.r_amp; pg.gain = sp->pg.gain; pg.flags = sp->pg.flags;
+        float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
+        bool has_fin = false;
 #pragma unroll
-    for (int j = 0; j < NP; ++j) {
-        const float4 v = x[j];
-        y0 = y0 + lgam * (v.x - y0); y1 = y1 + lgam * (v.y - y1);
-        y2 = y2 + hgam * (v.x - y2); y3 = y3 + hgam * (v.y - y3);
-        const float2 oa = epilogue(band_out(kf, v.x, v.y, y0, y1, y2, y3), pg);
-        if (mf + 2u * (uint32_t)j == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
-        y0 = y0 + lgam * (v.z - y0); y1 = y1 + lgam * (v.w - y1);
-        y2 = y2 + hgam * (v.z - y2); y3 = y3 + hgam * (v.w - y3);
-        const float2 ob = epilogue(band_out(kf, v.z, v.w, y0, y1, y2, y3), pg);
-        if (mf + 2u * (uint32_t)j + 1u == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
-        xt[tid * (uint32_t)(NP + 1) + (uint32_t)j] = make_float4(oa.x, oa.y, ob.x, ob.y);
+        for (int j = 0; j < NP; ++j) {
+            const float4 v = x[j];
+            y0 = y0 + lgam * (v.x - y0); y1 = y1 + lgam * (v.y - y1);
+            y2 = y2 + hgam * (v.x - y2); y3 = y3 + hgam * (v.y - y3);
+            const float2 oa = epilogue(band_out(kf, v.x, v.y, y0, y1, y2, y3), pg);
+            if (mf + 2u * (uint32_t)j == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
+            y0 = y0 + lgam * (v.z - y0); y1 = y1 + lgam * (v.w - y1);
+            y2 = y2 + hgam * (v.z - y2); y3 = y3 + hgam * (v.w - y3);
+            const float2 ob = epilogue(band_out(kf, v.z, v.w, y0, y1, y2, y3), pg);
+            if (mf + 2u * (uint32_t)j + 1u == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
+            x[j] = make_float4(oa.x, oa.y, ob.x, ob.y);
+        }
+        if (has_fin) {   // the lane that holds the chunk's last frame carries the state over (constant chains: pass1)
+            if (!state_may_be_written) {
+                while (__hip_atomic_load((gu32)(TD_GLOBAL char*)(d.ticket + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+                    __builtin_amdgcn_s_sleep(8);
+                state_may_be_written = true;
+            }
+            float* sf = reinterpret_cast<float*>(sp->state);
+            if (lgam != 0.0f) { sf[0] = f0; sf[1] = f1; }
+            if (hgam != 0.0f) { sf[2] = f2; sf[3] = f3; }
+            sp->state->first = 0u;
+        }
+        if (s + 1u < n_stages) {
+            // the links to the next band-pass vertex, each with its own sum_inputs `0.0 + x`: an Adsr vertex multiplies by
+            // its gain of the frame (k_adsr_env), then pan / gain; a single-input Sum is pan / gain only; finally the next
+            // vertex' own `0.0 + x`.  Frames at or beyond M become 0, as sum_terms leaves them.
+            const uint32_t np = sp->n_post;
+            for (uint32_t p = 0; p < np; ++p) {
+                const float* env = sp->post[p].env;
+                PanGain lp;
+                lp.l_amp = sp->post[p].pg.l_amp; lp.r_amp = sp->post[p].pg.r_amp; lp.gain = sp->post[p].pg.gain; lp.flags = sp->post[p].pg.flags;
+                if (env) {
+#pragma unroll
+                    for (int q = 0; q < NP / 2; ++q) {
+                        // (mf is a multiple of NF: 16-byte aligned; the buffer holds at least frames + 3 gains)
+                        const float4 e = mf + 4u * (uint32_t)q < M ? gload4(env + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        float4 a = x[2 * q], b = x[2 * q + 1];
+                        a = make_float4((0.0f + a.x) * e.x, (0.0f + a.y) * e.x, (0.0f + a.z) * e.y, (0.0f + a.w) * e.y);
+                        b = make_float4((0.0f + b.x) * e.z, (0.0f + b.y) * e.z, (0.0f + b.z) * e.w, (0.0f + b.w) * e.w);
+                        x[2 * q] = epilogue4(a, lp);
+                        x[2 * q + 1] = epilogue4(b, lp);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) x[j] = epilogue4(add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]), lp);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x[j] = zero_tail(add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]), mf + 2u * (uint32_t)j, M);
+        }
     }
+    // the last vertex' output, back through the staging for coalesced stores
+#pragma unroll
+    for (int j = 0; j < NP; ++j) xt[tid * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NP; ++q) store_pair(d.out, tile0 + 2u * ((uint32_t)q * 256u + tid), M, xt[slot((uint32_t)q * 256u + tid)]);
-    if (has_fin) {   // the lane that holds the chunk's last frame carries the state over (constant chains: see above)
-        if (first_pred != 0u) {   // tile 0 was not among the polled predecessors: it must have read the old state first
-            while ((uint32_t)(granule_load(d.sync) >> 32) != 1u) __builtin_amdgcn_s_sleep(8);
-        }
-        float* sf = reinterpret_cast<float*>(d.state);
-        if (lgam != 0.0f) { sf[0] = f0; sf[1] = f1; }
-        if (hgam != 0.0f) { sf[2] = f2; sf[3] = f3; }
-        d.state->first = 0u;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2532,6 +2743,21 @@ void launch_synth(const SynthDesc* d, int n, uint32_t frames, hipStream_t s) {
 void launch_sampsyn(const SampsynDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
     TD_BATCHED(k_sampsyn, tiles(frames), kThreads, d, n, frames);
+}
+void adsr_fill_run_consts(AdsrVDesc* d) {
+    const AdsrConfD& c = d->conf;
+    d->rcp[0] = 1.0 / (double)c.attack_sec;
+    d->rcp[1] = 1.0 / (double)c.decay_sec;
+    d->rcp[2] = 1.0 / (double)c.sustain_sec;
+    d->rcp[3] = 1.0 / (double)c.release_sec;
+    d->rcp[4] = 1.0 / (double)(float)d->sr;
+    const float lo = fminf(fminf(c.std_vel, c.attack_vel), fminf(c.decay_vel, c.sustain_vel));
+    d->tame = lo > -0.999f ? 1u : 0u;   // (NaN levels: not tame)
+}
+void launch_adsr_env(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t s) {
+    if (!n || !frames) return;
+    const uint32_t per = (uint32_t)kThreads * (uint32_t)kEnvRun;
+    TD_BATCHED(k_adsr_env, (frames + per - 1u) / per, kThreads, d, n, frames);
 }
 void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {
     if (!n || !frames) return;
