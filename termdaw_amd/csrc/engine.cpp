@@ -1097,7 +1097,8 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
 struct ScanPlan {
     int nf = 16;
     uint32_t n_tiles = 0, K = 1;
-    size_t pw_off = 0;
+    uint32_t Kw = 0;          // look-back depth in wave-tiles (k_band_chain); 0: deeper than kScanMaxK -> not chainable
+    size_t pw_off = 0, pk_off = 0;
 };
 static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPlan* sp) {
     if (M >= 0x7FFF0000ull) return false;
@@ -1114,6 +1115,15 @@ static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPla
     }
     if (!(kmax <= (double)kScanMaxK)) return false;
     sp->K = (uint32_t)kmax;
+    // the same per wave-tile (a quarter of the tile): k_band_chain hands over per wave
+    double kw = 1.0;
+    for (float gamma : {v.lgamma, v.hgamma}) {
+        if (gamma == 0.0f) continue;
+        const double q = 1.0 - (double)gamma;
+        if (!(q > 0.0)) continue;
+        kw = std::max(kw, ceil((double)g->band_depth / (-(tile / 4.0) * log(q))));
+    }
+    sp->Kw = (sp->nf == 16 && kw <= (double)kScanMaxK) ? (uint32_t)kw : 0u;
     return true;
 }
 
@@ -1325,6 +1335,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     u = g->edges[u][0];
                 }
                 if (!ok || inlined[u] || !scan_plan.count(u) || cons[u].size() != 1 || (long)u == g->output_vertex) continue;
+                // (k_band_chain runs `pass` vertices -- whose right-channel smoothers reach no output -- at 16 frames per lane)
+                if (!g->vertices[b].pass || !g->vertices[u].pass || !kv.second.Kw || !scan_plan[u].Kw) continue;
                 prev_of[b] = u;
                 next_of[u] = b;
                 links_before[b] = links;
@@ -1902,7 +1914,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         uint32_t& tm = term_mode[first_of(vi)];
                         if (tm == TERMS_ALL_LOOP16 || tm == TERMS_ALL_LOOP32) tm = TERMS_MIXED;
                     }
-                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[first_of(a)] < term_mode[first_of(b)]; });
+                    auto launch_key = [&](size_t vi) { return term_mode[first_of(vi)] | (chain_of.count(vi) ? 0x10000u : 0u); };
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return launch_key(a) < launch_key(b); });
                     std::vector<BandScanDesc> d;
                     std::vector<size_t> stages_off;
                     for (size_t vi : vs) {
@@ -1936,6 +1949,20 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 it = scan_pw_off.emplace(key, st.put(pw)).first;
                             }
                             sp.pw_off = it->second;
+                            if (piece.size() > 1) {   // k_band_chain: per-frame and per-wave-tile powers
+                                for (int c = 0; c < 2; ++c)
+                                    for (int n2 = 0; n2 < 16; ++n2) x.pn[c][n2] = (float)pow(q[c], (double)(n2 + 1));
+                                x.Kw = sp.Kw;
+                                key.push_back('k');
+                                auto ik = scan_pw_off.find(key);
+                                if (ik == scan_pw_off.end()) {
+                                    std::vector<double> pk(2 * kScanMaxK);
+                                    for (int c = 0; c < 2; ++c)
+                                        for (uint32_t j = 0; j < kScanMaxK; ++j) pk[c * kScanMaxK + j] = pow(q[c], nf * 64.0 * (double)j);
+                                    ik = scan_pw_off.emplace(key, st.put(pk)).first;
+                                }
+                                sp.pk_off = ik->second;
+                            }
                             if (i + 1 < piece.size()) {   // the links to the next vertex of the chain
                                 const std::vector<ChainLink>& links = links_before[piece[i + 1]];
                                 x.n_post = (uint32_t)links.size();
@@ -1952,8 +1979,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         for (size_t i = 0; i < piece.size(); ++i) {
                             const size_t o = so + i * sizeof(BandStageDesc);
                             ptr_field(o, offsetof(BandStageDesc, pw), scan_plan[piece[i]].pw_off);
+                            if (piece.size() > 1) ptr_field(o, offsetof(BandStageDesc, pk), scan_plan[piece[i]].pk_off);
                             cb.sync_fix.push_back({o + offsetof(BandStageDesc, sync), cb.sync_bytes});
-                            cb.sync_bytes += (size_t)sp0.n_tiles * 64;
+                            cb.sync_bytes += (size_t)sp0.n_tiles * 128;   // 8 granules per tile, or 4 per wave-tile (chain)
                         }
                         BandScanDesc x{};
                         x.out = g->vbuf[vi];
@@ -1975,9 +2003,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     size_t b = 0;   // one launch per term mode (vs is sorted by it)
                     while (b < vs.size()) {
                         size_t e2 = b;
-                        while (e2 < vs.size() && term_mode[first_of(vs[e2])] == term_mode[first_of(vs[b])]) ++e2;
+                        while (e2 < vs.size() && launch_key(vs[e2]) == launch_key(vs[b])) ++e2;
                         add_launch(fam, off + b * sizeof(BandScanDesc), (int)(e2 - b),
-                                   term_mode[first_of(vs[b])] | ((uint32_t)scan_plan[first_of(vs[b])].nf << 8), lv);
+                                   launch_key(vs[b]) | ((uint32_t)scan_plan[first_of(vs[b])].nf << 8), lv);
                         b = e2;
                     }
                     continue;
@@ -2204,7 +2232,10 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, L.M, s); break;
-                case F_BAND_SCAN: launch_band_scan((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)(L.aux >> 8), s); break;
+                case F_BAND_SCAN:
+                    if (L.aux & 0x10000u) launch_band_chain((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, s);
+                    else launch_band_scan((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)((L.aux >> 8) & 0xFFu), s);
+                    break;
                 case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, L.M, s); break;
             }
         }

@@ -325,11 +325,12 @@ struct BandSpecDesc {
 //   One vertex (n_stages 1): tiles are numbered by blockIdx.x and waiting is bounded -- a predecessor that has not
 //   published in time is recomputed by the waiting workgroup itself, same arithmetic, same values -- so nothing depends on
 //   dispatch order; only tile 0, which depends on nobody, is waited for without bound.
-//   A chain (n_stages > 1: band-pass vertices linked by single-input, single-consumer gain / pan stages and Adsr
-//   vertices -- the shape of BASELINE config 4's 252 effect stages): the tile's frames stay in registers from stage to
-//   stage, the links (`0.0 + x`, envelope gain, pan / gain: BandPost) are applied in between, and every stage has its own
-//   granules.  A workgroup cannot recompute a predecessor's stage s > 0, so tiles are numbered by a ticket drawn at start
-//   (a workgroup only ever waits for lower tickets, whose holders are running), and waits are unbounded.
+//   A chain (n_stages > 1: `pass` band-pass vertices linked by single-input, single-consumer gain / pan stages and Adsr
+//   vertices -- the shape of BASELINE config 4's 252 effect stages; k_band_chain): the frames stay in registers from
+//   stage to stage, the links (`0.0 + x`, envelope gain, pan / gain: BandPost) are applied in between, and every stage
+//   has its own granules.  Nobody can recompute a predecessor's stage s > 0, so tiles are numbered by a ticket drawn at
+//   start (one only ever waits for lower tickets, whose holders are running), and waits are unbounded.  There a WAVE
+//   owns NF * 64 frames and hands over per wave: no workgroup barrier inside the stage loop.
 constexpr uint32_t kScanMaxK = 128;   // look-back depth limit (tiles); slower smoothers take the exact kernels
 constexpr uint32_t kScanMaxStages = 128;   // band-pass vertices per launch (the engine cuts longer chains)
 struct BandPost {               // one link between two band-pass vertices of a chain
@@ -352,6 +353,10 @@ struct BandStageDesc {          // one band-pass vertex
     // each link first does its own sum_inputs `0.0 + x`, and so does the next band-pass vertex
     uint32_t n_post, pad;
     BandPost post[3];
+    // k_band_chain (a chain's launch; `pass` vertices only): a WAVE owns NF * 64 frames and hands over per wave
+    float pn[2][16];            // (1 - gamma)^(n + 1), n = 0 .. NF - 1: what an entry state still weighs after n + 1 frames
+    const double* pk;           // [2][kScanMaxK]: (1 - gamma)^(NF * 64 * j): a predecessor j wave-tiles back
+    uint32_t Kw, pad3;          // look-back depth in wave-tiles (1 .. kScanMaxK)
 };
 struct BandScanDesc {
     const InTerm* ins;          // the (first) vertex' input terms, in connect() order
@@ -364,6 +369,7 @@ struct BandScanDesc {
     uint32_t pad[3];
 };
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
+void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);   // n_stages >= 2, NF 16
 inline uint32_t band_scan_tile_frames(int nf) { return (uint32_t)nf * (uint32_t)kThreads; }
 
 // ---- build-defined sinc resampler (stands in for the un-vendored rubato crate; DESIGN.md "Resampler") ----

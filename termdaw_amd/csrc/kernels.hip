@@ -2297,43 +2297,65 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     const BandStageDesc TD_CONST* sp = stages;
     float lgam = 0.f, hgam = 0.f;
     double al = 0.0, ah = 0.0, gl = 0.0, gh = 0.0, awl = 0.0, awh = 0.0;
+    bool need_r = true;
     auto set_stage = [&](uint32_t s) {
         sp = stages + s;
         lgam = sp->lgamma; hgam = sp->hgamma;
         al = 1.0 - (double)lgam; ah = 1.0 - (double)hgam; gl = (double)lgam; gh = (double)hgam;
         awl = sp->aw[0]; awh = sp->aw[1];
+        need_r = sp->pass == 0u;
     };
     // ---- zero-state responses of x: of the lane's run (b), of the wave up to the lane (excl), of the tile up to the
     // wave (xw), of the whole tile (B).  Used for the workgroup's own tile and, should a predecessor of a single vertex
     // fail to publish in time, for that predecessor's tile: identical arithmetic, identical values.
+    // need_r: the right-channel smoothers (chains 1, 3).  A `pass` vertex' right output is r - cutl (extensions.rs:685,
+    // quirk Q7): its right smoothers reach no output, now or after any later chunk, so they are not run (their two state
+    // words are left as they are; their granules carry zeros).
     auto pass1 = [&](uint32_t s, bool is_tile0) {
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+        if (need_r) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const float4 v = x[j];
-            b0 = __builtin_fma(b0, al, gl * (double)v.x);
-            b1 = __builtin_fma(b1, al, gl * (double)v.y);
-            b2 = __builtin_fma(b2, ah, gh * (double)v.x);
-            b3 = __builtin_fma(b3, ah, gh * (double)v.y);
-            b0 = __builtin_fma(b0, al, gl * (double)v.z);
-            b1 = __builtin_fma(b1, al, gl * (double)v.w);
-            b2 = __builtin_fma(b2, ah, gh * (double)v.z);
-            b3 = __builtin_fma(b3, ah, gh * (double)v.w);
+            for (int j = 0; j < NP; ++j) {
+                const float4 v = x[j];
+                b0 = __builtin_fma(b0, al, gl * (double)v.x);
+                b1 = __builtin_fma(b1, al, gl * (double)v.y);
+                b2 = __builtin_fma(b2, ah, gh * (double)v.x);
+                b3 = __builtin_fma(b3, ah, gh * (double)v.y);
+                b0 = __builtin_fma(b0, al, gl * (double)v.z);
+                b1 = __builtin_fma(b1, al, gl * (double)v.w);
+                b2 = __builtin_fma(b2, ah, gh * (double)v.z);
+                b3 = __builtin_fma(b3, ah, gh * (double)v.w);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const double xa = (double)x[j].x, xb = (double)x[j].z;
+                b0 = __builtin_fma(b0, al, gl * xa);
+                b2 = __builtin_fma(b2, ah, gh * xa);
+                b0 = __builtin_fma(b0, al, gl * xb);
+                b2 = __builtin_fma(b2, ah, gh * xb);
+            }
         }
 #pragma unroll
         for (int q = 0; q < 6; ++q) {   // inclusive scan over the wave: b_i += a^(NF * 2^q) b_(i - 2^q)
             const uint32_t dd = 1u << q;
             const double pl = sp->ap[0][q], ph = sp->ap[1][q];
-            const double t0 = __shfl_up(b0, dd, 64), t1 = __shfl_up(b1, dd, 64), t2 = __shfl_up(b2, dd, 64), t3 = __shfl_up(b3, dd, 64);
+            const double t0 = __shfl_up(b0, dd, 64), t2 = __shfl_up(b2, dd, 64);
             if (lane >= dd) {
                 b0 = __builtin_fma(t0, pl, b0);
-                b1 = __builtin_fma(t1, pl, b1);
                 b2 = __builtin_fma(t2, ph, b2);
-                b3 = __builtin_fma(t3, ph, b3);
+            }
+            if (need_r) {
+                const double t1 = __shfl_up(b1, dd, 64), t3 = __shfl_up(b3, dd, 64);
+                if (lane >= dd) {
+                    b1 = __builtin_fma(t1, pl, b1);
+                    b3 = __builtin_fma(t3, ph, b3);
+                }
             }
         }
-        excl[0] = __shfl_up(b0, 1u, 64); excl[1] = __shfl_up(b1, 1u, 64);
-        excl[2] = __shfl_up(b2, 1u, 64); excl[3] = __shfl_up(b3, 1u, 64);
+        excl[0] = __shfl_up(b0, 1u, 64); excl[2] = __shfl_up(b2, 1u, 64);
+        excl[1] = 0.0; excl[3] = 0.0;
+        if (need_r) { excl[1] = __shfl_up(b1, 1u, 64); excl[3] = __shfl_up(b3, 1u, 64); }
         if (lane == 0u) excl[0] = excl[1] = excl[2] = excl[3] = 0.0;
         if (lane == 63u) { wtot[wave][0] = b0; wtot[wave][1] = b1; wtot[wave][2] = b2; wtot[wave][3] = b3; }
         if (is_tile0 && tid == 0u) {
@@ -2368,8 +2390,21 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     };
     bool state_may_be_written = tile == 0u;   // (this workgroup has seen "tile 0 has read the carried states")
 
+    const double* pw_cur = nullptr;
+    double pwl = 1.0, pwh = 1.0;   // (1 - gamma)^(NF lane), low / high
     for (uint32_t s = 0; s < n_stages; ++s) {
         set_stage(s);
+        if (sp->pw != pw_cur) {   // (uniform; the stages of a chain of identical filters share one table: loaded once)
+            pw_cur = sp->pw;
+            pwl = pw_cur[lane];
+            pwh = pw_cur[64u + lane];
+        }
+        // the next link's envelope gains for the lane's frames: issued now, used after pass 2
+        const float* env_pre = (s + 1u < n_stages && sp->n_post) ? (sp->post[0].env ? sp->post[0].env : (sp->n_post > 1u ? sp->post[1].env : nullptr)) : nullptr;
+        float4 envv[NP / 2];
+#pragma unroll
+        for (int q = 0; q < NP / 2; ++q)
+            envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned long long* const sync = sp->sync;
         const uint32_t n_pred = min(tile, sp->K), first_pred = tile - n_pred;
         // Work list of the stage: the own tile; then -- a single vertex only, and only if a predecessor did not publish
@@ -2392,6 +2427,10 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
                     }
                 }
                 if (n_pred == 0u) break;
+                if (d.flags & 2u) {   // (timing experiments only: no look-back -- wrong results)
+                    for (uint32_t i = tid; i < n_pred * 8u; i += kThreads) pb[i] = 0u;
+                    break;
+                }
                 if (wave == 0u) {
                     const unsigned long long* g0 = sync + (size_t)first_pred * 8u;
                     const uint32_t n8 = n_pred * 8u;
@@ -2466,9 +2505,17 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
             double C = 0.0;
             if (tile == 0u) C = (double)yinit_s[tid];
             else
-                for (uint32_t p = 0; p < n_pred; ++p) {
-                    const unsigned long long u = (unsigned long long)pb[p * 8u + 2u * tid] | ((unsigned long long)pb[p * 8u + 2u * tid + 1u] << 32);
-                    C = __builtin_fma(C, a, __longlong_as_double((long long)u));
+                for (uint32_t p0 = 0; p0 < n_pred; p0 += 16u) {   // (the LDS reads of a group in flight together, then the dependent chain)
+                    double bv[16];
+#pragma unroll
+                    for (uint32_t e = 0; e < 16u; ++e) {
+                        const uint32_t p = min(p0 + e, n_pred - 1u);
+                        const unsigned long long u = (unsigned long long)pb[p * 8u + 2u * tid] | ((unsigned long long)pb[p * 8u + 2u * tid + 1u] << 32);
+                        bv[e] = __longlong_as_double((long long)u);
+                    }
+#pragma unroll
+                    for (uint32_t e = 0; e < 16u; ++e)
+                        if (p0 + e < n_pred) C = __builtin_fma(C, a, bv[e]);
                 }
             carry_s[tid] = C;
         }
@@ -2476,29 +2523,54 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         // entry state of the lane's run, exact arithmetic rounded once: excl + a^(NF lane) (xw + a_wave^wave C)
         double awpl = 1.0, awph = 1.0;
         for (uint32_t w = 0; w < wave; ++w) { awpl *= awl; awph *= awh; }
-        const double pl = sp->pw[lane], ph = sp->pw[64u + lane];
-        float y0 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[0], xw[0]), excl[0]);
-        float y1 = (float)__builtin_fma(pl, __builtin_fma(awpl, carry_s[1], xw[1]), excl[1]);
-        float y2 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[2], xw[2]), excl[2]);
-        float y3 = (float)__builtin_fma(ph, __builtin_fma(awph, carry_s[3], xw[3]), excl[3]);
-        // the lane's frames in the reference's own arithmetic (extensions.rs:671-688); x becomes the vertex' output
+        float y0 = (float)__builtin_fma(pwl, __builtin_fma(awpl, carry_s[0], xw[0]), excl[0]);
+        float y1 = (float)__builtin_fma(pwl, __builtin_fma(awpl, carry_s[1], xw[1]), excl[1]);
+        float y2 = (float)__builtin_fma(pwh, __builtin_fma(awph, carry_s[2], xw[2]), excl[2]);
+        float y3 = (float)__builtin_fma(pwh, __builtin_fma(awph, carry_s[3], xw[3]), excl[3]);
+        // the lane's frames in the reference's own arithmetic (extensions.rs:671-688); x becomes the vertex' output.
+        // Pan / gain steps a vertex skips (flags) are skipped by uniform branches, not computed and masked.
         const BandCoef kf = band_coef(lgam, hgam, sp->pass);
         PanGain pg;
         pg.l_amp = sp->pg.l_amp; pg.r_amp = sp->pg.r_amp; pg.gain = sp->pg.gain; pg.flags = sp->pg.flags;
+        auto epi4 = [](float4 v, const PanGain& g4) {
+            if (g4.flags & 1u) { v.x *= g4.l_amp; v.y *= g4.r_amp; v.z *= g4.l_amp; v.w *= g4.r_amp; }
+            if (g4.flags & 2u) { v.x *= g4.gain; v.y *= g4.gain; v.z *= g4.gain; v.w *= g4.gain; }
+            return v;
+        };
         float f0 = 0.f, f1 = 0.f, f2 = 0.f, f3 = 0.f;
         bool has_fin = false;
+        const bool fin_here = mlast - tile0 < TILE;   // (uniform: the chunk's last frame lies in this tile)
+        if (need_r) {
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const float4 v = x[j];
-            y0 = y0 + lgam * (v.x - y0); y1 = y1 + lgam * (v.y - y1);
-            y2 = y2 + hgam * (v.x - y2); y3 = y3 + hgam * (v.y - y3);
-            const float2 oa = epilogue(band_out(kf, v.x, v.y, y0, y1, y2, y3), pg);
-            if (mf + 2u * (uint32_t)j == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
-            y0 = y0 + lgam * (v.z - y0); y1 = y1 + lgam * (v.w - y1);
-            y2 = y2 + hgam * (v.z - y2); y3 = y3 + hgam * (v.w - y3);
-            const float2 ob = epilogue(band_out(kf, v.z, v.w, y0, y1, y2, y3), pg);
-            if (mf + 2u * (uint32_t)j + 1u == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
-            x[j] = make_float4(oa.x, oa.y, ob.x, ob.y);
+            for (int j = 0; j < NP; ++j) {
+                const float4 v = x[j];
+                y0 = y0 + lgam * (v.x - y0); y1 = y1 + lgam * (v.y - y1);
+                y2 = y2 + hgam * (v.x - y2); y3 = y3 + hgam * (v.y - y3);
+                const float2 oa = band_out(kf, v.x, v.y, y0, y1, y2, y3);
+                if (fin_here && mf + 2u * (uint32_t)j == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
+                y0 = y0 + lgam * (v.z - y0); y1 = y1 + lgam * (v.w - y1);
+                y2 = y2 + hgam * (v.z - y2); y3 = y3 + hgam * (v.w - y3);
+                const float2 ob = band_out(kf, v.z, v.w, y0, y1, y2, y3);
+                if (fin_here && mf + 2u * (uint32_t)j + 1u == mlast) { f0 = y0; f1 = y1; f2 = y2; f3 = y3; has_fin = true; }
+                x[j] = epi4(make_float4(oa.x, oa.y, ob.x, ob.y), pg);
+            }
+        } else {
+            // pass: cut_mul = 0, pass_mul = 1 -> out = (l - cutl, r - cutl) with cutl = (lmul ll + hmul (l - hl)) 0.5; for
+            // finite values the same bits as the reference's `cutl * cut_mul + passl * pass_mul` up to the sign of a zero
+            const bool lo_on = lgam != 0.0f, hi_on = hgam != 0.0f;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const float4 v = x[j];
+                y0 = y0 + lgam * (v.x - y0);
+                y2 = y2 + hgam * (v.x - y2);
+                const float ca = ((lo_on ? y0 : 0.0f) + (hi_on ? v.x - y2 : 0.0f)) * 0.5f;
+                if (fin_here && mf + 2u * (uint32_t)j == mlast) { f0 = y0; f2 = y2; has_fin = true; }
+                y0 = y0 + lgam * (v.z - y0);
+                y2 = y2 + hgam * (v.z - y2);
+                const float cb = ((lo_on ? y0 : 0.0f) + (hi_on ? v.z - y2 : 0.0f)) * 0.5f;
+                if (fin_here && mf + 2u * (uint32_t)j + 1u == mlast) { f0 = y0; f2 = y2; has_fin = true; }
+                x[j] = epi4(make_float4(v.x - ca, v.y - ca, v.z - cb, v.w - cb), pg);
+            }
         }
         if (has_fin) {   // the lane that holds the chunk's last frame carries the state over (constant chains: pass1)
             if (!state_may_be_written) {
@@ -2507,14 +2579,15 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
                 state_may_be_written = true;
             }
             float* sf = reinterpret_cast<float*>(sp->state);
-            if (lgam != 0.0f) { sf[0] = f0; sf[1] = f1; }
-            if (hgam != 0.0f) { sf[2] = f2; sf[3] = f3; }
+            if (lgam != 0.0f) { sf[0] = f0; if (need_r) sf[1] = f1; }
+            if (hgam != 0.0f) { sf[2] = f2; if (need_r) sf[3] = f3; }
             sp->state->first = 0u;
         }
         if (s + 1u < n_stages) {
-            // the links to the next band-pass vertex, each with its own sum_inputs `0.0 + x`: an Adsr vertex multiplies by
-            // its gain of the frame (k_adsr_env), then pan / gain; a single-input Sum is pan / gain only; finally the next
-            // vertex' own `0.0 + x`.  Frames at or beyond M become 0, as sum_terms leaves them.
+            // The links to the next band-pass vertex: an Adsr vertex multiplies by its gain of the frame (k_adsr_env), then
+            // pan / gain; a single-input Sum is pan / gain only.  Every link and the next vertex start with their own
+            // sum_inputs `0.0 + x`, whose only effect is -0 -> +0; a zero stays a zero through the multiplies in between, so
+            // ONE `0.0 + x` at the end leaves the same bits.  Frames at or beyond M become 0, as sum_terms leaves them.
             const uint32_t np = sp->n_post;
             for (uint32_t p = 0; p < np; ++p) {
                 const float* env = sp->post[p].env;
@@ -2524,20 +2597,24 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
 #pragma unroll
                     for (int q = 0; q < NP / 2; ++q) {
                         // (mf is a multiple of NF: 16-byte aligned; the buffer holds at least frames + 3 gains)
-                        const float4 e = mf + 4u * (uint32_t)q < M ? gload4(env + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        float4 a = x[2 * q], b = x[2 * q + 1];
-                        a = make_float4((0.0f + a.x) * e.x, (0.0f + a.y) * e.x, (0.0f + a.z) * e.y, (0.0f + a.w) * e.y);
-                        b = make_float4((0.0f + b.x) * e.z, (0.0f + b.y) * e.z, (0.0f + b.z) * e.w, (0.0f + b.w) * e.w);
-                        x[2 * q] = epilogue4(a, lp);
-                        x[2 * q + 1] = epilogue4(b, lp);
+                        const float4 e = env == env_pre ? envv[q]
+                                       : mf + 4u * (uint32_t)q < M ? gload4(env + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 a = x[2 * q], b = x[2 * q + 1];
+                        x[2 * q] = make_float4(a.x * e.x, a.y * e.x, a.z * e.y, a.w * e.y);
+                        x[2 * q + 1] = make_float4(b.x * e.z, b.y * e.z, b.z * e.w, b.w * e.w);
                     }
-                } else {
+                }
+                if (lp.flags) {
 #pragma unroll
-                    for (int j = 0; j < NP; ++j) x[j] = epilogue4(add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]), lp);
+                    for (int j = 0; j < NP; ++j) x[j] = epi4(x[j], lp);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NP; ++j) x[j] = zero_tail(add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]), mf + 2u * (uint32_t)j, M);
+            for (int j = 0; j < NP; ++j) x[j] = add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]);
+            if (tile0 + TILE > M) {   // (uniform: only the chunk's last tile has frames beyond M)
+#pragma unroll
+                for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
+            }
         }
     }
     // the last vertex' output, back through the staging for coalesced stores
@@ -2546,6 +2623,248 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NP; ++q) store_pair(d.out, tile0 + 2u * ((uint32_t)q * 256u + tid), M, xt[slot((uint32_t)q * 256u + tid)]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_band_chain: a chain of `pass` band-pass vertices in ONE launch (BandScanDesc with n_stages >= 2)
+// ------------------------------------------------------------------------------------------------
+// The frames of a wave -- NF * 64 consecutive ones, NF per lane -- stay in registers from stage to stage; the links
+// between two vertices (envelope gain, pan / gain) are applied in between.  Per stage and wave:
+//   z[n]   the smoothers' zero-state response inside the lane's run, the reference's own step  z + gamma (x - z)  (f32)
+//   scan   of the runs' responses over the wave (double), the wave's total published as four granules
+//   C      = sum_j a_wave^j B_(wave-tile - 1 - j) over the Kw preceding wave-tiles: lane j reads predecessor j's granules
+//          (spinning until they are tagged), multiplies by its power, the wave adds up (double)
+//   y[n]   = z[n] + (1 - gamma)^(n + 1) c, c the lane's entry state (exact arithmetic, rounded once) -- no second
+//          dependent walk -- then the vertex' output  (l - cut, r - cut), cut = (lmul low + hmul (l - high)) / 2.
+// A `pass` vertex' right-channel smoothers reach no output (extensions.rs:685, quirk Q7) and are not run.  No workgroup
+// barrier inside the stage loop: the four waves of a workgroup only share the ticket (wave-tile = 4 * ticket + wave) and
+// the staging memory, each wave its own quarter.  Waves wait for lower wave-tiles only: same workgroup or a lower ticket.
+template <int TMODE>
+__global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M) {
+    constexpr int NF = 16, NP = NF / 2;
+    constexpr uint32_t WT = (uint32_t)NF * 64u;         // frames per wave-tile
+    const BandScanDesc& d = descs[blockIdx.y];
+    if (blockIdx.x >= d.n_tiles) return;
+    __shared__ float4 xt[kThreads * (NP + 1)];          // staging, one quarter per wave: lane-major, one pad word per lane run
+    __shared__ float st_l[kScanMaxStages][5];           // wave-tile 0: every stage's carried state {y[4], first} as the launch found it
+    __shared__ uint32_t tile_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t n_stages = d.n_stages;
+    const BandStageDesc TD_CONST* const stages = (const BandStageDesc TD_CONST*)(const TD_CONST char*)d.stages;   // (uniform: scalar loads)
+    if (tid == 0u) tile_s = atomicAdd(d.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = tile_s;
+    if (tile == 0u) {
+        // The carried states, before anybody can have replaced them: the wave holding the chunk's last frame stores a
+        // stage's new state only after it has seen the word set below.
+        for (uint32_t i = tid; i < n_stages * 5u; i += kThreads) {
+            const uint32_t s = i / 5u, e = i - 5u * s;
+            const uint32_t TD_GLOBAL* sw = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)stages[s].state);
+            st_l[s][e] = __uint_as_float(sw[e]);
+        }
+        __syncthreads();
+        if (tid == 0u) __hip_atomic_store((gu32)(TD_GLOBAL char*)(d.ticket + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const uint32_t wt = tile * 4u + wave;               // this wave's tile
+    const uint32_t wt0 = wt * WT, mlast = M - 1u, mf = wt0 + (uint32_t)NF * lane;
+    float4* const xw4 = xt + wave * 64u * (uint32_t)(NP + 1);   // the wave's quarter of the staging
+    auto slot = [](uint32_t p) { return p + p / (uint32_t)NP; };
+    // ---- the first vertex' input terms for this wave's frames, coalesced (16-byte word q * 64 + lane), then lane-consecutive
+    float4 x[NP];
+    {
+        const TermTab ins = term_tab(d.ins);
+        const uint32_t k = d.k;
+#pragma unroll
+        for (int r = 0; r < NP / 2; ++r) {
+            const uint32_t m0 = wt0 + (uint32_t)(2 * r) * 128u + 2u * lane, m1 = m0 + 128u;
+            float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+            sum_terms<TMODE>(ins, k, m0, m1, M, a0, a1);   // sum_inputs (extensions.rs:310-319): zero, += in edge order
+            xw4[slot((uint32_t)(2 * r) * 64u + lane)] = a0;
+            xw4[slot((uint32_t)(2 * r + 1) * 64u + lane)] = a1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // (the wave's own LDS words: ordered within the wave)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) x[j] = xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j];
+    }
+    bool state_may_be_written = tile == 0u;
+    const double* pw_cur = nullptr;
+    const double* pk_cur = nullptr;
+    double pwl = 1.0, pwh = 1.0;     // (1 - gamma)^(NF lane)
+    double pkl = 0.0, pkh = 0.0;     // (1 - gamma)^(NF 64 lane): the weight of the predecessor `lane` wave-tiles back
+    double pkl2 = 0.0, pkh2 = 0.0;   // ... and of predecessor 64 + lane
+    const bool tail = wt0 + WT > M;  // (uniform: only the chunk's last wave-tiles have frames beyond M)
+    const bool fin_here = mlast >= wt0 && mlast - wt0 < WT;
+
+    for (uint32_t s = 0; s < n_stages; ++s) {
+        const BandStageDesc TD_CONST* const sp = stages + s;
+        const float lgam = sp->lgamma, hgam = sp->hgamma;
+        if (sp->pw != pw_cur) {   // (uniform; the stages of a chain of identical filters share their tables: loaded once)
+            pw_cur = sp->pw;
+            pwl = pw_cur[lane];
+            pwh = pw_cur[64u + lane];
+        }
+        if (sp->pk != pk_cur) {
+            pk_cur = sp->pk;
+            pkl = pk_cur[lane]; pkh = pk_cur[kScanMaxK + lane];
+            pkl2 = pk_cur[64u + lane]; pkh2 = pk_cur[kScanMaxK + 64u + lane];
+        }
+        // the next link's envelope gains for the lane's frames: issued now, used after the output
+        const float* env_pre = (s + 1u < n_stages && sp->n_post) ? (sp->post[0].env ? sp->post[0].env : (sp->n_post > 1u ? sp->post[1].env : nullptr)) : nullptr;
+        float4 envv[NP / 2];
+#pragma unroll
+        for (int q = 0; q < NP / 2; ++q)
+            envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // ---- zero-state responses inside the lane's run
+        float zl[NF], zh[NF];
+        {
+            float a = 0.0f, b = 0.0f;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                a = __builtin_fmaf(lgam, x[j].x - a, a); b = __builtin_fmaf(hgam, x[j].x - b, b);
+                zl[2 * j] = a; zh[2 * j] = b;
+                a = __builtin_fmaf(lgam, x[j].z - a, a); b = __builtin_fmaf(hgam, x[j].z - b, b);
+                zl[2 * j + 1] = a; zh[2 * j + 1] = b;
+            }
+        }
+        double b0 = (double)zl[NF - 1], b2 = (double)zh[NF - 1];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {   // inclusive scan over the wave: b_i += a^(NF * 2^q) b_(i - 2^q)
+            const uint32_t dd = 1u << q;
+            const double t0 = __shfl_up(b0, dd, 64), t2 = __shfl_up(b2, dd, 64);
+            if (lane >= dd) {
+                b0 = __builtin_fma(t0, sp->ap[0][q], b0);
+                b2 = __builtin_fma(t2, sp->ap[1][q], b2);
+            }
+        }
+        double e0 = __shfl_up(b0, 1u, 64), e2 = __shfl_up(b2, 1u, 64);   // the wave's response up to the lane's run
+        if (lane == 0u) { e0 = 0.0; e2 = 0.0; }
+        double W0 = __shfl(b0, 63, 64), W2 = __shfl(b2, 63, 64);         // ... and over the whole wave-tile
+        // state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
+        float yi0 = 0.f, yi2 = 0.f;
+        if (wt == 0u) {
+            const bool first = __float_as_uint(st_l[s][4]) != 0u;
+            const float x00 = __shfl(x[0].x, 0, 64);
+            yi0 = first ? x00 : st_l[s][0];
+            yi2 = first ? x00 : st_l[s][2];
+            if (first && lane == 0u) {   // a constant chain (gamma 0) keeps its seed for good
+                float* sf = reinterpret_cast<float*>(sp->state);
+                if (lgam == 0.0f) sf[0] = yi0;
+                if (hgam == 0.0f) sf[2] = yi2;
+            }
+            W0 = __builtin_fma((double)yi0, sp->aw[0], W0);   // (what this wave-tile leaves behind, entered with the TRUE state)
+            W2 = __builtin_fma((double)yi2, sp->aw[1], W2);
+        }
+        unsigned long long* const sync = sp->sync;
+        if (lane < 4u) {   // publish: granule q = chain (q >> 1) low / high word
+            const unsigned long long u = (unsigned long long)__double_as_longlong(lane < 2u ? W0 : W2);
+            granule_store(sync + (size_t)wt * 4u + lane, (lane & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
+        }
+        // ---- state entering the wave-tile
+        double C0 = (double)yi0, C2 = (double)yi2;
+        if (wt != 0u) {
+            const uint32_t n_pred = min(wt, sp->Kw);
+            C0 = 0.0; C2 = 0.0;
+            for (uint32_t base = 0; base < n_pred; base += 64u) {   // (one trip unless the look-back is deeper than 64 wave-tiles)
+                const uint32_t j = base + lane;
+                const bool mine = j < n_pred;
+                const unsigned long long* g = sync + (size_t)(wt - 1u - (mine ? j : 0u)) * 4u;
+                unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+                for (;;) {
+                    bool ok = true;
+                    if (d.flags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
+                    if (mine) {
+                        g0 = granule_load(g); g1 = granule_load(g + 1); g2 = granule_load(g + 2); g3 = granule_load(g + 3);
+                        ok = (uint32_t)(g0 >> 32) == 1u && (uint32_t)(g1 >> 32) == 1u && (uint32_t)(g2 >> 32) == 1u && (uint32_t)(g3 >> 32) == 1u;
+                    }
+                    if (__all(ok ? 1 : 0)) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (mine) {
+                    const double B0 = __longlong_as_double((long long)((g0 & 0xFFFFFFFFull) | (g1 << 32)));
+                    const double B2 = __longlong_as_double((long long)((g2 & 0xFFFFFFFFull) | (g3 << 32)));
+                    C0 = __builtin_fma(base ? pkl2 : pkl, B0, C0);
+                    C2 = __builtin_fma(base ? pkh2 : pkh, B2, C2);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) { C0 += __shfl_xor(C0, off, 64); C2 += __shfl_xor(C2, off, 64); }
+        }
+        // the lane's entry state, exact arithmetic rounded once
+        const float c0 = (float)__builtin_fma(pwl, C0, e0), c2 = (float)__builtin_fma(pwh, C2, e2);
+        // ---- output (extensions.rs:682-687 with cut_mul 0, pass_mul 1), pan / gain by uniform branches
+        PanGain pg;
+        pg.l_amp = sp->pg.l_amp; pg.r_amp = sp->pg.r_amp; pg.gain = sp->pg.gain; pg.flags = sp->pg.flags;
+        auto epi4 = [](float4 v, const PanGain& g4) {
+            if (g4.flags & 1u) { v.x *= g4.l_amp; v.y *= g4.r_amp; v.z *= g4.l_amp; v.w *= g4.r_amp; }
+            if (g4.flags & 2u) { v.x *= g4.gain; v.y *= g4.gain; v.z *= g4.gain; v.w *= g4.gain; }
+            return v;
+        };
+        const bool lo_on = lgam != 0.0f, hi_on = hgam != 0.0f;
+        float f0 = 0.f, f2 = 0.f;
+        bool has_fin = false;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const float4 v = x[j];
+            const float ya0 = __builtin_fmaf(sp->pn[0][2 * j], c0, zl[2 * j]), ya2 = __builtin_fmaf(sp->pn[1][2 * j], c2, zh[2 * j]);
+            const float yb0 = __builtin_fmaf(sp->pn[0][2 * j + 1], c0, zl[2 * j + 1]), yb2 = __builtin_fmaf(sp->pn[1][2 * j + 1], c2, zh[2 * j + 1]);
+            const float ca = ((lo_on ? ya0 : 0.0f) + (hi_on ? v.x - ya2 : 0.0f)) * 0.5f;
+            const float cb = ((lo_on ? yb0 : 0.0f) + (hi_on ? v.z - yb2 : 0.0f)) * 0.5f;
+            if (fin_here) {
+                if (mf + 2u * (uint32_t)j == mlast) { f0 = ya0; f2 = ya2; has_fin = true; }
+                if (mf + 2u * (uint32_t)j + 1u == mlast) { f0 = yb0; f2 = yb2; has_fin = true; }
+            }
+            x[j] = epi4(make_float4(v.x - ca, v.y - ca, v.z - cb, v.w - cb), pg);
+        }
+        if (has_fin) {   // the lane that holds the chunk's last frame carries the state over
+            if (!state_may_be_written) {
+                while (__hip_atomic_load((gu32)(TD_GLOBAL char*)(d.ticket + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+                    __builtin_amdgcn_s_sleep(8);
+            }
+            float* sf = reinterpret_cast<float*>(sp->state);
+            if (lo_on) sf[0] = f0;
+            if (hi_on) sf[2] = f2;
+            sp->state->first = 0u;
+        }
+        if (fin_here) state_may_be_written = state_may_be_written || __any(has_fin ? 1 : 0) != 0;
+        if (s + 1u < n_stages) {
+            // The links to the next band-pass vertex: an Adsr vertex multiplies by its gain of the frame (k_adsr_env), then
+            // pan / gain; a single-input Sum is pan / gain only.  Every link and the next vertex start with their own
+            // sum_inputs `0.0 + x`, whose only effect is -0 -> +0; a zero stays a zero through the multiplies in between, so
+            // ONE `0.0 + x` at the end leaves the same bits.  Frames at or beyond M become 0, as sum_terms leaves them.
+            const uint32_t np = sp->n_post;
+            for (uint32_t p = 0; p < np; ++p) {
+                const float* env = sp->post[p].env;
+                PanGain lp;
+                lp.l_amp = sp->post[p].pg.l_amp; lp.r_amp = sp->post[p].pg.r_amp; lp.gain = sp->post[p].pg.gain; lp.flags = sp->post[p].pg.flags;
+                if (env) {
+#pragma unroll
+                    for (int q = 0; q < NP / 2; ++q) {
+                        const float4 e = env == env_pre ? envv[q]
+                                       : mf + 4u * (uint32_t)q < M ? gload4(env + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 a = x[2 * q], b = x[2 * q + 1];
+                        x[2 * q] = make_float4(a.x * e.x, a.y * e.x, a.z * e.y, a.w * e.y);
+                        x[2 * q + 1] = make_float4(b.x * e.z, b.y * e.z, b.z * e.w, b.w * e.w);
+                    }
+                }
+                if (lp.flags) {
+#pragma unroll
+                    for (int j = 0; j < NP; ++j) x[j] = epi4(x[j], lp);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x[j] = add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]);
+            if (tail) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
+            }
+        }
+    }
+    // the last vertex' output, back through the wave's staging for coalesced stores
+#pragma unroll
+    for (int j = 0; j < NP; ++j) xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+#pragma unroll
+    for (int q = 0; q < NP; ++q) store_pair(d.out, wt0 + 2u * ((uint32_t)q * 64u + lane), M, xw4[slot((uint32_t)q * 64u + lane)]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2801,6 +3120,17 @@ void launch_band_scan(const BandScanDesc* d, int n, uint32_t frames, uint32_t te
         case TERMS_ADSR1: launch_band_scan_mode<TERMS_ADSR1>(d, n, frames, gx, nf, s); break;
         case TERMS_WITH_ADSR: launch_band_scan_mode<TERMS_WITH_ADSR>(d, n, frames, gx, nf, s); break;
         default: launch_band_scan_mode<TERMS_MIXED>(d, n, frames, gx, nf, s); break;
+    }
+}
+void launch_band_chain(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {
+    if (!n || !frames) return;
+    const uint32_t tile = band_scan_tile_frames(16), gx = (frames + tile - 1u) / tile;
+    switch (term_mode) {
+        case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_EDGE_FEW>), gx, kThreads, d, n, frames); break;
+        case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_ALL_EDGE>), gx, kThreads, d, n, frames); break;
+        case TERMS_ADSR1: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_ADSR1>), gx, kThreads, d, n, frames); break;
+        case TERMS_WITH_ADSR: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_WITH_ADSR>), gx, kThreads, d, n, frames); break;
+        default: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_MIXED>), gx, kThreads, d, n, frames); break;
     }
 }
 #undef TD_BATCHED
