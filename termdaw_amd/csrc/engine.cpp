@@ -1097,7 +1097,7 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
 struct ScanPlan {
     int nf = 16;
     uint32_t n_tiles = 0, K = 1;
-    uint32_t Kw = 0;          // look-back depth in wave-tiles (k_band_chain); 0: deeper than kScanMaxK -> not chainable
+    uint32_t Kw = 0;          // k_band_chain's look-back depth (= K); 0: not chainable
     size_t pw_off = 0, pk_off = 0;
 };
 static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPlan* sp) {
@@ -1115,15 +1115,7 @@ static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPla
     }
     if (!(kmax <= (double)kScanMaxK)) return false;
     sp->K = (uint32_t)kmax;
-    // the same per wave-tile (a quarter of the tile): k_band_chain hands over per wave
-    double kw = 1.0;
-    for (float gamma : {v.lgamma, v.hgamma}) {
-        if (gamma == 0.0f) continue;
-        const double q = 1.0 - (double)gamma;
-        if (!(q > 0.0)) continue;
-        kw = std::max(kw, ceil((double)g->band_depth / (-(tile / 4.0) * log(q))));
-    }
-    sp->Kw = (sp->nf == 16 && kw <= (double)kScanMaxK) ? (uint32_t)kw : 0u;
+    sp->Kw = sp->nf == 16 ? sp->K : 0u;   // (k_band_chain is built for 16 frames per lane)
     return true;
 }
 
@@ -1958,7 +1950,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 if (ik == scan_pw_off.end()) {
                                     std::vector<double> pk(2 * kScanMaxK);
                                     for (int c = 0; c < 2; ++c)
-                                        for (uint32_t j = 0; j < kScanMaxK; ++j) pk[c * kScanMaxK + j] = pow(q[c], nf * 64.0 * (double)j);
+                                        for (uint32_t j = 0; j < kScanMaxK; ++j) pk[c * kScanMaxK + j] = pow(q[c], nf * 256.0 * (double)j);
                                     ik = scan_pw_off.emplace(key, st.put(pk)).first;
                                 }
                                 sp.pk_off = ik->second;

@@ -329,8 +329,7 @@ struct BandSpecDesc {
 //   vertices -- the shape of BASELINE config 4's 252 effect stages; k_band_chain): the frames stay in registers from
 //   stage to stage, the links (`0.0 + x`, envelope gain, pan / gain: BandPost) are applied in between, and every stage
 //   has its own granules.  Nobody can recompute a predecessor's stage s > 0, so tiles are numbered by a ticket drawn at
-//   start (one only ever waits for lower tickets, whose holders are running), and waits are unbounded.  There a WAVE
-//   owns NF * 64 frames and hands over per wave: no workgroup barrier inside the stage loop.
+//   start (one only ever waits for lower tickets, whose holders are running), and waits are unbounded.
 constexpr uint32_t kScanMaxK = 128;   // look-back depth limit (tiles); slower smoothers take the exact kernels
 constexpr uint32_t kScanMaxStages = 128;   // band-pass vertices per launch (the engine cuts longer chains)
 struct BandPost {               // one link between two band-pass vertices of a chain
@@ -353,10 +352,10 @@ struct BandStageDesc {          // one band-pass vertex
     // each link first does its own sum_inputs `0.0 + x`, and so does the next band-pass vertex
     uint32_t n_post, pad;
     BandPost post[3];
-    // k_band_chain (a chain's launch; `pass` vertices only): a WAVE owns NF * 64 frames and hands over per wave
+    // k_band_chain (a chain's launch; `pass` vertices only)
     float pn[2][16];            // (1 - gamma)^(n + 1), n = 0 .. NF - 1: what an entry state still weighs after n + 1 frames
-    const double* pk;           // [2][kScanMaxK]: (1 - gamma)^(NF * 64 * j): a predecessor j wave-tiles back
-    uint32_t Kw, pad3;          // look-back depth in wave-tiles (1 .. kScanMaxK)
+    const double* pk;           // [2][kScanMaxK]: (1 - gamma)^(NF * 256 * j): the weight of the tile j + 1 tiles back
+    uint32_t Kw, pad3;          // (= K)
 };
 struct BandScanDesc {
     const InTerm* ins;          // the (first) vertex' input terms, in connect() order

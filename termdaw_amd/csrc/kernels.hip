@@ -2628,17 +2628,19 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
 // ------------------------------------------------------------------------------------------------
 // k_band_chain: a chain of `pass` band-pass vertices in ONE launch (BandScanDesc with n_stages >= 2)
 // ------------------------------------------------------------------------------------------------
-// The frames of a wave -- NF * 64 consecutive ones, NF per lane -- stay in registers from stage to stage; the links
-// between two vertices (envelope gain, pan / gain) are applied in between.  Per stage and wave:
+// The frames of a tile -- NF * 256 consecutive ones, NF per lane -- stay in registers from stage to stage; the links
+// between two vertices (envelope gain, pan / gain) are applied in between.  Per stage:
 //   z[n]   the smoothers' zero-state response inside the lane's run, the reference's own step  z + gamma (x - z)  (f32)
-//   scan   of the runs' responses over the wave (double), the wave's total published as four granules
-//   C      = sum_j a_wave^j B_(wave-tile - 1 - j) over the Kw preceding wave-tiles: lane j reads predecessor j's granules
-//          (spinning until they are tagged), multiplies by its power, the wave adds up (double)
+//   scan   of the runs' responses over the wave (double), the four waves' totals combined through LDS (barrier 1); the
+//          tile's total published as four granules by wave 0
+//   C      = sum_j a_tile^j B_(tile - 1 - j) over the K preceding tiles: lane j of wave 0 reads predecessor j's granules
+//          (spinning until they are tagged), multiplies by its power, the wave adds up (double); to LDS (barrier 2)
 //   y[n]   = z[n] + (1 - gamma)^(n + 1) c, c the lane's entry state (exact arithmetic, rounded once) -- no second
 //          dependent walk -- then the vertex' output  (l - cut, r - cut), cut = (lmul low + hmul (l - high)) / 2.
-// A `pass` vertex' right-channel smoothers reach no output (extensions.rs:685, quirk Q7) and are not run.  No workgroup
-// barrier inside the stage loop: the four waves of a workgroup only share the ticket (wave-tile = 4 * ticket + wave) and
-// the staging memory, each wave its own quarter.  Waves wait for lower wave-tiles only: same workgroup or a lower ticket.
+// A `pass` vertex' right-channel smoothers reach no output (extensions.rs:685, quirk Q7) and are not run.
+// (Tried and dropped, both bit-identical: every WAVE handing over for itself -- no barriers, but 2 816 pollers with a
+// four times deeper look-back: 0.71 ms for BASELINE config 4's 84 stages against 0.60; a wave owning two wave-tiles half
+// a timeline apart so that one's hand-off passes under the other's arithmetic -- 256 registers, two waves per SIMD: 1.22 ms.)
 template <int TMODE>
 __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M) {
     constexpr int NF = 16, NP = NF / 2;
@@ -2646,7 +2648,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     const BandScanDesc& d = descs[blockIdx.y];
     if (blockIdx.x >= d.n_tiles) return;
     __shared__ float4 xt[kThreads * (NP + 1)];          // staging, one quarter per wave: lane-major, one pad word per lane run
-    __shared__ float st_l[kScanMaxStages][5];           // wave-tile 0: every stage's carried state {y[4], first} as the launch found it
+    __shared__ float st_l[kScanMaxStages][5];           // tile 0: every stage's carried state {y[4], first} as the launch found it
+    __shared__ double wtot[kThreads / 64][2];
+    __shared__ double carry_s[2];
     __shared__ uint32_t tile_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_stages = d.n_stages;
@@ -2738,36 +2742,43 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         }
         double e0 = __shfl_up(b0, 1u, 64), e2 = __shfl_up(b2, 1u, 64);   // the wave's response up to the lane's run
         if (lane == 0u) { e0 = 0.0; e2 = 0.0; }
-        double W0 = __shfl(b0, 63, 64), W2 = __shfl(b2, 63, 64);         // ... and over the whole wave-tile
-        // state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
-        float yi0 = 0.f, yi2 = 0.f;
-        if (wt == 0u) {
-            const bool first = __float_as_uint(st_l[s][4]) != 0u;
-            const float x00 = __shfl(x[0].x, 0, 64);
-            yi0 = first ? x00 : st_l[s][0];
-            yi2 = first ? x00 : st_l[s][2];
-            if (first && lane == 0u) {   // a constant chain (gamma 0) keeps its seed for good
-                float* sf = reinterpret_cast<float*>(sp->state);
-                if (lgam == 0.0f) sf[0] = yi0;
-                if (hgam == 0.0f) sf[2] = yi2;
+        if (lane == 63u) { wtot[wave][0] = b0; wtot[wave][1] = b2; }
+        __syncthreads();   // barrier 1: the four waves' totals
+        double xw0 = 0.0, xw2 = 0.0, T0 = 0.0, T2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave / whole; a_wave^wave
+#pragma unroll
+        for (uint32_t w = 0; w < 4u; ++w) {
+            if (w == wave) { xw0 = T0; xw2 = T2; }
+            if (w < wave) { awp0 *= sp->aw[0]; awp2 *= sp->aw[1]; }
+            T0 = __builtin_fma(T0, sp->aw[0], wtot[w][0]);
+            T2 = __builtin_fma(T2, sp->aw[1], wtot[w][1]);
+        }
+        if (wave == 0u) {
+            // state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
+            double C0 = 0.0, C2 = 0.0;
+            unsigned long long* const sync = sp->sync;
+            if (tile == 0u) {
+                const bool first = __float_as_uint(st_l[s][4]) != 0u;
+                const float x00 = __shfl(x[0].x, 0, 64);
+                const float yi0 = first ? x00 : st_l[s][0], yi2 = first ? x00 : st_l[s][2];
+                if (first && lane == 0u) {   // a constant chain (gamma 0) keeps its seed for good
+                    float* sf = reinterpret_cast<float*>(sp->state);
+                    if (lgam == 0.0f) sf[0] = yi0;
+                    if (hgam == 0.0f) sf[2] = yi2;
+                }
+                C0 = (double)yi0; C2 = (double)yi2;
+                T0 = __builtin_fma(C0, sp->at[0], T0);   // (what this tile leaves behind, entered with the TRUE state)
+                T2 = __builtin_fma(C2, sp->at[1], T2);
             }
-            W0 = __builtin_fma((double)yi0, sp->aw[0], W0);   // (what this wave-tile leaves behind, entered with the TRUE state)
-            W2 = __builtin_fma((double)yi2, sp->aw[1], W2);
-        }
-        unsigned long long* const sync = sp->sync;
-        if (lane < 4u) {   // publish: granule q = chain (q >> 1) low / high word
-            const unsigned long long u = (unsigned long long)__double_as_longlong(lane < 2u ? W0 : W2);
-            granule_store(sync + (size_t)wt * 4u + lane, (lane & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
-        }
-        // ---- state entering the wave-tile
-        double C0 = (double)yi0, C2 = (double)yi2;
-        if (wt != 0u) {
-            const uint32_t n_pred = min(wt, sp->Kw);
-            C0 = 0.0; C2 = 0.0;
-            for (uint32_t base = 0; base < n_pred; base += 64u) {   // (one trip unless the look-back is deeper than 64 wave-tiles)
+            if (lane < 4u) {   // publish: granule q = chain (q >> 1) low / high word
+                const unsigned long long u = (unsigned long long)__double_as_longlong(lane < 2u ? T0 : T2);
+                granule_store(sync + (size_t)tile * 8u + lane, (lane & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
+            }
+        if (tile != 0u) {
+            const uint32_t n_pred = min(tile, sp->K);
+            for (uint32_t base = 0; base < n_pred; base += 64u) {   // (one trip unless the look-back is deeper than 64 tiles)
                 const uint32_t j = base + lane;
                 const bool mine = j < n_pred;
-                const unsigned long long* g = sync + (size_t)(wt - 1u - (mine ? j : 0u)) * 4u;
+                const unsigned long long* g = sync + (size_t)(tile - 1u - (mine ? j : 0u)) * 8u;
                 unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
                 for (;;) {
                     bool ok = true;
@@ -2789,8 +2800,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) { C0 += __shfl_xor(C0, off, 64); C2 += __shfl_xor(C2, off, 64); }
         }
-        // the lane's entry state, exact arithmetic rounded once
-        const float c0 = (float)__builtin_fma(pwl, C0, e0), c2 = (float)__builtin_fma(pwh, C2, e2);
+            if (lane == 0u) { carry_s[0] = C0; carry_s[1] = C2; }
+        }
+        __syncthreads();   // barrier 2: the state entering the tile
+        // the lane's entry state, exact arithmetic rounded once: e + a^(NF lane) (xw + a_wave^wave C)
+        const float c0 = (float)__builtin_fma(pwl, __builtin_fma(awp0, carry_s[0], xw0), e0);
+        const float c2 = (float)__builtin_fma(pwh, __builtin_fma(awp2, carry_s[1], xw2), e2);
         // ---- output (extensions.rs:682-687 with cut_mul 0, pass_mul 1), pan / gain by uniform branches
         PanGain pg;
         pg.l_amp = sp->pg.l_amp; pg.r_amp = sp->pg.r_amp; pg.gain = sp->pg.gain; pg.flags = sp->pg.flags;
