@@ -39,6 +39,9 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0      # ... 6.29 TB/s measured float4 copy
+L2_PEAK_GBS = 34500.0      # ... "L2 (per XCD)": 4 MiB per XCD, ~34.5 TB/s aggregate
+L2_GATHER_GBS = 17800.0    # ... "Indexed rows: gather": rows every workgroup shares (the XCD's L2), 16.8-18.8 TB/s chip-wide
+MALL_GATHER_GBS = 8600.0   # ... the same from a 38 MB table (Infinity Cache): 8.6 TB/s
 SIMDS = 256 * 4            # CUs x SIMDs
 CLOCK_HZ = 2.4e9           # max clock (guide); a wave64 VALU instruction occupies its SIMD-32 for 2 cycles
 
@@ -46,7 +49,7 @@ SECONDS = 60.0
 N_SRC = 64
 PROF_EVERY = 8
 PREWARM_S = 0.25           # untimed, before the W warm-up steps: steady device clocks (see time_batch)
-PROFILE_TAG = "r02"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
+PROFILE_TAG = "r03"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
 
 
 def algorithmic_bytes_per_frame(k, fused, packed):
@@ -147,6 +150,39 @@ def cpu_all_cores(seconds, workers):
                       "per-process rates; slowest render %.3f s" % (done, slowest)}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N ...` without a launcher: run the same command line under torch.distributed.run
+    (--nproc-per-node N on 127.0.0.1, a free port), print the ONE JSON line rank 0 produced, return the exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        out = out.strip()
+        if out.startswith("{") and out.endswith("}"):
+            try:
+                json.loads(out)
+                line = out
+                continue
+            except ValueError:
+                pass
+        if out:
+            sys.stderr.write(out + "\n")
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+        rc = 1
+    return rc
+
+
 def profiled(name):
     """A committed rocprofv3 summary of THIS round (profiles/<tag>_<name>.json), or None."""
     path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))
@@ -205,39 +241,78 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     return dt, ktimes, peaks, every
 
 
+def time_project(p, api, opts, reps):
+    """One project rendered in a pipelined loop (fresh-after-refresh state each time): ms per render, kernel families."""
+    sb, fb, g = p.build(api)
+    for k, v in opts.items():
+        g.set_option(k, v)
+
+    def render():
+        g.reset_normalize_vertices()
+        fb.set_time(0)
+        g.set_time(0)
+        g.render_all_async(sb, fb, p.cs, 16)
+    for _ in range(3):
+        render()
+    g.sync()
+    g.host_times(reset=True)     # (the first renders allocate buffers and arenas)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        render()
+    g.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    g.set_profiling(1)
+    for _ in range(2):
+        render()
+    g.sync()
+    kt = g.kernel_times()
+    g.set_profiling(0)
+    hosts = g.host_times()
+    kernels = sorted(((k, v[0] / 2.0, v[1] // 2, v[0] / max(v[1], 1)) for k, v in kt.items()), key=lambda r: -r[1])
+    return ms, kernels, hosts, (sb, fb, g)
+
+
+def time_config_batch(mk, api, P, opts, steps):
+    """P identical-shape projects (variants 0 .. P-1) through td_batch_*: ms per step, per project."""
+    from termdaw_amd import batch as tb
+    b, first = tb.build_shard(api, lambda pid: mk(pid), list(range(P)), opts)
+
+    def step():
+        b.rewind()
+        b.render_all_async(first.cs, 16)
+    for _ in range(2):
+        step()
+    b.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    b.sync()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    frames = first.cs * first.bl
+    del b
+    return {"projects": P, "steps": steps, "ms_per_step": round(ms, 4), "ms_per_project": round(ms / P, 4),
+            "Msamples_per_s": round(frames * P / ms / 1e3, 1)}
+
+
 def other_configs(api, workloads, ub, chain_ns):
     """BASELINE configs 1, 3, 4 (N = 1): ms per render in a pipelined loop, kernel breakdown, dominant kernel with its
-    bound.  Bounds: config 1 launch latency; k_synth f32 VALU issue (instruction count from the committed PMC pass);
-    k_band_spec the dependent-chain latency of its warm-up walk (ns per dependent VALU measured in this process)."""
+    bound.  Configs 3 and 4 hold band-pass vertices and are reported in BOTH band modes -- "exact" (the default and the
+    parity mode: bit-identical to the reference's serial recurrence) and "scan" (engine option band_mode 1, tolerance
+    class <= 1e-6 RMS) -- each entry says which; each also as a batch of 8 and 32 such projects through td_batch_*.
+    Bounds: config 1 launch latency; k_synth / k_band_scan f32 VALU issue (instruction count from the committed PMC
+    pass); k_band_spec the dependent-chain latency of its warm-up walk (ns per dependent VALU measured in this process)."""
     out = []
     valu = profiled("valu") or {}
-    for name, mk, reps in (("config1", workloads.config1, 50), ("config3", workloads.config3, 10), ("config4", workloads.config4, 4)):
+    issue_ns = float(ub.td_ubench_fma_issue_ns(SIMDS // 4)) if ub is not None else -1.0
+    plan = (("config1", workloads.config1, None, 50, ()),
+            ("config3", workloads.config3, "exact", 10, (8, 32)), ("config3", workloads.config3, "scan", 10, (8, 32)),
+            ("config4", workloads.config4, "exact", 4, (8, 32)), ("config4", workloads.config4, "scan", 10, (8, 32)))
+    for name, mk, mode, reps, batches in plan:
         p = mk()
-        sb, fb, g = p.build(api)
         frames = p.cs * p.bl
-
-        def render():
-            g.reset_normalize_vertices()
-            fb.set_time(0)
-            g.set_time(0)
-            g.render_all_async(sb, fb, p.cs, 16)
-        for _ in range(2):
-            render()
-        g.sync()
-        g.host_times(reset=True)     # (the first render allocates buffers and arenas)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            render()
-        g.sync()
-        ms = (time.perf_counter() - t0) / reps * 1e3
-        g.set_profiling(1)
-        for _ in range(2):
-            render()
-        g.sync()
-        kt = g.kernel_times()
-        g.set_profiling(0)
-        hosts = g.host_times()
-        kernels = sorted(((k, v[0] / 2.0, v[1] // 2, v[0] / max(v[1], 1)) for k, v in kt.items()), key=lambda r: -r[1])
+        opts = {} if mode is None else {"band_mode": 1 if mode == "scan" else 0}
+        ms, kernels, hosts, built = time_project(p, api, opts, reps)
+        g = built[2]
         dom = kernels[0]
         launches = sum(k[2] for k in kernels)
         entry = {"config": name, "frames": frames, "vertices": sum(len(v) for k, v in p.calls.items() if k.startswith("add_")),
@@ -246,22 +321,28 @@ def other_configs(api, workloads, ub, chain_ns):
                  "host_ms_per_render": {k: round(v / max(hosts["chunks"], 1), 4) for k, v in hosts.items() if k != "chunks"},
                  "kernels": [{"kernel": k[0], "ms_per_render": round(k[1], 4), "launches": int(k[2]), "avg_ms": round(k[3], 5)} for k in kernels],
                  "dominant": dom[0]}
+        if mode is not None:
+            entry["band_mode"] = mode
+            entry["band_mode_note"] = ("exact: speculative-segment kernels, bit-identical to the reference's serial recurrence (default, parity mode)"
+                                       if mode == "exact" else
+                                       "scan: blocked affine scan (k_band_scan / k_band_chain), tolerance class: <= 1e-6 RMS and +-1 LSB against the "
+                                       "oracle (tests/test_gpu_band_scan.py; measured RMS per chain depth: profiles/%s_scan_rms.txt)" % PROFILE_TAG)
+        vkey = name if mode in (None, "exact") else name + "_scan"
+        insts = (valu.get(vkey, {}).get(dom[0]) or {}).get("SQ_INSTS_VALU")
         if name == "config1":
             floor = launches * 1.45e-3    # MI355X_MICROARCH.md price list, row "boundary": dependent kernel boundary 1.45 us
             entry["bound"] = {"kind": "launch latency", "floor_ms": round(floor, 5), "frac": round(floor / ms, 4),
                               "note": "%d dependent launches x 1.45 us (guide: same-stream kernel boundary); the kernels themselves move "
                                       "%.1f MB" % (launches, frames * (2 * 4 + 8 + 20) / 1e6)}
-        elif dom[0] == "k_synth":
-            insts = (valu.get("config3", {}).get("k_synth") or {}).get("SQ_INSTS_VALU")
-            issue_ns = float(ub.td_ubench_fma_issue_ns(SIMDS // 4)) if ub is not None else -1.0
+        elif dom[0] in ("k_synth", "k_band_scan"):
             if insts and issue_ns > 0:
                 floor = insts * issue_ns / SIMDS * 1e-6
                 entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4),
                                   "SQ_INSTS_VALU_profiled": insts, "profile": "profiles/%s_valu.json" % PROFILE_TAG,
                                   "ns_per_fma_per_simd_measured": round(issue_ns, 3),
-                                  "note": "wave-level VALU instructions (PMC, committed profile) x the issue time of the FASTEST class (v_fma_f32, "
-                                          "8 waves per SIMD, measured in this process) / 1024 SIMDs; compares, selects, min / max, conversions "
-                                          "and packed ops issue ~1.7x slower (profiles/r02_issue_rate.txt), so the true floor is higher"}
+                                  "note": "wave-level VALU instructions per launch (PMC, committed profile) x the issue time of the FASTEST class "
+                                          "(v_fma_f32, 8 waves per SIMD, measured in this process) / 1024 SIMDs; compares, selects, min / max, "
+                                          "conversions, packed and f64 ops issue slower, so the true floor is higher"}
             else:
                 entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": None, "frac": None, "note": "no committed PMC pass for this round"}
         elif dom[0] == "k_band_spec" and chain_ns and chain_ns > 0:
@@ -277,9 +358,41 @@ def other_configs(api, workloads, ub, chain_ns):
                               "note": "medium warm-up (30/gamma from the block-response guess, 20 Hz stage) + one 256-frame segment, 3 dependent "
                                       "VALU per step, one wave alone on its SIMD (tools/ubench/ceilings.hip td_ubench_valu_chain_ns); the "
                                       "rest of the launch is the segment's output phase and the first workgroup's longer walk"}
+        del built, g
+        if batches:
+            entry["batch"] = []
+            for P in batches:
+                try:
+                    bsteps = 3 if (name == "config4" and mode == "exact") else 6
+                    e = time_config_batch(lambda pid: mk(variant=pid), api, P, opts, bsteps)
+                    e["per_project_over_single"] = round(e["ms_per_project"] / ms, 4)
+                    entry["batch"].append(e)
+                except Exception as ex:   # noqa: BLE001
+                    entry["batch"].append({"projects": P, "error": str(ex)})
         out.append(entry)
-        del sb, fb, g
     return out
+
+
+def edge_buffer_mode(api, workloads, seconds, frames, copy_gbs, reps=5):
+    """SURVEY 8(d)'s sum+normalize check on the SAME project with the edge-buffer model (engine option fuse_sources 0: one
+    HBM buffer per source vertex, the Normalize reads 64 of them): k_sum + k_scale move 8k+8 + 8+8 = 536 B per frame
+    (+ the 4 B PCM), which IS HBM traffic there (L2 hit 2 %, profiles/*_pmc_summary.json "nofuse")."""
+    p = workloads.config2(seconds=seconds, n_src=N_SRC)
+    ms, kernels, _, built = time_project(p, api, {"fuse_sources": 0, "output_f32": 1}, reps)
+    kd = {k[0]: k[3] for k in kernels}
+    del built
+    if "k_sum" not in kd or "k_scale" not in kd:
+        return None
+    nbytes = 536 * frames
+    gbs = nbytes / ((kd["k_sum"] + kd["k_scale"]) * 1e-3) / 1e9
+    return {"k_sum_ms": round(kd["k_sum"], 5), "k_scale_ms": round(kd["k_scale"], 5), "k_sample_loop_ms": round(kd.get("k_sample_loop", 0.0), 5),
+            "ms_per_render": round(ms, 4), "bytes": int(nbytes), "bytes_per_frame": 536, "GB/s": round(gbs, 1),
+            "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frac_measured_copy": round(gbs / copy_gbs, 4),
+            "measured_copy_GBs": round(copy_gbs, 1), "renders": reps,
+            "k_sum_alone_GBs": round(520 * frames / (kd["k_sum"] * 1e-3) / 1e9, 1),
+            "note": "run after the timed region, outside it: the headline project rebuilt with engine options fuse_sources 0 "
+                    "(SURVEY 8(d)'s edge-buffer model) and output_f32 1 (pass B writes the f32 frames back, as the 8+8 of the model "
+                    "says); HIP-event time per launch, %d renders; north_star asks >= 40 %% of the measured copy rate here" % reps}
 
 
 def main():
@@ -298,6 +411,11 @@ def main():
     if args.cpu_worker is not None:
         cpu_worker(args.cpu_worker, args.seconds)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Invoked plainly with --gpus N: start the N ranks ourselves -- fresh child processes through torch.distributed.run,
+        # BEFORE anything in this process touches HIP / torch.cuda (a process that has initialised the GPU must never exec
+        # or fork GPU work) -- relay rank 0's JSON line and propagate the exit code.
+        sys.exit(launch_ranks(args.gpus))
 
     # Everything any library writes to stdout while the bench runs (RCCL prints a version banner through the C runtime)
     # goes to stderr: stdout carries the ONE JSON line and nothing else.
@@ -309,8 +427,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch   # (before the engine: both then share ONE HIP runtime in this process)
     import torch.distributed as dist
@@ -492,6 +609,21 @@ def main():
             vp = ((profiled("valu") or {}).get("config2") or {}).get(dom["kernel"])
             if vp:
                 roofline["valu_profiled"] = dict(vp, profile="profiles/%s_valu.json" % PROFILE_TAG)
+            if fused and packed and dom["kernel"] == "k_sum":
+                # two hardware-denominated readings beside the measured ceiling (guide figures only, no ubench):
+                #  frac_of_l2_peak: the gathered + written bytes against the aggregate L2 bandwidth;
+                #  l2_mall_split: the bytes split by the PROFILED L2 hit rate -- hits at the guide's L2 gather rate, the rest at
+                #  its Infinity-Cache gather rate, one after the other -- as a time floor for this launch
+                gathered = dom["algorithmic_bytes_per_launch"]
+                roofline["frac_of_l2_peak"] = round(dom["achieved"] / L2_PEAK_GBS, 4)
+                roofline["l2_peak_GBs"] = L2_PEAK_GBS
+                hit = ((dom.get("traffic_profiled") or {}).get("l2_hit_rate"))
+                if hit is not None:
+                    floor_ms = (gathered * hit / (L2_GATHER_GBS * 1e9) + gathered * (1.0 - hit) / (MALL_GATHER_GBS * 1e9)) * 1e3
+                    roofline["l2_mall_split"] = {"l2_hit_rate_profiled": hit, "l2_gather_GBs": L2_GATHER_GBS, "mall_gather_GBs": MALL_GATHER_GBS,
+                                                 "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / dom["avg_ms"], 4),
+                                                 "note": "bytes x hit rate / 17.8 TB/s + bytes x (1 - hit rate) / 8.6 TB/s (MI355X_MICROARCH.md, "
+                                                         "'Indexed rows: gather'), hit rate from profiles/%s_pmc_summary.json" % PROFILE_TAG}
             if fused and dom["kernel"] == "k_sum":
                 roofline["survey_model"] = {
                     "bytes_per_frame": survey_abf["k_sum"],
@@ -503,6 +635,7 @@ def main():
             "value": round(value, 2),
             "unit": "Msamples/s",
             "n_gpus": world,
+            "n_ranks_seen": dist.get_world_size() if use_dist else 1,   # what the process group itself reports
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -589,6 +722,10 @@ def main():
             out["pcie_inclusive"] = {"ms_per_render": round(ts[2] * 1e3, 4), "Msamples_per_s": round(frames / ts[2] / 1e6, 1),
                                      "note": "render + D2H of the PCM into pageable host memory; not part of `value`"}
             chain_ns = float(ub.td_ubench_valu_chain_ns()) if ub is not None else None
+            try:
+                out["edge_buffer_mode"] = edge_buffer_mode(api, workloads, args.seconds, frames, copy_gbs)
+            except Exception as e:   # noqa: BLE001
+                out["edge_buffer_mode"] = {"error": str(e)}
             try:
                 out["configs"] = other_configs(api, workloads, ub, chain_ns)
             except Exception as e:   # noqa: BLE001

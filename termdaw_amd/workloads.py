@@ -396,8 +396,10 @@ NOTE_ADSR = [0.01, 0.1, 0.8, 5.0, 0.2, 0.5]     # project.lua:36
 STD_ADSR = [0.01, 1.0, 1.0, 1.0, 1.0, 0.4]      # project.lua:37
 
 
-def config3(seconds=60.0, voices=32):
-    """synth (32 simultaneous voices, 3 oscillators) -> adsr -> bandpass -> normalize."""
+def config3(seconds=60.0, voices=32, variant=0):
+    """synth (32 simultaneous voices, 3 oscillators) -> adsr -> bandpass -> normalize.
+    variant: the projects of a batch differ like config 5's do by their seeds -- here the chord is transposed by
+    variant % 7 semitones and the velocities scaled (same shape, same launches)."""
     p = ProjectScript(48000, 1024)
     p.set_length(seconds)
     p.set_render_samplerate(48000)
@@ -406,9 +408,9 @@ def config3(seconds=60.0, voices=32):
     t = 0.0
     while t < seconds:
         for j in range(voices):
-            ev.append((t, 36.0 + j, 0.25 + 0.02 * j))
+            ev.append((t, 36.0 + j + variant % 7, (0.25 + 0.02 * j) * (1.0 - 0.03 * (variant % 5))))
         for j in range(voices):
-            ev.append((t + 1.5, 36.0 + j, 0.0))
+            ev.append((t + 1.5, 36.0 + j + variant % 7, 0.0))
         t += 2.0
     ev.sort(key=lambda e: e[0])
     p.event_files["notes"] = np.array(ev, dtype=np.float32)
@@ -514,18 +516,18 @@ def synth_project(seconds=3.0, bl=1024, voices=5):
     return p
 
 
-def config4(seconds=60.0, depth=252):
+def config4(seconds=60.0, depth=252, variant=0):
     """Deep chain (BASELINE config 4): wavetable synth (sampsyn, 64 x 2048 table, seed 7) + sample_lerp over a
     44.1 kHz asset (hits every 0.25 s, lerp_len 40) -> sum -> `depth` single-input vertices alternating
     sum(gain 1.41, angle +-1) / bandpass(20 Hz, 18 kHz) / adsr -> normalize = depth + 4 vertices.
     The wavetable oscillator and the 44.1 k -> 48 k resample sit on un-vendored crates (sampsyn, rubato) in
     the reference; here they are this engine's own documented stand-ins (parity unpinned vs the reference,
-    bit-exact vs the oracle)."""
+    bit-exact vs the oracle).  variant: asset seeds 7 + variant (the projects of a batch, like config 5's seed offsets)."""
     p = ProjectScript(48000, 1024)
     p.set_length(seconds)
-    p.assets["kick"] = Asset(kick_int16(7, 18375, sr=44100), sr=44100)
+    p.assets["kick"] = Asset(kick_int16(7 + variant, 18375, sr=44100), sr=44100)
     p.load_sample("kick", "kick", "")
-    p.resources["table"] = wavetable_bytes(7)
+    p.resources["table"] = wavetable_bytes(7 + variant)
     p.load_resource("table", "table")
     hits = [(0.25 * i, 36.0, 0.9) for i in range(int(seconds / 0.25))]
     p.event_files["hits"] = np.array(hits, dtype=np.float32)

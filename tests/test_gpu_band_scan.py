@@ -145,3 +145,75 @@ def test_scan_mode_leaves_bit_exact_kinds_alone(gpu_api, oracle):
     has_band = len(p.calls.get("add_bandpass", [])) > 0
     got = p.render(gpu_api, built=_scan_build(p, gpu_api))
     (assert_close if has_band else assert_bit_exact)(got, p.render(oracle))
+
+
+def _chain_project(shapes, seconds=2.0, lo=60.0, hi=9000.0, pass_=True):
+    """noise loop -> band-pass vertices linked as `shapes` says: "" (direct), "s" (gain / pan stage), "a" (Adsr vertex),
+    "sa", "as", "sas" -- single-input, single-consumer links, what k_band_chain runs in one launch."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(seconds)
+    p.assets["n"] = W.Asset(W.noise_int16(9, 50021))
+    p.load_sample("n", "n", "")
+    p.event_files["g"] = np.array([(0.21 * i + 0.03, 60.0, 0.8) for i in range(int(seconds / 0.21) + 1)], np.float32)
+    p.load_midi_floww("g", "g")
+    p.add_sampleloop("src", 0.7, 10.0, "n")
+    p.add_bandpass("b0", 1.0, 0.0, 1.0, lo, hi, pass_)
+    p.connect("src", "b0")
+    prev = "b0"
+    for i, shape in enumerate(shapes):
+        for j, ch in enumerate(shape):
+            name = "l%d_%d" % (i, j)
+            if ch == "s":
+                p.add_sum(name, 1.3, -12.0 if i % 2 else 7.0)
+            else:
+                p.add_adsr(name, 1.0, 0.0, 0.6, "g", False, True, -1, [0.01, 0.05, 0.7, 0.05, 0.3, 0.02])
+            p.connect(prev, name)
+            prev = name
+        name = "b%d" % (i + 1)
+        p.add_bandpass(name, 1.1 if i % 3 == 0 else 1.0, 3.0 if i % 3 == 1 else 0.0, 1.0, lo * (1 + i % 4), hi, pass_)
+        p.connect(prev, name)
+        prev = name
+    p.add_normalize("out", 1.0, 0.0)
+    p.connect(prev, "out")
+    p.set_output("out")
+    return p
+
+
+@pytest.mark.parametrize("chunk", [0, 7000])
+def test_chain_link_shapes(gpu_api, oracle, chunk):
+    """Every link shape between two band-pass vertices of a chain, fresh, chunked (state carried per stage) and rendered
+    twice; the same project with chains switched off (one launch per vertex) agrees with it to rounding."""
+    p = _chain_project(["", "s", "a", "sa", "as", "sas", "", "a"])
+    gb, ob = _scan_build(p, gpu_api), p.build(oracle)
+    if chunk:
+        gb[2].set_option("max_chunk_frames", chunk)
+    for _ in range(2):
+        got, ref = p.render(gpu_api, built=gb), p.render(oracle, built=ob)
+        assert_close(got, ref)
+    single = p.render(gpu_api, built=_scan_build(p, gpu_api, band_chain=0))
+    assert_close(single, p.render(oracle))
+    assert _rms(single[1], p.render(gpu_api, built=_scan_build(p, gpu_api))[1]) <= 2e-7
+
+
+def test_chain_longer_than_one_launch(gpu_api, oracle):
+    """140 band-pass vertices in a row: the chain is cut at kScanMaxStages (128), the cut vertex is materialised."""
+    p = _chain_project([""] * 139, seconds=0.5, lo=300.0, hi=12000.0)
+    assert_close(p.render(gpu_api, built=_scan_build(p, gpu_api)), p.render(oracle))
+
+
+def test_cut_vertex_in_a_chain_is_its_own_launch(gpu_api, oracle):
+    """`pass` false vertices (whose right output needs the right-channel smoothers) do not join chains."""
+    p = _chain_project(["s", "a", ""], pass_=False)
+    assert_close(p.render(gpu_api, built=_scan_build(p, gpu_api)), p.render(oracle))
+
+
+def test_chain_after_set_time_reseeds_every_stage(gpu_api, oracle):
+    """set_time raises every band-pass vertex' `first` flag (extensions.rs:196-204): the next render seeds each stage's
+    smoothers from its own first input frame (extensions.rs:664-670), in a chain too."""
+    p = _chain_project(["s", "a", "sa"], seconds=1.0)
+    gb, ob = _scan_build(p, gpu_api), p.build(oracle)
+    assert_close(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
+    for b in (gb, ob):
+        b[1].set_time(0)
+        b[2].set_time(0)
+    assert_close(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
