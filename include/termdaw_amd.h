@@ -177,6 +177,14 @@ size_t td_graph_device_bytes(const td_graph* g);
  * one single-input Sum -- is a Sum / Normalize / band-pass is evaluated inside that consumer's summing kernel, as one
  * of its input terms: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
+ * "band_mode" 0|1 (default 0 = exact: band_pass_gen, extensions.rs:654-689, bit-identical to the reference's serial
+ * recurrence -- the parity mode.  1 = scan: the same filter as a blocked affine scan, TOLERANCE class: <= 1e-6 RMS on
+ * the f32 output and +-1 LSB on the PCM against the exact mode (measured 6.4e-8 RMS through 84 band-pass vertices in a
+ * row); one launch per band-pass vertex, and ONE launch for a whole chain of `pass` band-pass vertices linked by
+ * single-input Sum / Adsr vertices.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel
+ * smoothers never reach an output (extensions.rs:685) and are not run in this mode);
+ * "band_chain" 0|1 (default 1; 0: scan mode launches every band-pass vertex on its own) / "band_scan_nf" 8|16 (frames
+ * per lane of a single vertex' launch) / "band_scan_debug" n (tests: bit 0 forces the bounded-wait fallback);
  * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
  * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed
  * only, the bit-wise check and repair keep every result exact);
@@ -221,7 +229,9 @@ size_t td_batch_size(const td_batch* b);
  * right after State::refresh, from which a fresh render starts. */
 void td_batch_rewind(td_batch* b);
 /* td_graph_render_all[_async] for every project (each project's PCM / f32 stays readable through its own
- * td_graph_read_pcm / td_graph_output_pcm_device).  Returns frames per project, 0 on failure. */
+ * td_graph_read_pcm / td_graph_output_pcm_device).  Returns n_blocks x the FIRST project's block length (projects of a
+ * batch may differ in block length: project i rendered n_blocks x its own), 0 on failure.  On failure the FlowwBank
+ * cursors of the projects compiled in the failing step are back where that step found them. */
 size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits);
 size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits);
 int td_batch_sync(td_batch* b);

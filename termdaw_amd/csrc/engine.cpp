@@ -165,6 +165,9 @@ void td_samplebank::release(void* p) {
             if ((unsigned char*)p >= s.base && (unsigned char*)p < s.base + s.cap) {
                 if (s.live) --s.live;
                 if (s.live == 0) {               // nothing left in it: reuse from the start, or give it back
+                    // (kernels queued by td_graph_render_all_async / td_batch_render_all_async on the engines' non-blocking
+                    // streams may still gather from this memory: the per-sample hipFree of the old path synchronised implicitly)
+                    (void)hipDeviceSynchronize();
                     if (i + 1 == v.size()) s.used = 0;
                     else { (void)hipFree(s.base); v.erase(v.begin() + (long)i); }
                 }
@@ -870,11 +873,11 @@ static void build_plan(td_graph* g) {
 
 static int ensure_graph_device(td_graph* g) {
     if (!ensure_device(g->device)) return 0;
+    if (!g->stream) {   // (also after a td_batch_free whose stream creation failed: made on next use)
+        TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        g->owns_stream = true;
+    }
     if (!g->ev_fork) {
-        if (!g->stream) {
-            TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
-            g->owns_stream = true;
-        }
         TD_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         TD_HIP(hipMalloc(&g->d_scalar, 256));
     }
@@ -2182,6 +2185,19 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         ar.graph_key.clear();
         TD_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
     }
+    // An error return between BeginCapture and EndCapture would leave the stream capturing (every later call on it then
+    // fails): this guard ends the capture and drops the partial graph on any exit that has not completed it.
+    struct CaptureGuard {
+        hipStream_t s;
+        bool active;
+        ~CaptureGuard() {
+            if (!active) return;
+            hipGraph_t partial = nullptr;
+            (void)hipStreamEndCapture(s, &partial);
+            if (partial) (void)hipGraphDestroy(partial);
+            (void)hipGetLastError();
+        }
+    } capture_guard{stream, want_graph};
     for (auto& z : cb.zero) TD_HIP(hipMemsetAsync(ar.d + upload + z.off, 0, z.bytes, stream));
     if (cb.sync_bytes) TD_HIP(hipMemsetAsync(ar.d + sync_at, 0, cb.sync_bytes, stream));
 
@@ -2242,6 +2258,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     }
     if (want_graph) {
         hipGraph_t graph = nullptr;
+        capture_guard.active = false;
         TD_HIP(hipStreamEndCapture(stream, &graph));
         hipGraphExec_t exec = nullptr;
         const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -2416,12 +2433,21 @@ static int batch_render_chunks(td_batch* b, size_t n_blocks, bool is_scan, int b
         const auto t0 = std::chrono::steady_clock::now();
         cb.clear();
         bool any = false;
+        // (a failing project must not leave the cursors of the projects compiled before it in this step half-advanced)
+        std::vector<std::pair<size_t, std::vector<size_t>>> fb_before(P);
         for (size_t i = 0; i < P; ++i) {
             nb[i] = std::min(rp[i].chunk_blocks, n_blocks - done[i]);
             if (!nb[i]) continue;
             any = true;
-            if (!compile_next_chunk(b->graphs[i], b->sbs[i], b->fbs[i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb))
+            fb_before[i] = {b->fbs[i]->frame, b->fbs[i]->start_indices};
+            if (!compile_next_chunk(b->graphs[i], b->sbs[i], b->fbs[i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
+                for (size_t q = 0; q <= i; ++q)
+                    if (nb[q]) {
+                        b->fbs[q]->frame = fb_before[q].first;
+                        b->fbs[q]->start_indices = fb_before[q].second;
+                    }
                 return 0;
+            }
         }
         if (!any) break;
         const uint8_t* scratch_base = nullptr;
@@ -2603,8 +2629,11 @@ void td_graph_free(td_graph* g) {
                 break;
             }
     }
-    if (g->stream && hipSetDevice(g->device) == hipSuccess) {
-        (void)hipStreamSynchronize(g->stream);
+    const bool has_device_state = g->stream || !g->pool.empty() || !g->wavetables.empty() || g->dstate || g->arena.d || g->d_pcm ||
+                                  g->d_out_f32 || g->d_resampled || g->d_scalar || g->ev_fork;
+    if (has_device_state && hipSetDevice(g->device) == hipSuccess) {
+        if (g->stream) (void)hipStreamSynchronize(g->stream);
+        else (void)hipDeviceSynchronize();   // (a graph whose stream could not be re-made after td_batch_free)
         for (float2* p : g->pool) (void)hipFree(p);
         for (float* p : g->wavetables) (void)hipFree(p);
         free_tables(g);
@@ -2621,7 +2650,7 @@ void td_graph_free(td_graph* g) {
                 (void)hipEventDestroy(g->ev_join[a]);
                 (void)hipStreamDestroy(g->aux[a]);
             }
-        if (g->owns_stream) (void)hipStreamDestroy(g->stream);
+        if (g->owns_stream && g->stream) (void)hipStreamDestroy(g->stream);
     }
     delete g;
 }
@@ -3108,6 +3137,8 @@ void td_batch_free(td_batch* b) {
         g->batch = nullptr;
         g->stream = nullptr;
         g->owns_stream = true;
+        g->band_stats_base = nullptr;   // (it pointed into the batch arena's scratch, freed below)
+        g->band_stats_off.clear();
         if (dev_ok && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) != hipSuccess) g->stream = nullptr;
     }
     if (dev_ok) {

@@ -2200,9 +2200,10 @@ __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __re
     const BandSpecDesc& d = descs[blockIdx.y];
     if (d.stats[3] == 0u) return;   // (no job: the usual case -- which is why the grid is a few hundred workgroups, not one per tile)
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
-    for (uint32_t tile0 = blockIdx.x * kTileFrames; tile0 < M; tile0 += gridDim.x * kTileFrames)
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * kTileFrames; tile0 < M; tile0 += (uint64_t)gridDim.x * kTileFrames)   // (64-bit: M may sit near 2^32)
         for (uint32_t f = threadIdx.x; f < (uint32_t)kTileFrames; f += kThreads) {
-            const uint32_t m = tile0 + f;
+            if (tile0 + f >= M) break;
+            const uint32_t m = (uint32_t)tile0 + f;
             if (m >= M) break;
             const uint32_t j = d.seg_job[m / d.S];
             if (j == kNoJob) continue;

@@ -92,3 +92,20 @@ def test_resampler_is_block_streamable(gpu_api):
             k = np.argmax(np.abs(l))
             scale = full_l[k] / l[k]
             assert np.allclose(full_l[:m], l * scale, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("file_sr", [44100, 96000, 32000])
+def test_resampler_has_unity_dc_gain(gpu_api, oracle, file_sr):
+    """rubato's SincFixedIn normalises its sinc table to unity gain and scales the cut-off by the ratio when it
+    down-samples.  The stand-in does the second explicitly (fc = 0.95 * min(1, to / from)); its taps fc sinc(fc d) bh(u)^2
+    already sum to 1 within 1e-11 per phase in double (tests/test_oracle_kats.py::test_sinc_table_sums_to_one), so a
+    constant comes out as the same constant once the 128-frame delay line is full -- within 1e-6, on both sides."""
+    pcm = np.full((6000, 2), 1234, np.float32)
+    pcm[:, 1] = -777
+    for be in (gpu_api, oracle):
+        sb = be.SampleBank(48000)
+        sb.add_decoded("s", pcm.reshape(-1), 2, file_sr, 16, "")   # (the load peak-normalises each channel pair: 1.0 / -0.6297)
+        l, r = sb.get_sample(0)
+        lo = int(np.ceil(256 * 48000 / file_sr)) + 2               # the delay line (sinc_len input frames) is full from here on
+        assert np.abs(l[lo:-2] - np.float32(1.0)).max() <= 1e-6
+        assert np.abs(r[lo:-2] - np.float32(-777.0) * (np.float32(1.0) / np.float32(1234.0))).max() <= 1e-6

@@ -250,3 +250,25 @@ def test_graph_rules(oracle):   # graph.rs:58-174
     g3.add_sampleloop("src", 1, 0, 0)
     g3.set_output("src")
     assert g3.check_graph()                         # a source may be the output
+
+
+def test_sinc_table_sums_to_one():
+    """The stand-in resampler's taps T[p][k] = fc sinc(fc d) bh(u)^2 (the parameter set of sample.rs:152-158)
+    sum to 1 per phase within 1e-9 in double -- the unity DC gain rubato gets by normalising its table -- for up-sampling
+    (fc = 0.95) and down-sampling (fc = 0.95 * to / from) alike; and a constant input comes out as the constant."""
+    for frm, to in ((44100, 48000), (48000, 44100), (96000, 48000), (22050, 48000)):
+        fc = 0.95 * min(1.0, to / frm)
+        for p in (0, 1, 100, 255, 256):
+            k = np.arange(256)
+            d = k - 127.0 - p / 256.0
+            z = fc * d
+            sinc = np.where(z == 0, 1.0, np.sin(np.pi * z) / (np.pi * np.where(z == 0, 1.0, z)))
+            u = (d + 128.0) / 256.0
+            bh = 0.35875 - 0.48829 * np.cos(2 * np.pi * u) + 0.14128 * np.cos(4 * np.pi * u) - 0.01168 * np.cos(6 * np.pi * u)
+            assert abs(float((fc * sinc * bh * bh).sum()) - 1.0) < 1e-9
+    from oracle import binding as oracle
+    sb = oracle.SampleBank(48000)
+    sb.add_decoded("s", np.full(2 * 4000, 500.0, np.float32), 2, 44100, 16, "")
+    l, r = sb.get_sample(0)
+    lo = int(np.ceil(256 * 48000 / 44100)) + 2
+    assert np.abs(l[lo:-2] - 1.0).max() <= 1e-6 and np.abs(r[lo:-2] - 1.0).max() <= 1e-6

@@ -9,6 +9,7 @@ def family(s):   # "void tdk::k_sum16w<4, true>(args)" -> ("k_sum", "tdk::k_sum1
     full = re.sub(r"^void ", "", s.split("(")[0]).strip()
     base = re.sub(r"<.*$", "", full).replace("tdk::", "")
     if base.startswith("k_sum"): base = "k_sum"
+    if base == "k_band_chain": base = "k_band_scan"   # (the engine's launch family: a chain is a k_band_scan launch with several stages)
     return base, full
 
 def newest(pattern):
@@ -68,7 +69,8 @@ if __name__ == "__main__":
     json.dump(res, open("profiles/%s_pmc_summary.json" % tag, "w"), indent=1, sort_keys=True)
     valu = {}
     for cfg, d in (("config2", "gpurun_out/pmc_%s_fused_VALU" % tag), ("config2_nofuse", "gpurun_out/pmc_%s_nofuse_VALU" % tag),
-                   ("config3", "gpurun_out/pmc_%s_c3_VALU" % tag), ("config4", "gpurun_out/pmc_%s_c4_VALU" % tag)):
+                   ("config3", "gpurun_out/pmc_%s_c3_VALU" % tag), ("config4", "gpurun_out/pmc_%s_c4_VALU" % tag),
+                   ("config3_scan", "gpurun_out/pmc_%s_c3scan_VALU" % tag), ("config4_scan", "gpurun_out/pmc_%s_c4scan_VALU" % tag)):
         rows = {}
         for (fam, full), v in counters(d).items():
             row = {cn: sum(vals) / len(vals) for cn, vals in v.items()}

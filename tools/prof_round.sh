@@ -3,7 +3,7 @@
 #   gpurun_out/pmc_<tag>_<mode>_*/  separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | VALU counters
 #   gpurun_out/pmc_<tag>_c3_VALU, _c4_VALU   the same VALU pass for configs 3 and 4 (tools/time_configs.py)
 # then tools/pmc_summary.py <tag> writes profiles/<tag>_pmc_summary.json and profiles/<tag>_valu.json.
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=/root/repo
 cd /tmp && export TMPDIR=/tmp
 B="--no-cpu-baseline --no-extras"
@@ -22,5 +22,12 @@ for c in c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_$c -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_$c.log 2>&1
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
 done
+# the same two configs with the tolerance-class band-pass (engine option band_mode 1: k_band_scan / k_band_chain)
+export TD_OPTS=band_mode=1
+for c in c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}scan -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}scan.log 2>&1
+  rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}scan_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
+done
+unset TD_OPTS
 cd $R
 python tools/pmc_summary.py $TAG

@@ -66,6 +66,30 @@ KERNEL64(k_pkmul, OP2("v_pk_mul_f32"))
 KERNEL64(k_pkadd, OP2("v_pk_add_f32"))
 KERNEL64(k_pkmov, "\n v_pk_mov_b32 %0, %0, %8\n v_pk_mov_b32 %1, %1, %8\n v_pk_mov_b32 %2, %2, %8\n v_pk_mov_b32 %3, %3, %8\n v_pk_mov_b32 %4, %4, %8\n v_pk_mov_b32 %5, %5, %8\n v_pk_mov_b32 %6, %6, %8\n v_pk_mov_b32 %7, %7, %8")
 
+// Round 3: int16 -> f32 of a packed (l | r << 16) word, the two forms side by side (ns per SEQUENCE, not per instruction):
+//  k_cvt16_sdwa   what sum_terms16w does: v_cvt_f32_i32_sdwa sext(WORD_0) + sext(WORD_1)                        (2 instructions)
+//  k_cvt16_magic  the exact magic-number form: w ^ 0x80008000; (t & 0xffff) | 0x4B400000; 0x4B400000 | t.WORD_1 (an SDWA or);
+//                 then - 12615680.0f on each half                                                              (5 instructions)
+#define SEQ8(a, b) a("%0") b("%0") a("%1") b("%1") a("%2") b("%2") a("%3") b("%3") a("%4") b("%4") a("%5") b("%5") a("%6") b("%6") a("%7") b("%7")
+#define CVT_LO(r) "\n v_cvt_f32_i32_sdwa %10, sext(" r ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0"
+#define CVT_HI(r) "\n v_cvt_f32_i32_sdwa " r ", sext(" r ") dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1"
+#define MAG_A(r) "\n v_xor_b32 " r ", 0x80008000, " r "\n v_and_or_b32 %10, " r ", %11, %12\n v_or_b32_sdwa " r ", %12, " r " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+#define MAG_B(r) "\n v_sub_f32 %10, %10, %13\n v_sub_f32 " r ", " r ", %13"
+#define KERNEL_CVT(name, A, B)                                                                                                    \
+    __global__ __launch_bounds__(256) void name(float* out, float g, int n) {                                                     \
+        float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7, t = 0;  \
+        const unsigned long long mask = 0x5555555555555555ull * (unsigned)n;                                                      \
+        const unsigned lo16 = 0xffffu, magic = 0x4B400000u;                                                                       \
+        const float c = 12615680.0f;                                                                                              \
+        _Pragma("unroll 1") for (int i = 0; i < n; ++i) {                                                                         \
+            REP8(asm volatile(SEQ8(A, B) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)        \
+                              : "v"(g), "s"(mask), "v"(t), "v"(lo16), "v"(magic), "v"(c) : "vcc");)                               \
+        }                                                                                                                         \
+        out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + t;                                          \
+    }
+KERNEL_CVT(k_cvt16_sdwa, CVT_LO, CVT_HI)
+KERNEL_CVT(k_cvt16_magic, MAG_A, MAG_B)
+
 typedef void (*kern_t)(float*, float, int);
 static void run(const char* name, kern_t k, float* d) {
     printf("%-16s", name);
@@ -88,5 +112,7 @@ int main() {
     R(k_fma); R(k_mul); R(k_add); R(k_sub); R(k_min); R(k_max); R(k_mov); R(k_cmp); R(k_cnd); R(k_rndne); R(k_floor);
     R(k_cvt_i32_f32); R(k_cvt_f32_i32); R(k_rcp); R(k_xor); R(k_and); R(k_lshl); R(k_ashr); R(k_bfe); R(k_addu); R(k_mullo); R(k_mulhi);
     R(k_perm); R(k_cvt_f32_f16); R(k_sdwa); R(k_fma64); R(k_mul64); R(k_add64); R(k_rndne64); R(k_pkfma); R(k_pkmul); R(k_pkadd); R(k_pkmov);
+    printf("(the next two: ns per int16-pair conversion SEQUENCE -- 2 and 5 instructions)\n");
+    R(k_cvt16_sdwa); R(k_cvt16_magic);
     return 0;
 }
