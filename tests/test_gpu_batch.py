@@ -141,3 +141,42 @@ def test_batch_with_chunked_members(gpu_api, oracle):
             ref = og.render_all(osb, ofb, cs, 16)
             got = (batch.read_pcm(i, cs), _f32_of(gpu_api, batch, i, cs))
             (assert_bit_exact if exact[i] else assert_close)(got, ref)
+
+
+@pytest.mark.parametrize("band_mode", [0, 1])
+def test_config4_batch_of_8(gpu_api, oracle, band_mode):
+    """Eight config-4 projects (256-vertex chain, asset seeds 7 + project id) in one batch at 10 s: every member against
+    its own oracle render -- bit for bit with the exact band-pass kernels, within 1e-6 RMS / +-1 LSB in scan mode (where the
+    eight chains are ONE k_band_chain launch)."""
+    seconds, n = 10.0, 8
+    batch = gpu_api.Batch()
+    projects = [W.config4(seconds=seconds, variant=pid) for pid in range(n)]
+    cs = projects[0].cs
+    for p in projects:
+        built = p.build(gpu_api)
+        built[2].set_option("band_mode", band_mode)
+        batch.add(*built)
+    batch.rewind()
+    assert batch.render_all(cs, 16) == cs * 1024
+    digests = set()
+    for i, p in enumerate(projects):
+        ref = p.render(oracle)
+        got = (batch.read_pcm(i, cs), _f32_of(gpu_api, batch, i, cs))
+        (assert_close if band_mode else assert_bit_exact)(got, ref)
+        digests.add(_digest(ref[0]))
+    assert len(digests) == n   # (different assets -> different renders)
+
+
+def test_config3_batch_of_8_scan(gpu_api, oracle):
+    seconds, n = 6.0, 8
+    batch = gpu_api.Batch()
+    projects = [W.config3(seconds=seconds, variant=pid) for pid in range(n)]
+    cs = projects[0].cs
+    for p in projects:
+        built = p.build(gpu_api)
+        built[2].set_option("band_mode", 1)
+        batch.add(*built)
+    batch.rewind()
+    batch.render_all(cs, 16)
+    for i, p in enumerate(projects):
+        assert_close((batch.read_pcm(i, cs), _f32_of(gpu_api, batch, i, cs)), p.render(oracle))
