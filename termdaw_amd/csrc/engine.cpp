@@ -471,7 +471,7 @@ struct VTables {   // per-vertex compile result: offsets into the vertex' table 
     const uint8_t* dev = nullptr;   // device address the offsets refer to
     size_t hits_off = 0;
     uint32_t n_hits = 0;
-    size_t istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0;
+    size_t istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0, tile_order_off = 0;
     uint32_t n_int = 0;
     uint64_t t0 = 0;
 };
@@ -577,6 +577,15 @@ static void put_intervals(IntervalBuilder& ib, Staging& st, VTables& vt) {
         tile_first[t] = it;
     }
     vt.tile_first_off = st.put(tile_first);
+    {   // tiles with an interval start strictly inside them first (IntervalTab::tile_order)
+        const size_t nt = tile_first.size() - 1;
+        std::vector<uint32_t> order, light;
+        order.reserve(nt);
+        for (size_t t = 0; t < nt; ++t) (tile_first[t + 1] > tile_first[t] + (ib.istart[tile_first[t + 1]] == (t + 1) * kTileFrames ? 1u : 0u)
+                                             ? order : light).push_back((uint32_t)t);
+        order.insert(order.end(), light.begin(), light.end());
+        vt.tile_order_off = st.put(order);
+    }
     vt.istart_off = st.put(ib.istart);
     vt.ivoff_off = st.put(ib.ivoff);
     vt.voices_off = st.put(ib.voices);
@@ -1206,6 +1215,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 tc->hits_off = t.hits_off; tc->n_hits = t.n_hits;
                 tc->istart_off = t.istart_off; tc->ivoff_off = t.ivoff_off; tc->voices_off = t.voices_off;
                 tc->tile_first_off = t.tile_first_off; tc->n_int = t.n_int;
+                tc->tile_order_off = t.tile_order_off;
                 tc->end_state.clear();
                 save_state(v, tc->end_state);
                 tc->key = key;
@@ -1217,6 +1227,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         o.hits_off = tc->hits_off; o.n_hits = tc->n_hits;
         o.istart_off = tc->istart_off; o.ivoff_off = tc->ivoff_off; o.voices_off = tc->voices_off;
         o.tile_first_off = tc->tile_first_off; o.n_int = tc->n_int;
+        o.tile_order_off = tc->tile_order_off;
     }
 
     // ---- 2. descriptors: walk levels, assign edge buffers
@@ -1668,6 +1679,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SynthDesc) + offsetof(SynthDesc, tab);
+                        tab_field(o, offsetof(IntervalTab, tile_order), vt[vs[i]], vt[vs[i]].tile_order_off);
                         tab_field(o, offsetof(IntervalTab, istart), vt[vs[i]], vt[vs[i]].istart_off);
                         tab_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
                         tab_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]], vt[vs[i]].ivoff_off);

@@ -95,7 +95,7 @@ struct TableCache {
     hipEvent_t copied = nullptr;
     bool inflight = false;
     // table layout: offsets into d
-    size_t hits_off = 0, istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0;
+    size_t hits_off = 0, istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0, tile_order_off = 0;
     uint32_t n_hits = 0, n_int = 0;
 };
 

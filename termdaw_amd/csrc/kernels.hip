@@ -1099,58 +1099,70 @@ TD_DEV void synth_env4(const AdsrConfD& c, f2 ta, f2 tb, float rel_t, float held
     eb.x = apply_ads_fast(c, tb.x); eb.y = apply_ads_fast(c, tb.y);
 }
 struct SynthEnv2 { f2 sq, tf, tr; };
-// oscillators x velocity x envelope x volume for the two frames of a pair (extensions.rs:499-524)
-TD_DEV f2 synth_osc2(const SynthDesc& d, const float4 n, const SynthEnv2& e, f2 time) {   // n = (hz, vel, env_t, rel_t)
-    const float hz = n.x, vel = n.y;
-    f2 s = (f2)(0.0f), sn = (f2)(0.0f);
-    if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any2(time * hz * 2.0f * kPi);
-    if (d.square.volume > 0.0f) {
+// oscillators x velocity x envelope x volume for the two frames of a pair (extensions.rs:499-524), added to `acc`.
+// k = (vel * volume * osc_amp_multiplier) per oscillator, folded once per voice: per oscillator and pair the product is one
+// multiply and one FMA instead of three multiplies, an add and the final `* osc_amp_multiplier` (tolerance class); the sine's
+// argument `time * hz * 2.0 * PI` as (time * hz) * (2 PI): the doubling is exact, the roundings are the reference's, and
+// time * hz is the triangle's argument anyway.  SPEC 1: all three oscillators on, the triangle sharing the top-flat's
+// envelope (BASELINE config 3's shape) -- the uniform flag tests of the generic form cost a branch each per voice.
+struct SynthAmp { float sq, tf, tr; };
+template <int SPEC>
+TD_DEV f2 synth_osc2(const SynthDesc& d, const float4 n, const SynthEnv2& e, const SynthAmp& k, f2 time, f2 acc) {   // n = (hz, vel, env_t, rel_t)
+    const float hz = n.x;
+    const bool sq_on = SPEC ? true : d.square.volume > 0.0f, tf_on = SPEC ? true : d.topflat.volume > 0.0f;
+    const bool tr_on = SPEC ? true : d.triangle.volume > 0.0f;
+    const f2 th = time * hz;
+    f2 sn = (f2)(0.0f);
+    if (sq_on || tf_on) sn = sin_any2(th * (2.0f * kPi));
+    if (sq_on) {
         const float z = d.square.param;
         f2 osc;
         osc.x = fminf(fmaxf(sn.x, -z), z);
         osc.y = fminf(fmaxf(sn.y, -z), z);
-        osc = osc * (1.0f / z);
-        s += osc * vel * e.sq * d.square.volume;
+        acc = fma2(osc * (1.0f / z), e.sq * k.sq, acc);
     }
-    if (d.topflat.volume > 0.0f) {
+    if (tf_on) {
         const float z = d.topflat.param;
         f2 m;
         m.x = fminf(sn.x, z);
         m.y = fminf(sn.y, z);
-        const f2 osc = (m + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
-        s += osc * vel * e.tf * d.topflat.volume;
+        acc = fma2((m + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z)), e.tf * k.tf, acc);
     }
-    if (d.triangle.volume > 0.0f) {
-        const f2 th = time * hz;
+    if (tr_on) {
         f2 fl = th + 0.5f;
         fl.x = floorf(fl.x);
         fl.y = floorf(fl.y);
         f2 dd = th - fl;
         dd.x = fabsf(dd.x);
         dd.y = fabsf(dd.y);
-        const f2 osc = 4.0f * dd - 1.0f;
-        s += osc * vel * e.tr * d.triangle.volume;
+        acc = fma2(fma2((f2)(4.0f), dd, (f2)(-1.0f)), e.tr * k.tr, acc);
     }
-    return s * d.osc_amp_multiplier;
+    return acc;
 }
 // one voice, the lane's four frames: a += voice(pair a), b += voice(pair b)
+template <int SPEC>
 TD_DEV void synth_voice4(const SynthDesc& d, const float4 n, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
     const float rel_t = n.w;
     const SynthHeld h = synth_held(d, rel_t);
     const f2 eta = n.z + oa, etb = n.z + ob;
     SynthEnv2 ea{(f2)(0.0f), (f2)(0.0f), (f2)(0.0f)}, eb = ea;
-    if (d.square.volume > 0.0f) synth_env4(d.square.adsr, eta, etb, rel_t, h.sq, ea.sq, eb.sq);
-    if (d.topflat.volume > 0.0f) {
-        if (d.tf_env_src == 1u) { ea.tf = ea.sq; eb.tf = eb.sq; }
+    const bool sq_on = SPEC ? true : d.square.volume > 0.0f, tf_on = SPEC ? true : d.topflat.volume > 0.0f;
+    const bool tr_on = SPEC ? true : d.triangle.volume > 0.0f;
+    const uint32_t tf_src = SPEC ? 0u : d.tf_env_src, tr_src = SPEC ? 2u : d.tr_env_src;
+    if (sq_on) synth_env4(d.square.adsr, eta, etb, rel_t, h.sq, ea.sq, eb.sq);
+    if (tf_on) {
+        if (tf_src == 1u) { ea.tf = ea.sq; eb.tf = eb.sq; }
         else synth_env4(d.topflat.adsr, eta, etb, rel_t, h.tf, ea.tf, eb.tf);
     }
-    if (d.triangle.volume > 0.0f) {
-        if (d.tr_env_src == 1u) { ea.tr = ea.sq; eb.tr = eb.sq; }
-        else if (d.tr_env_src == 2u) { ea.tr = ea.tf; eb.tr = eb.tf; }
+    if (tr_on) {
+        if (tr_src == 1u) { ea.tr = ea.sq; eb.tr = eb.sq; }
+        else if (tr_src == 2u) { ea.tr = ea.tf; eb.tr = eb.tf; }
         else synth_env4(d.triangle.adsr, eta, etb, rel_t, h.tr, ea.tr, eb.tr);
     }
-    a += synth_osc2(d, n, ea, ta);
-    b += synth_osc2(d, n, eb, tb);
+    const float kv = n.y * d.osc_amp_multiplier;
+    const SynthAmp k{kv * d.square.volume, kv * d.topflat.volume, kv * d.triangle.volume};
+    a = synth_osc2<SPEC>(d, n, ea, k, ta, a);
+    b = synth_osc2<SPEC>(d, n, eb, k, tb, b);
 }
 // The lane's frame pairs ma, ma + 1 and mb, mb + 1.  A wave's frames nearly always lie in ONE interval (intervals start
 // at block starts and event frames): the voice list is then the same for every lane, the voice records come in through
@@ -1178,10 +1190,18 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
         if (!two_a) { ta.y = ta.x; oa.y = oa.x; }
         if (!two_b) { tb.y = tb.x; ob.y = ob.x; }
         f2 a = (f2)(0.0f), b = (f2)(0.0f);
-        for (uint32_t v = v0; v < v1; ++v) {
-            const f4c q = vc[v];
-            const float4 n = make_float4(q.x, q.y, q.z, q.w);
-            synth_voice4(d, n, ta, tb, oa, ob, a, b);
+        if (d.square.volume > 0.0f && d.topflat.volume > 0.0f && d.triangle.volume > 0.0f && d.tf_env_src == 0u && d.tr_env_src == 2u) {
+            f4c q = vc[v0];   // (v0 == v1: the terminating record of the table is read and not used)
+            for (uint32_t v = v0; v < v1; ++v) {   // (one uniform test per wave instead of half a dozen per voice)
+                const f4c qn = vc[v + 1u];   // the next record's scalar load flies under this voice's arithmetic
+                synth_voice4<1>(d, make_float4(q.x, q.y, q.z, q.w), ta, tb, oa, ob, a, b);
+                q = qn;
+            }
+        } else {
+            for (uint32_t v = v0; v < v1; ++v) {
+                const f4c q = vc[v];
+                synth_voice4<0>(d, make_float4(q.x, q.y, q.z, q.w), ta, tb, oa, ob, a, b);
+            }
         }
         pa = make_float2(a.x, two_a ? a.y : 0.0f);
         pb = make_float2(b.x, two_b ? b.y : 0.0f);
@@ -1192,7 +1212,9 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
 }
 __global__ __launch_bounds__(kThreads) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
     const SynthDesc& d = descs[blockIdx.y];
-    const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
+    // (tiles whose waves take the per-frame form go first: IntervalTab::tile_order)
+    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
+    const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
     // (frames at or beyond M are computed on clamped indices and not stored: the uniform-interval test needs whole waves)
     const uint32_t mc0 = min(m0, M - 1u), mc1 = min(m1, M - 1u);
