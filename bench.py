@@ -507,6 +507,11 @@ def main():
         value = total_frames / dt / 1e6
         fused, packed = not args.no_fuse, not args.no_pack
         abf = algorithmic_bytes_per_frame(N_SRC, fused, packed)
+        single_pass = fused and "k_scale" not in ktimes and "k_norm_fix" in ktimes
+        if single_pass:
+            # SumDesc mode 4 (engine option single_pass_normalize): the running peak is found inside the summing launch through
+            # granules, the frames leave the registers as int16 PCM -- no raw-sum write, no pass B
+            abf["k_sum"] = (4.0 if packed else 8.0) * N_SRC + 4.0
         survey_abf = algorithmic_bytes_per_frame(N_SRC, False, False)   # SURVEY 8(d) edge-buffer figure
         ub = None
         try:
@@ -648,6 +653,8 @@ def main():
                                    "per GPU per step (project p of the job on rank p mod N, seed offset 64*p)" % (args.seconds, P),
                        "frames_per_project": frames, "projects_per_gpu": P, "vertices_per_project": N_SRC + 1,
                        "source_inlining": not args.no_fuse, "packed_samples": (not args.no_fuse) and (not args.no_pack),
+                       "normalize": "single pass: running peak through in-launch granules (k_sum16w mode 4) + k_norm_fix check" if single_pass
+                                    else "two passes: k_sum (sum + block peaks), k_scale",
                        "output": "int16 PCM in HBM (engine option output_f32 0: no f32 copy of the output vertex is kept)",
                        "parallelism": "projects sharded across GPUs; RCCL all-reduce(max) of the %d-entry peak table only" % (P * world)},
             "roofline": roofline,

@@ -195,6 +195,10 @@ size_t td_graph_device_bytes(const td_graph* g);
  * takes n / gamma frames -- again speed only;
  * "spec_normalize" 0|1 (default 1: a render after td_graph_normalize_scan normalises in ONE pass, speculating that
  * no block exceeds the scanned peak; a check kernel redoes the vertex the two-pass way when one does -- same values);
+ * "single_pass_normalize" 0|1 (default 1: a FRESH render of a Normalize vertex whose inputs are all looping samples on a
+ * timeline of >= 1 800 blocks finds the running peak inside the summing launch -- every tile publishes its maximum and
+ * reads the earlier tiles' -- and scales, pans, gains and quantises out of registers; the same check kernel stands behind
+ * it; 0: the two launches sum + peaks / scale -- same values);
  * "output_f32" 0|1 (default 1; 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames --
  * td_graph_read_f32 then fails, the PCM is unchanged);
  * "table_cache" 0|1 (default 1: the compiled event tables of an event-driven vertex stay on the device and are

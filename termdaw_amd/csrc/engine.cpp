@@ -1447,6 +1447,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::vector<size_t> fam_v[F_COUNT];
         std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
         std::map<size_t, BandPlan> band_plan;
+        std::vector<size_t> norm_pending;
+        std::map<size_t, uint32_t> norm_mode;   // Normalize vertices: SumDesc::mode (1 two passes, 3 / 4 one pass + k_norm_fix)
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
             if (inlined[vi]) continue;
@@ -1462,8 +1464,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 case K_SUM: fam_v[F_SUM].push_back(vi); break;
                 case K_NORMALIZE:
                     fam_v[F_SUM].push_back(vi);
-                    // after a normalize scan the peak is known: one pass + a (normally empty) fix launch instead of two
-                    fam_v[(g->spec_normalize && !is_scan && v.peak_known && !v.has_init_override) ? F_NORMFIX : F_SCALE].push_back(vi);
+                    norm_pending.push_back(vi);   // (F_SCALE or F_NORMFIX: decided below, once the term modes are known)
                     break;
                 case K_ADSR: fam_v[(v.wet < 0.0001f) ? F_SUM : F_ADSR].push_back(vi); break;
                 case K_BAND_PASS:
@@ -1579,6 +1580,22 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 tab_field(t, offsetof(IntervalTab, voices), vt[a], vt[a].voices_off);
                 ptr_field(ins_off[vi] + th.first * sizeof(InTerm), offsetof(InTerm, len), o);
             }
+        }
+        for (size_t vi : norm_pending) {
+            const Vertex& v = g->vertices[vi];
+            uint32_t mode = 1u;
+            if (g->spec_normalize && !is_scan) {
+                // after a normalize scan the peak is known: one pass + a (normally empty) fix launch instead of two (mode 3);
+                // a FRESH render whose sum runs in the wide all-loop kernels (k_sum16w: every tile resident at once) finds the
+                // running peak through granules inside that one launch (mode 4)
+                const uint32_t tm = term_mode[vi];
+                const bool wide = (tm == TERMS_ALL_LOOP16 || tm == TERMS_ALL_LOOP32) && bl == (size_t)kTileFrames &&
+                                  M >= (size_t)1800 * kTileFrames && M < ((size_t)1 << 31);
+                if (v.peak_known && !v.has_init_override) mode = 3u;
+                else if (wide && g->single_pass_normalize) mode = 4u;
+            }
+            norm_mode[vi] = mode;
+            fam_v[mode == 1u ? F_SCALE : F_NORMFIX].push_back(vi);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
         std::map<size_t, SumDesc> sum_desc_of;                      // Normalize vertices: their k_sum descriptor (k_norm_fix reuses it)
@@ -1715,7 +1732,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     // parallel band-pass vertices first get their summed input materialised (no epilogue)
                     for (size_t vi : fam_v[F_BAND_SPEC]) vs.push_back(vi);
                     // one launch per term mode (k_sum is instantiated per mode): group the vertices by it
-                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return term_mode[a] < term_mode[b]; });
+                    // (a single-pass running-peak Normalize -- mode 4 -- only exists in the wide kernels: a group of its own)
+                    auto sum_key = [&](size_t vi) { return term_mode[vi] * 2u + ((norm_mode.count(vi) && norm_mode[vi] == 4u) ? 1u : 0u); };
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return sum_key(a) < sum_key(b); });
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
                         SumDesc x{};
@@ -1723,9 +1742,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.out = presum ? band_plan[vi].tmp : g->vbuf[vi];
                         x.out_q4 = presum ? band_plan[vi].tmpq : nullptr;
                         x.k = (uint32_t)g->edges[vi].size();
-                        const bool spec = v.kind == K_NORMALIZE &&
-                                          std::find(fam_v[F_NORMFIX].begin(), fam_v[F_NORMFIX].end(), vi) != fam_v[F_NORMFIX].end();
-                        x.mode = v.kind == K_NORMALIZE ? (spec ? 3u : 1u) : (presum ? 2u : 0u);
+                        const bool spec = v.kind == K_NORMALIZE && norm_mode[vi] != 1u;
+                        x.mode = v.kind == K_NORMALIZE ? norm_mode[vi] : (presum ? 2u : 0u);
                         if (spec && (long)vi == g->output_vertex && pcm_dst && qmode) {
                             x.pcm = pcm_dst;
                             x.amplitude = amplitude;
@@ -1761,6 +1779,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
                             norm_scratch[vs[i]] = {pk, ic};
                             sum_desc_of[vs[i]] = d[i];
+                            if (d[i].mode == 4u) {   // one granule per tile of the widest kernel form (2 blocks per tile)
+                                cb.sync_fix.push_back({o + offsetof(SumDesc, sync), cb.sync_bytes});
+                                cb.sync_bytes += ((nb + 1) / 2 * 8 + 63) & ~(size_t)63;
+                            }
                             scratch_field(o, offsetof(SumDesc, peaks), pk);
                             scratch_field(o, offsetof(SumDesc, init_copy), ic);
                             if (peaks_need_zero) cb.zero.push_back({pk, nb * sizeof(float)});
@@ -2025,13 +2047,14 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 while (b < vs.size()) {
                     size_t e2 = b;
                     bool wide_ok = true;   // (k_sum16w: plain sums, or normalize pass A with the tile as reference block)
-                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]]) {
+                    auto m4 = [&](size_t vi) { return fam == F_SUM && norm_mode.count(vi) && norm_mode[vi] == 4u; };
+                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]] && m4(vs[e2]) == m4(vs[b])) {
                         wide_ok = wide_ok && (g->vertices[vs[e2]].kind != K_NORMALIZE || bl == (size_t)kTileFrames);
                         // (a band-pass vertex' input sum -- mode 2: planar copy, 256-frame liveness -- only exists in the pair-mapped k_sum)
                         wide_ok = wide_ok && !(fam == F_SUM && band_plan.count(vs[e2]));
                         ++e2;
                     }
-                    add_launch(fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u), lv);
+                    add_launch(fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u) | (m4(vs[b]) ? 0x200u : 0u), lv);
                     b = e2;
                 }
                 continue;
@@ -2244,7 +2267,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, L.M, s); break;
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
                 case F_ENV: launch_adsr_env((const AdsrVDesc*)d, L.n, L.M, s); break;
-                case F_SUM: launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, s); break;
+                case F_SUM: launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, (L.aux & 0x200u) != 0u, s); break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, L.M, L.bl, L.is_scan, s); break;
                 case F_NORMFIX: launch_norm_fix((const SumDesc*)d, L.n, L.M, L.bl, s); break;
                 case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, L.M, L.aux & 0xFFu, s); break;
@@ -3130,6 +3153,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }
     if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
+    if (k == "single_pass_normalize") { g->single_pass_normalize = value != 0; return 1; }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "table_cache") { g->table_cache = value != 0; return 1; }
     if (k == "graph_replay") { g->graph_replay = value != 0; return 1; }

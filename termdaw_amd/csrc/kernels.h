@@ -96,6 +96,7 @@ struct SumDesc {
                                //    render louder than the scan was): sum, scale by 1 / max, epilogue, optional quantise
                                //    straight out of registers; block peaks still go to `peaks`, a peak above max sets
                                //    state->violated and k_norm_fix (same descriptors) redoes the vertex the two-pass way
+                               // 4: Normalize in ONE pass with the running peak (fresh renders), see `sync` below
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
     uint32_t pad;
     PanGain pg;
@@ -108,6 +109,9 @@ struct SumDesc {
     float amplitude;
     uint32_t qmode;
     const BandRespParam* rp;   // mode 2: block responses wanted (nullptr: not)
+    // mode 4 (k_sum16w only): Normalize in ONE pass with the RUNNING peak -- every tile publishes its maximum as a granule
+    // in `sync` ([tiles] words, zeroed before the launch) and reads the earlier tiles'; k_norm_fix behind it as in mode 3
+    unsigned long long* sync;
 };
 
 // Normalize pass B: running max over the block peaks (`*max = buf_max.max(*max)`), buf.scale(len, 1.0 / max)
@@ -417,7 +421,8 @@ void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
-void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, hipStream_t s);
+// must_wide: the descriptors hold a mode-4 Normalize, which only the k_sum16w forms implement (the engine sets it where they would run anyway)
+void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 // second half of the speculative single-pass normalize: a no-op unless a block peak exceeded the carried max
 void launch_norm_fix(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);

@@ -104,6 +104,20 @@ TD_DEV void store_quant_pair(void* pcm, uint32_t qmode, uint32_t m, uint32_t M, 
 
 TD_DEV float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
+// Inter-workgroup hand-off inside a launch: 8-byte {tag = 1, value} granules, one agent-scope atomic store each, read back
+// with agent-scope atomic loads (global_store / global_load ... sc1: L1 bypassed, the data word carries its own validity,
+// so no fence on either side; cdna_hip_programming.md Guideline 16, form R2); the granule words are zeroed by the engine
+// before every launch (ONE memset per submission).
+typedef unsigned long long TD_GLOBAL* gu64;
+typedef uint32_t TD_GLOBAL* gu32;
+TD_DEV void granule_store(unsigned long long* p, uint32_t value) {
+    __hip_atomic_store((gu64)(TD_GLOBAL char*)p, (1ull << 32) | (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+TD_DEV unsigned long long granule_load(const unsigned long long* p) {
+    return __hip_atomic_load((gu64)(TD_GLOBAL char*)const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr uint32_t kScanSpinLimitSum = 20000;   // polls (~1 us each) of one earlier tile's granule before k_sum16w mode 4 gives up
+
 template <typename IDX>
 TD_DEV float4 loop_pair(const float2* s, IDX len, IDX idx) {
     float2 a = gload2(s + idx);
@@ -606,6 +620,8 @@ template <int NQ, bool PACKED = true>
 __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__ descs, uint32_t M) {
     const SumDesc& d = descs[blockIdx.y];
     const uint32_t m = blockIdx.x * (kTileFrames * NQ) + 4u * NQ * threadIdx.x;
+    // (mode 4: the carried max, read before anything else -- the last tile replaces it once every tile has published)
+    const float spec_init_early = d.mode == 4 ? (d.use_init ? d.init_max : gload1(&d.state->max)) : 0.0f;
     float4 a[2 * NQ];
     if (PACKED) sum_terms16w<NQ>(term_tab(d.ins), d.k, m, M, a);
     else sum_terms32w<NQ>(term_tab(d.ins), d.k, m, M, a);
@@ -618,11 +634,80 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
 #pragma unroll
     for (int q = 0; q < 2 * NQ; ++q) if (m + 2u * q < M) pk = absmax4(pk, a[q]);
     float spec_init = 0.0f;
+    if (d.mode == 4) {
+        // Single-pass RUNNING-PEAK normalize (fresh renders: `*max = buf_max.max(*max)` block by block, extensions.rs:321-329)
+        // for a grid that is resident at once: the tile's block peaks first, the tile's maximum published as one granule,
+        // every earlier tile's granule read back (704 tiles: three 8-byte loads per lane, spinning until tagged) -- their
+        // maximum with the carried max is the running peak entering this tile.  Then the frames are scaled, panned, gained
+        // and quantised straight out of the registers: the raw sums never reach memory and pass B (k_scale) is not launched.
+        // Waiting is bounded (a workgroup only waits for LOWER tiles, which the dispatcher starts first in practice but need
+        // not): a tile that gives up raises `violated`, and k_norm_fix -- launched behind every such kernel, one load per
+        // workgroup when nothing is wrong -- redoes the vertex the two-pass way from the block peaks stored here.
+        const float init = spec_init_early;
+        __shared__ float wm4[kThreads / 64], pm4[kThreads / 64];
+        __shared__ uint32_t bad4;
+        const uint32_t wave = threadIdx.x >> 6;
+        const float pw = wave_max(pk);
+        if ((threadIdx.x & 63) == 0) wm4[wave] = pw;
+        if (threadIdx.x == 0) bad4 = 0u;
+        __syncthreads();
+        constexpr uint32_t wpb = 4 / NQ;   // waves per reference block
+        float pb[NQ], T = 0.0f;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            float p = wm4[b * wpb];
+            for (uint32_t u = 1; u < wpb; ++u) p = fmaxf(p, wm4[b * wpb + u]);
+            pb[b] = p;
+            T = fmaxf(T, p);
+        }
+        if (threadIdx.x < (uint32_t)NQ) {
+            const uint32_t b = blockIdx.x * NQ + threadIdx.x;
+            if (b * kTileFrames < M) d.peaks[b] = threadIdx.x == 0 ? pb[0] : threadIdx.x == 1 ? pb[NQ > 1 ? 1 : 0] : threadIdx.x == 2 ? pb[NQ > 2 ? 2 : 0] : pb[NQ > 3 ? 3 : 0];
+        }
+        unsigned long long* const sync = d.sync;
+        if (threadIdx.x == 0) {
+            asm volatile("" ::"v"(init));   // (the carried max has been READ before this tile counts as published: the last tile replaces it)
+            granule_store(sync + blockIdx.x, __float_as_uint(T));
+        }
+        float pm = 0.0f;
+        bool ok = true;
+        for (uint32_t idx = threadIdx.x; idx < blockIdx.x; idx += kThreads) {
+            unsigned long long g = granule_load(sync + idx);
+            for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < kScanSpinLimitSum; ++spin) {
+                __builtin_amdgcn_s_sleep(2);
+                g = granule_load(sync + idx);
+            }
+            ok = ok && (uint32_t)(g >> 32) == 1u;
+            pm = fmaxf(pm, __uint_as_float((uint32_t)g));
+        }
+        pm = wave_max(pm);
+        if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
+        if (!ok) bad4 = 1u;
+        __syncthreads();
+        float run = fmaxf(fmaxf(fmaxf(pm4[0], pm4[1]), fmaxf(pm4[2], pm4[3])), init);   // max_{b-1} entering the tile
+        float r_mine = 0.0f;
+        const uint32_t my_block = wave / wpb;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            run = fmaxf(pb[b], run);   // *max = buf_max.max(*max)
+            if ((uint32_t)b == my_block) r_mine = 1.0f / run;
+        }
+        if (threadIdx.x == 0) {
+            NormState* st = const_cast<NormState*>(d.state);
+            if (bad4) st->violated = 1u;
+            else if (blockIdx.x == gridDim.x - 1u) st->max = run;   // (every earlier tile has read the old value: see above)
+        }
+        spec_init = -1.0f;   // (no speculation to check below)
+#pragma unroll
+        for (int q = 0; q < 2 * NQ; ++q) a[q] = epilogue4(make_float4(a[q].x * r_mine, a[q].y * r_mine, a[q].z * r_mine, a[q].w * r_mine), d.pg);
+    }
     if (d.mode == 3) {   // speculative single-pass normalize (see SumDesc): scaled, finished frames out of registers
         spec_init = d.use_init ? d.init_max : d.state->max;
         const float r = 1.0f / spec_init;
 #pragma unroll
         for (int q = 0; q < 2 * NQ; ++q) a[q] = epilogue4(make_float4(a[q].x * r, a[q].y * r, a[q].z * r, a[q].w * r), d.pg);
+    }
+    if (d.mode == 3 || d.mode == 4) {
         if (d.out) {   // (nullptr: nobody reads the f32 form of this output vertex -- engine option "output_f32" 0)
 #pragma unroll
             for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
@@ -655,9 +740,10 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d.init_copy[0] = d.use_init ? d.init_max : d.state->max;
+        d.init_copy[0] = d.mode == 4 ? spec_init_early : (d.use_init ? d.init_max : d.state->max);
         d.init_copy[1] = d.state->scan_max;
     }
+    if (d.mode == 4) return;   // (block peaks stored above)
     pk = wave_max(pk);
     __shared__ float wm[kThreads / 64];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = pk;
@@ -749,7 +835,7 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
 __global__ __launch_bounds__(kThreads) void k_norm_fix(const SumDesc* __restrict__ descs, uint32_t M, uint32_t bl, uint32_t nb) {
     const SumDesc& d = descs[blockIdx.y];
     NormState* st = const_cast<NormState*>(d.state);
-    if (d.mode != 3u || st->violated == 0u) return;   // the normal case: the whole launch is a few hundred one-load workgroups
+    if ((d.mode != 3u && d.mode != 4u) || st->violated == 0u) return;   // the normal case: the whole launch is a few hundred one-load workgroups
     const float init = d.init_copy[0];
     __shared__ float wmax[kThreads / 64];
     const uint32_t n_tiles = (M + kTileFrames - 1) / kTileFrames;
@@ -2240,17 +2326,7 @@ __global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __re
 // k_band_scan: band_pass_gen as a blocked affine scan -- tolerance class; one launch per vertex or per chain of
 // band-pass vertices (BandScanDesc, kernels.h)
 // ------------------------------------------------------------------------------------------------
-// Inter-workgroup hand-off: 8-byte {tag = 1, value} granules, one agent-scope atomic store each, read back with
-// agent-scope atomic loads (global_store / global_load ... sc1: L1 bypassed, the data word carries its own validity, so
-// no fence on either side); the granule words are zeroed by the engine before every launch.
-typedef unsigned long long TD_GLOBAL* gu64;
-typedef uint32_t TD_GLOBAL* gu32;
-TD_DEV void granule_store(unsigned long long* p, uint32_t value) {
-    __hip_atomic_store((gu64)(TD_GLOBAL char*)p, (1ull << 32) | (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-TD_DEV unsigned long long granule_load(const unsigned long long* p) {
-    return __hip_atomic_load((gu64)(TD_GLOBAL char*)const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (granule_store / granule_load: the inter-workgroup hand-off words, defined with the helpers at the top of the file)
 TD_DEV double dsel4(const double v[4], uint32_t c) { return c == 0u ? v[0] : c == 1u ? v[1] : c == 2u ? v[2] : v[3]; }
 constexpr uint32_t kScanSpinLimit = 4096;   // polls (~1 us each) before a predecessor is recomputed instead of awaited
 
@@ -3016,10 +3092,12 @@ constexpr int kMaxGridY = 65535;
         hipLaunchKernelGGL(KERNEL, dim3((GRID_X), std::min((N) - o_, kMaxGridY)), dim3(BLOCK), 0, s, (D) + o_, __VA_ARGS__)
 
 static const auto k_sum32w_2 = &k_sum16w<2, false>;   // (names without a comma for the launch macro)
-void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, hipStream_t s) {
+void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
-    static const int forced_nq = getenv("TD_FORCE_NQ") ? atoi(getenv("TD_FORCE_NQ")) : 0;   // tuning aid: 1 | 2 | 4
+    static const int env_nq = getenv("TD_FORCE_NQ") ? atoi(getenv("TD_FORCE_NQ")) : 0;   // tuning aid: 1 | 2 | 4
+    const int forced_nq = (must_wide && env_nq == 1) ? 0 : env_nq;
+    if (must_wide) wide_ok = true;
     static const int slice_env = getenv("TD_SUM_SLICE") ? atoi(getenv("TD_SUM_SLICE")) : 0;  // tuning aid: projects per launch slice
     switch (term_mode) {
         case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_EDGE>), tiles(frames), kThreads, d, n, frames, bl, tpb); break;
