@@ -1592,10 +1592,16 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 const bool wide = (tm == TERMS_ALL_LOOP16 || tm == TERMS_ALL_LOOP32) && bl == (size_t)kTileFrames &&
                                   M >= (size_t)1800 * kTileFrames && M < ((size_t)1 << 31);
                 if (v.peak_known && !v.has_init_override) mode = 3u;
-                else if (wide && g->single_pass_normalize) mode = 4u;
+                else if (wide && g->single_pass_normalize) {
+                    // (the kernel form launch_sum will pick: 16 frames per lane from 2 600 tiles on, packed sources only)
+                    const bool packed = tm == TERMS_ALL_LOOP16;
+                    const int nq = (packed && M >= (size_t)2600 * kTileFrames) ? 4 : 2;
+                    const size_t gx = (M + (size_t)kTileFrames * nq - 1) / ((size_t)kTileFrames * nq);
+                    mode = (size_t)sum16w_resident_capacity(nq, packed) >= gx ? 5u : 4u;
+                }
             }
             norm_mode[vi] = mode;
-            fam_v[mode == 1u ? F_SCALE : F_NORMFIX].push_back(vi);
+            if (mode != 5u) fam_v[mode == 1u ? F_SCALE : F_NORMFIX].push_back(vi);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
         std::map<size_t, SumDesc> sum_desc_of;                      // Normalize vertices: their k_sum descriptor (k_norm_fix reuses it)
@@ -1733,7 +1739,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     for (size_t vi : fam_v[F_BAND_SPEC]) vs.push_back(vi);
                     // one launch per term mode (k_sum is instantiated per mode): group the vertices by it
                     // (a single-pass running-peak Normalize -- mode 4 -- only exists in the wide kernels: a group of its own)
-                    auto sum_key = [&](size_t vi) { return term_mode[vi] * 2u + ((norm_mode.count(vi) && norm_mode[vi] == 4u) ? 1u : 0u); };
+                    auto sum_key = [&](size_t vi) { return term_mode[vi] * 2u + ((norm_mode.count(vi) && norm_mode[vi] >= 4u) ? 1u : 0u); };
                     std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return sum_key(a) < sum_key(b); });
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
@@ -1779,7 +1785,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
                             norm_scratch[vs[i]] = {pk, ic};
                             sum_desc_of[vs[i]] = d[i];
-                            if (d[i].mode == 4u) {   // one granule per tile of the widest kernel form (2 blocks per tile)
+                            if (d[i].mode >= 4u) {   // one granule per tile of the widest kernel form (2 blocks per tile)
                                 cb.sync_fix.push_back({o + offsetof(SumDesc, sync), cb.sync_bytes});
                                 cb.sync_bytes += ((nb + 1) / 2 * 8 + 63) & ~(size_t)63;
                             }
@@ -2047,7 +2053,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 while (b < vs.size()) {
                     size_t e2 = b;
                     bool wide_ok = true;   // (k_sum16w: plain sums, or normalize pass A with the tile as reference block)
-                    auto m4 = [&](size_t vi) { return fam == F_SUM && norm_mode.count(vi) && norm_mode[vi] == 4u; };
+                    auto m4 = [&](size_t vi) { return fam == F_SUM && norm_mode.count(vi) && norm_mode[vi] >= 4u; };
                     while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]] && m4(vs[e2]) == m4(vs[b])) {
                         wide_ok = wide_ok && (g->vertices[vs[e2]].kind != K_NORMALIZE || bl == (size_t)kTileFrames);
                         // (a band-pass vertex' input sum -- mode 2: planar copy, 256-frame liveness -- only exists in the pair-mapped k_sum)

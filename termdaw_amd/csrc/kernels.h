@@ -97,6 +97,7 @@ struct SumDesc {
                                //    straight out of registers; block peaks still go to `peaks`, a peak above max sets
                                //    state->violated and k_norm_fix (same descriptors) redoes the vertex the two-pass way
                                // 4: Normalize in ONE pass with the running peak (fresh renders), see `sync` below
+                               // 5: the same for a grid that is resident at once (checked on the host): no k_norm_fix behind it
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
     uint32_t pad;
     PanGain pg;
@@ -421,7 +422,8 @@ void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
-// must_wide: the descriptors hold a mode-4 Normalize, which only the k_sum16w forms implement (the engine sets it where they would run anyway)
+int sum16w_resident_capacity(int nq, bool packed);   // workgroups of k_sum16w<nq, packed> the device holds at once (0: unknown)
+// must_wide: the descriptors hold a mode-4 / mode-5 Normalize, which only the k_sum16w forms implement (the engine sets it where they would run anyway)
 void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 // second half of the speculative single-pass normalize: a no-op unless a block peak exceeded the carried max

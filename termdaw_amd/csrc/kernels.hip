@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
     const SumDesc& d = descs[blockIdx.y];
     const uint32_t m = blockIdx.x * (kTileFrames * NQ) + 4u * NQ * threadIdx.x;
     // (mode 4: the carried max, read before anything else -- the last tile replaces it once every tile has published)
-    const float spec_init_early = d.mode == 4 ? (d.use_init ? d.init_max : gload1(&d.state->max)) : 0.0f;
+    const float spec_init_early = d.mode >= 4 ? (d.use_init ? d.init_max : gload1(&d.state->max)) : 0.0f;
     float4 a[2 * NQ];
     if (PACKED) sum_terms16w<NQ>(term_tab(d.ins), d.k, m, M, a);
     else sum_terms32w<NQ>(term_tab(d.ins), d.k, m, M, a);
@@ -634,15 +634,18 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
 #pragma unroll
     for (int q = 0; q < 2 * NQ; ++q) if (m + 2u * q < M) pk = absmax4(pk, a[q]);
     float spec_init = 0.0f;
-    if (d.mode == 4) {
+    if (d.mode >= 4) {
         // Single-pass RUNNING-PEAK normalize (fresh renders: `*max = buf_max.max(*max)` block by block, extensions.rs:321-329)
         // for a grid that is resident at once: the tile's block peaks first, the tile's maximum published as one granule,
         // every earlier tile's granule read back (704 tiles: three 8-byte loads per lane, spinning until tagged) -- their
         // maximum with the carried max is the running peak entering this tile.  Then the frames are scaled, panned, gained
         // and quantised straight out of the registers: the raw sums never reach memory and pass B (k_scale) is not launched.
-        // Waiting is bounded (a workgroup only waits for LOWER tiles, which the dispatcher starts first in practice but need
-        // not): a tile that gives up raises `violated`, and k_norm_fix -- launched behind every such kernel, one load per
-        // workgroup when nothing is wrong -- redoes the vertex the two-pass way from the block peaks stored here.
+        // A workgroup only waits for LOWER tiles, which the dispatcher starts first in practice but need not.  Mode 5: the host
+        // has checked that the whole grid is resident at once (occupancy x CUs, sum16w_resident_capacity), so every tile
+        // runs whatever the dispatch order and the wait needs no way out (a bound of seconds, then a trap: fail loudly).
+        // Mode 4 (a grid larger than that): the wait is bounded, a tile that gives up raises `violated`, and k_norm_fix --
+        // launched behind such a kernel, one load per workgroup when nothing is wrong -- redoes the vertex the two-pass way
+        // from the block peaks stored here.
         const float init = spec_init_early;
         __shared__ float wm4[kThreads / 64], pm4[kThreads / 64];
         __shared__ uint32_t bad4;
@@ -673,10 +676,12 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         bool ok = true;
         for (uint32_t idx = threadIdx.x; idx < blockIdx.x; idx += kThreads) {
             unsigned long long g = granule_load(sync + idx);
-            for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < kScanSpinLimitSum; ++spin) {
+            const uint32_t limit = d.mode == 5 ? 0x400000u : kScanSpinLimitSum;
+            for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < limit; ++spin) {
                 __builtin_amdgcn_s_sleep(2);
                 g = granule_load(sync + idx);
             }
+            if (d.mode == 5 && (uint32_t)(g >> 32) != 1u) __builtin_trap();   // (seconds without a resident tile publishing: not a state to compute on)
             ok = ok && (uint32_t)(g >> 32) == 1u;
             pm = fmaxf(pm, __uint_as_float((uint32_t)g));
         }
@@ -707,7 +712,7 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
 #pragma unroll
         for (int q = 0; q < 2 * NQ; ++q) a[q] = epilogue4(make_float4(a[q].x * r, a[q].y * r, a[q].z * r, a[q].w * r), d.pg);
     }
-    if (d.mode == 3 || d.mode == 4) {
+    if (d.mode >= 3) {
         if (d.out) {   // (nullptr: nobody reads the f32 form of this output vertex -- engine option "output_f32" 0)
 #pragma unroll
             for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
@@ -740,10 +745,10 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        d.init_copy[0] = d.mode == 4 ? spec_init_early : (d.use_init ? d.init_max : d.state->max);
+        d.init_copy[0] = d.mode >= 4 ? spec_init_early : (d.use_init ? d.init_max : d.state->max);
         d.init_copy[1] = d.state->scan_max;
     }
-    if (d.mode == 4) return;   // (block peaks stored above)
+    if (d.mode >= 4) return;   // (block peaks stored above)
     pk = wave_max(pk);
     __shared__ float wm[kThreads / 64];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = pk;
@@ -3092,6 +3097,22 @@ constexpr int kMaxGridY = 65535;
         hipLaunchKernelGGL(KERNEL, dim3((GRID_X), std::min((N) - o_, kMaxGridY)), dim3(BLOCK), 0, s, (D) + o_, __VA_ARGS__)
 
 static const auto k_sum32w_2 = &k_sum16w<2, false>;   // (names without a comma for the launch macro)
+// Workgroups of a k_sum16w form that the device holds at once (0: unknown).  A single-pass Normalize whose grid fits
+// needs no check launch behind it (SumDesc mode 5).
+int sum16w_resident_capacity(int nq, bool packed) {
+    static int cap[3] = {-1, -1, -1};   // <4, true>, <2, true>, <2, false>
+    const int i = packed ? (nq == 4 ? 0 : 1) : 2;
+    if (cap[i] < 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        hipError_t e = i == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sum16w<4, true>, kThreads, 0)
+                     : i == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sum16w<2, true>, kThreads, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sum16w<2, false>, kThreads, 0);
+        cap[i] = (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                     ? per_cu * prop.multiProcessorCount : 0;
+    }
+    return cap[i];
+}
 void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
@@ -3104,8 +3125,12 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
         case TERMS_ALL_LOOP32:
             // (8 frames per lane: 0.183 -> 0.152 ms on config 2 with f32 samples; 16 per lane: 0.211 ms -- twice the
             // bytes per frame of the packed form, the whole grid's working set no longer sits in L2)
-            if (wide_ok && frames >= 1800u * kTileFrames)
-                TD_BATCHED(k_sum32w_2, (frames + kTileFrames * 2 - 1) / (kTileFrames * 2), kThreads, d, n, frames);
+            if (wide_ok && frames >= 1800u * kTileFrames) {
+                const uint32_t gx = (frames + kTileFrames * 2 - 1) / (kTileFrames * 2);
+                const int per = must_wide ? std::max(1, sum16w_resident_capacity(2, false) / (int)gx) : n;
+                for (int o = 0; o < n; o += per)
+                    hipLaunchKernelGGL(k_sum32w_2, dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+            }
             else
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames, bl, tpb);
             break;
@@ -3124,12 +3149,14 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
             // bare gather shows the same loss, so it is the access pattern, not the arithmetic).
             if (wide_ok && (forced_nq ? forced_nq == 4 : frames >= 2600u * kTileFrames)) {
                 const uint32_t gx = (frames + kTileFrames * 4 - 1) / (kTileFrames * 4);
-                const int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
+                int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
+                if (must_wide) per = std::max(1, std::min(per, sum16w_resident_capacity(4, true) / (int)gx));   // (mode 5: a slice must be resident at once)
                 for (int o = 0; o < n; o += per)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<4>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
             } else if (wide_ok && (forced_nq ? forced_nq == 2 : frames >= 1800u * kTileFrames)) {
                 const uint32_t gx = (frames + kTileFrames * 2 - 1) / (kTileFrames * 2);
-                const int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
+                int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
+                if (must_wide) per = std::max(1, std::min(per, sum16w_resident_capacity(2, true) / (int)gx));
                 for (int o = 0; o < n; o += per)
                     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<2>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
             }
