@@ -1448,7 +1448,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
         std::map<size_t, BandPlan> band_plan;
         std::vector<size_t> norm_pending;
-        std::map<size_t, uint32_t> norm_mode;   // Normalize vertices: SumDesc::mode (1 two passes, 3 / 4 one pass + k_norm_fix)
+        std::map<size_t, uint32_t> norm_mode;   // Normalize vertices: SumDesc::mode (1 two passes, 3 / 4 one pass + k_norm_fix, 5 one pass)
+        std::map<size_t, int> norm_tpw;         // ... of those, the ones that take k_norm1: tiles per workgroup
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
             if (inlined[vi]) continue;
@@ -1592,7 +1593,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 const bool wide = (tm == TERMS_ALL_LOOP16 || tm == TERMS_ALL_LOOP32) && bl == (size_t)kTileFrames &&
                                   M >= (size_t)1800 * kTileFrames && M < ((size_t)1 << 31);
                 if (v.peak_known && !v.has_init_override) mode = 3u;
-                else if (wide && g->single_pass_normalize) {
+                else if (!wide && g->single_pass_normalize && bl == (size_t)kTileFrames && M < ((size_t)1 << 31)) {
+                    // any other input terms, any timeline whose grid is resident at once: k_norm1
+                    const int tpw = norm1_tiles_per_workgroup(tm, (uint32_t)M);
+                    if (tpw) { mode = 5u; norm_tpw[vi] = tpw; }
+                } else if (wide && g->single_pass_normalize) {
                     // (the kernel form launch_sum will pick: 16 frames per lane from 2 600 tiles on, packed sources only)
                     const bool packed = tm == TERMS_ALL_LOOP16;
                     const int nq = (packed && M >= (size_t)2600 * kTileFrames) ? 4 : 2;
@@ -1739,7 +1744,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     for (size_t vi : fam_v[F_BAND_SPEC]) vs.push_back(vi);
                     // one launch per term mode (k_sum is instantiated per mode): group the vertices by it
                     // (a single-pass running-peak Normalize -- mode 4 -- only exists in the wide kernels: a group of its own)
-                    auto sum_key = [&](size_t vi) { return term_mode[vi] * 2u + ((norm_mode.count(vi) && norm_mode[vi] >= 4u) ? 1u : 0u); };
+                    auto sum_key = [&](size_t vi) {
+                        return term_mode[vi] * 16u + ((norm_mode.count(vi) && norm_mode[vi] >= 4u) ? 1u : 0u) + (norm_tpw.count(vi) ? 2u * (uint32_t)norm_tpw[vi] : 0u);
+                    };
                     std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return sum_key(a) < sum_key(b); });
                     for (size_t vi : vs) {
                         const Vertex& v = g->vertices[vi];
@@ -1785,9 +1792,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
                             norm_scratch[vs[i]] = {pk, ic};
                             sum_desc_of[vs[i]] = d[i];
-                            if (d[i].mode >= 4u) {   // one granule per tile of the widest kernel form (2 blocks per tile)
+                            if (d[i].mode >= 4u) {   // one granule per workgroup (at most one per block)
                                 cb.sync_fix.push_back({o + offsetof(SumDesc, sync), cb.sync_bytes});
-                                cb.sync_bytes += ((nb + 1) / 2 * 8 + 63) & ~(size_t)63;
+                                cb.sync_bytes += (nb * 8 + 63) & ~(size_t)63;
                             }
                             scratch_field(o, offsetof(SumDesc, peaks), pk);
                             scratch_field(o, offsetof(SumDesc, init_copy), ic);
@@ -2054,13 +2061,15 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     size_t e2 = b;
                     bool wide_ok = true;   // (k_sum16w: plain sums, or normalize pass A with the tile as reference block)
                     auto m4 = [&](size_t vi) { return fam == F_SUM && norm_mode.count(vi) && norm_mode[vi] >= 4u; };
-                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]] && m4(vs[e2]) == m4(vs[b])) {
+                    auto tpw_of = [&](size_t vi) { return (fam == F_SUM && norm_tpw.count(vi)) ? norm_tpw[vi] : 0; };
+                    while (e2 < vs.size() && term_mode[vs[e2]] == term_mode[vs[b]] && m4(vs[e2]) == m4(vs[b]) && tpw_of(vs[e2]) == tpw_of(vs[b])) {
                         wide_ok = wide_ok && (g->vertices[vs[e2]].kind != K_NORMALIZE || bl == (size_t)kTileFrames);
                         // (a band-pass vertex' input sum -- mode 2: planar copy, 256-frame liveness -- only exists in the pair-mapped k_sum)
                         wide_ok = wide_ok && !(fam == F_SUM && band_plan.count(vs[e2]));
                         ++e2;
                     }
-                    add_launch(fam, off + b * dsz, (int)(e2 - b), term_mode[vs[b]] | (wide_ok ? 0x100u : 0u) | (m4(vs[b]) ? 0x200u : 0u), lv);
+                    add_launch(fam, off + b * dsz, (int)(e2 - b),
+                               term_mode[vs[b]] | (wide_ok ? 0x100u : 0u) | (m4(vs[b]) ? 0x200u : 0u) | ((uint32_t)tpw_of(vs[b]) << 12), lv);
                     b = e2;
                 }
                 continue;
@@ -2273,7 +2282,10 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, L.M, s); break;
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
                 case F_ENV: launch_adsr_env((const AdsrVDesc*)d, L.n, L.M, s); break;
-                case F_SUM: launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, (L.aux & 0x200u) != 0u, s); break;
+                case F_SUM:
+                    if (L.aux >> 12) launch_norm1((const SumDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)(L.aux >> 12), s);   // single-pass Normalize, narrow forms
+                    else launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, (L.aux & 0x200u) != 0u, s);
+                    break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, L.M, L.bl, L.is_scan, s); break;
                 case F_NORMFIX: launch_norm_fix((const SumDesc*)d, L.n, L.M, L.bl, s); break;
                 case F_ADSR: launch_adsr((const AdsrVDesc*)d, L.n, L.M, L.aux & 0xFFu, s); break;

@@ -422,6 +422,10 @@ void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
+// k_norm1 (SumDesc mode 5 outside the wide all-loop sums): tiles per workgroup (1 | 2 | 4) with which the whole grid of a
+// `frames`-long chunk is resident at once, 0 if none; and its launch
+int norm1_tiles_per_workgroup(uint32_t term_mode, uint32_t frames);
+void launch_norm1(const SumDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int tpw, hipStream_t s);
 int sum16w_resident_capacity(int nq, bool packed);   // workgroups of k_sum16w<nq, packed> the device holds at once (0: unknown)
 // must_wide: the descriptors hold a mode-4 / mode-5 Normalize, which only the k_sum16w forms implement (the engine sets it where they would run anyway)
 void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s);

@@ -767,6 +767,98 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_norm1: Normalize in ONE launch for any input terms (SumDesc mode 5), reference block = the 1024-frame tile
+// ------------------------------------------------------------------------------------------------
+// The same scheme as k_sum16w's mode 5 for the narrow forms: a workgroup sums TPW consecutive tiles (1, 2 or 4: chosen by the
+// host so that the whole grid is resident at once -- the waits below then need no way out), publishes the largest of their
+// block peaks as one granule, reads every earlier workgroup's, and scales / pans / gains / quantises its frames out of the
+// registers with the running peak  max_b = peak_b.max(max_{b-1})  (extensions.rs:321-329): same f32 operations as k_sum
+// mode 1 + k_scale, one launch instead of two and no raw-sum round trip.
+template <int TMODE, int TPW>
+__global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ descs, uint32_t M, uint32_t n_tiles) {
+    const SumDesc& d = descs[blockIdx.y];
+    // (the carried max, read before anything else: the last workgroup replaces it once every workgroup has published)
+    const float init = d.use_init ? d.init_max : gload1(&d.state->max);
+    constexpr bool quad_map = TMODE == TERMS_ALL_LOOP16;
+    const uint32_t wave = threadIdx.x >> 6;
+    float4 a[2 * TPW];
+    uint32_t mm[2 * TPW];
+    __shared__ float wm[TPW][kThreads / 64], pm4[kThreads / 64];
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        const uint32_t tile = blockIdx.x * (uint32_t)TPW + (uint32_t)u;
+        const uint32_t m0 = tile * kTileFrames + (quad_map ? 4 : 2) * threadIdx.x;
+        const uint32_t m1 = m0 + (quad_map ? 2 : kTileFrames / 2);
+        mm[2 * u] = m0;
+        mm[2 * u + 1] = m1;
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
+        if (tile < n_tiles) {   // (uniform)
+            if (quad_map) sum_terms16(term_tab(d.ins), d.k, m0, M, a0, a1);
+            else sum_terms<TMODE>(term_tab(d.ins), d.k, m0, m1, M, a0, a1);
+        }
+        a[2 * u] = a0;
+        a[2 * u + 1] = a1;
+        float pk = 0.0f;   // block peaks are those of the RAW sum
+        if (m0 < M) pk = absmax4(pk, a0);
+        if (m1 < M) pk = absmax4(pk, a1);
+        pk = wave_max(pk);
+        if ((threadIdx.x & 63) == 0) wm[u][wave] = pk;
+    }
+    __syncthreads();
+    float pb[TPW], T = 0.0f;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        pb[u] = fmaxf(fmaxf(wm[u][0], wm[u][1]), fmaxf(wm[u][2], wm[u][3]));
+        T = fmaxf(T, pb[u]);
+    }
+    if (threadIdx.x < (uint32_t)TPW) {
+        const uint32_t tile = blockIdx.x * (uint32_t)TPW + threadIdx.x;
+        float p = pb[0];
+#pragma unroll
+        for (int u = 1; u < TPW; ++u) if (threadIdx.x == (uint32_t)u) p = pb[u];
+        if (tile < n_tiles) d.peaks[tile] = p;
+    }
+    if (threadIdx.x == 0) {
+        asm volatile("" ::"v"(init));   // (the carried max has been READ before this workgroup counts as published)
+        granule_store(d.sync + blockIdx.x, __float_as_uint(T));
+        if (blockIdx.x == 0) {
+            d.init_copy[0] = init;
+            d.init_copy[1] = d.state->scan_max;
+        }
+    }
+    float pm = 0.0f;
+    for (uint32_t idx = threadIdx.x; idx < blockIdx.x; idx += kThreads) {
+        unsigned long long g = granule_load(d.sync + idx);
+        for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < 0x400000u; ++spin) {
+            __builtin_amdgcn_s_sleep(2);
+            g = granule_load(d.sync + idx);
+        }
+        if ((uint32_t)(g >> 32) != 1u) __builtin_trap();   // (seconds without a resident workgroup publishing: not a state to compute on)
+        pm = fmaxf(pm, __uint_as_float((uint32_t)g));
+    }
+    pm = wave_max(pm);
+    if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
+    __syncthreads();
+    float run = fmaxf(fmaxf(fmaxf(pm4[0], pm4[1]), fmaxf(pm4[2], pm4[3])), init);   // max_{b-1} entering the first tile
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+        run = fmaxf(pb[u], run);   // *max = buf_max.max(*max)
+        const float r = 1.0f / run;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t m = mm[2 * u + h];
+            if (m < M) {
+                float4 v = a[2 * u + h];
+                v = epilogue4(make_float4(v.x * r, v.y * r, v.z * r, v.w * r), d.pg);
+                if (d.out) store_pair(d.out, m, M, v);
+                if (d.qmode) store_quant_pair(d.pcm, d.qmode, m, M, v, d.amplitude);
+            }
+        }
+    }
+    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1u) const_cast<NormState*>(d.state)->max = run;   // (every earlier workgroup has read the old value)
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_scale: Normalize pass B (running peak -> scale by 1/max, epilogue, optional fused quantise)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict__ descs, uint32_t M, uint32_t bl,
@@ -3112,6 +3204,65 @@ int sum16w_resident_capacity(int nq, bool packed) {
                      ? per_cu * prop.multiProcessorCount : 0;
     }
     return cap[i];
+}
+// k_norm1: the instantiation for (term mode, tiles per workgroup), its resident capacity, its launch
+template <int TMODE, int TPW>
+static int norm1_capacity_of() {
+    static int cap = -1;
+    if (cap < 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        cap = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_norm1<TMODE, TPW>, kThreads, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+               hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0;
+    }
+    return cap;
+}
+template <int TMODE>
+static int norm1_capacity_mode(int tpw) {
+    return tpw == 1 ? norm1_capacity_of<TMODE, 1>() : tpw == 2 ? norm1_capacity_of<TMODE, 2>() : norm1_capacity_of<TMODE, 4>();
+}
+static int norm1_capacity(uint32_t term_mode, int tpw) {
+    switch (term_mode) {
+        case TERMS_ALL_EDGE: return norm1_capacity_mode<TERMS_ALL_EDGE>(tpw);
+        case TERMS_ALL_LOOP32: return norm1_capacity_mode<TERMS_ALL_LOOP32>(tpw);
+        case TERMS_ALL_LOOP16: return norm1_capacity_mode<TERMS_ALL_LOOP16>(tpw);
+        case TERMS_EDGE_FEW: return norm1_capacity_mode<TERMS_EDGE_FEW>(tpw);
+        case TERMS_ADSR1: return norm1_capacity_mode<TERMS_ADSR1>(tpw);
+        case TERMS_WITH_ADSR: return norm1_capacity_mode<TERMS_WITH_ADSR>(tpw);
+        default: return norm1_capacity_mode<TERMS_MIXED>(tpw);
+    }
+}
+int norm1_tiles_per_workgroup(uint32_t term_mode, uint32_t frames) {
+    const uint32_t nt = (frames + kTileFrames - 1) / kTileFrames;
+    for (int tpw : {1, 2, 4})
+        if ((uint32_t)norm1_capacity(term_mode, tpw) >= (nt + (uint32_t)tpw - 1u) / (uint32_t)tpw) return tpw;
+    return 0;
+}
+template <int TMODE, int TPW>
+static void launch_norm1_of(const SumDesc* d, int n, uint32_t frames, hipStream_t s) {
+    static const auto kern = &k_norm1<TMODE, TPW>;   // (a name without a comma for the launch macro)
+    const uint32_t nt = (frames + kTileFrames - 1) / kTileFrames, gx = (nt + TPW - 1) / TPW;
+    const int per = std::max(1, norm1_capacity_of<TMODE, TPW>() / (int)gx);   // (a slice must be resident at once)
+    for (int o = 0; o < n; o += per)
+        hipLaunchKernelGGL(kern, dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames, nt);
+}
+template <int TMODE>
+static void launch_norm1_mode(const SumDesc* d, int n, uint32_t frames, int tpw, hipStream_t s) {
+    if (tpw == 1) launch_norm1_of<TMODE, 1>(d, n, frames, s);
+    else if (tpw == 2) launch_norm1_of<TMODE, 2>(d, n, frames, s);
+    else launch_norm1_of<TMODE, 4>(d, n, frames, s);
+}
+void launch_norm1(const SumDesc* d, int n, uint32_t frames, uint32_t term_mode, int tpw, hipStream_t s) {
+    if (!n || !frames) return;
+    switch (term_mode) {
+        case TERMS_ALL_EDGE: launch_norm1_mode<TERMS_ALL_EDGE>(d, n, frames, tpw, s); break;
+        case TERMS_ALL_LOOP32: launch_norm1_mode<TERMS_ALL_LOOP32>(d, n, frames, tpw, s); break;
+        case TERMS_ALL_LOOP16: launch_norm1_mode<TERMS_ALL_LOOP16>(d, n, frames, tpw, s); break;
+        case TERMS_EDGE_FEW: launch_norm1_mode<TERMS_EDGE_FEW>(d, n, frames, tpw, s); break;
+        case TERMS_ADSR1: launch_norm1_mode<TERMS_ADSR1>(d, n, frames, tpw, s); break;
+        case TERMS_WITH_ADSR: launch_norm1_mode<TERMS_WITH_ADSR>(d, n, frames, tpw, s); break;
+        default: launch_norm1_mode<TERMS_MIXED>(d, n, frames, tpw, s); break;
+    }
 }
 void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s) {
     if (!n || !frames) return;

@@ -19,14 +19,18 @@ def _families(g, render):
     return out, names
 
 
-@pytest.mark.parametrize("spec", [1, 0])
-def test_scanned_render_takes_the_single_pass(gpu_api, oracle, spec):
+@pytest.mark.parametrize("spec,single", [(1, 1), (1, 0), (0, 1)])
+def test_scanned_render_takes_the_single_pass(gpu_api, oracle, spec, single):
     p = W.config2(seconds=2.0)
     sb, fb, g = p.build(gpu_api)
     osb, ofb, og = p.build(oracle)
     g.set_option("spec_normalize", spec)
+    g.set_option("single_pass_normalize", single)
+    fresh_two_pass = not (spec and single)
     got, fam = _families(g, lambda: g.render_all(sb, fb, p.cs, 16))
-    assert "k_scale" in fam and "k_norm_fix" not in fam          # un-scanned: running peak, two passes
+    # un-scanned: the running peak -- in ONE launch (k_norm1 / k_sum16w mode 5: the grid is resident at once, the tiles hand
+    # their maxima over through granules) or, with that switched off, the two passes k_sum + k_scale
+    assert ("k_scale" in fam) == fresh_two_pass and "k_norm_fix" not in fam
     assert_bit_exact(got, og.render_all(osb, ofb, p.cs, 16))
     g.true_normalize_scan(sb, fb, p.cs)
     og.true_normalize_scan(osb, ofb, p.cs)
@@ -38,7 +42,7 @@ def test_scanned_render_takes_the_single_pass(gpu_api, oracle, spec):
     g.reset_normalize_vertices()                                   # back to the running-peak form
     og.reset_normalize_vertices()
     got, fam = _families(g, lambda: g.render_all(sb, fb, p.cs, 16))
-    assert "k_scale" in fam and "k_norm_fix" not in fam
+    assert ("k_scale" in fam) == fresh_two_pass and "k_norm_fix" not in fam
     assert_bit_exact(got, og.render_all(osb, ofb, p.cs, 16))
 
 
@@ -104,3 +108,40 @@ def test_scanned_block_pulls_and_synth(gpu_api, oracle):
         assert np.array_equal(gl.view(np.uint32), ol.view(np.uint32)) and np.array_equal(gr.view(np.uint32), orr.view(np.uint32)), b
         gfb.set_time_to_next_block()
         ofb.set_time_to_next_block()
+
+
+@pytest.mark.parametrize("project", ["config1", "config2_short", "config2_edge", "drum", "chain", "nested"])
+@pytest.mark.parametrize("single", [1, 0])
+def test_fresh_single_pass_normalize_is_value_identical(gpu_api, oracle, project, single):
+    """Fresh (un-scanned) renders: the running-peak Normalize in one launch (option single_pass_normalize, default) against
+    the two passes and the oracle, bit for bit -- packed-loop, f32 edge-buffer, Adsr-through and nested-Normalize inputs,
+    rendered twice (the carried max moves on) and in chunks."""
+    if project == "config1":
+        p = W.config1(seconds=2.0)
+    elif project in ("config2_short", "config2_edge"):
+        p = W.config2(seconds=3.0, n_src=9)
+    elif project == "drum":
+        p = W.drum_project(seconds=2.0)
+    elif project == "chain":
+        p = W.config4(seconds=1.5, depth=6)
+    else:
+        p = W.ProjectScript(48000, 1024)
+        p.set_length(2.0)
+        for k in range(4):
+            p.assets["s%d" % k] = W.Asset(W.noise_int16(500 + k, 3001 + 517 * k))
+            p.load_sample("s%d" % k, "s%d" % k, "")
+            p.add_sampleloop("v%d" % k, 0.3 + 0.2 * k, -30.0 + 20.0 * k, "s%d" % k)
+        p.add_normalize("inner", 0.9, 5.0)
+        p.add_normalize("out", 1.0, 0.0)
+        for k in range(4):
+            p.connect("v%d" % k, "inner" if k < 2 else "out")
+        p.connect("inner", "out")
+        p.set_output("out")
+    gb, ob = p.build(gpu_api), p.build(oracle)
+    gb[2].set_option("single_pass_normalize", single)
+    if project == "config2_edge":
+        gb[2].set_option("fuse_sources", 0)
+    for rep in range(2):
+        assert_bit_exact(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
+    gb[2].set_option("max_chunk_frames", 9000)
+    assert_bit_exact(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
