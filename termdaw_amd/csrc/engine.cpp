@@ -1732,6 +1732,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SampsynDesc) + offsetof(SampsynDesc, tab);
+                        tab_field(o, offsetof(IntervalTab, tile_order), vt[vs[i]], vt[vs[i]].tile_order_off);
                         tab_field(o, offsetof(IntervalTab, istart), vt[vs[i]], vt[vs[i]].istart_off);
                         tab_field(o, offsetof(IntervalTab, tile_first), vt[vs[i]], vt[vs[i]].tile_first_off);
                         tab_field(o, offsetof(IntervalTab, ivoff), vt[vs[i]], vt[vs[i]].ivoff_off);
@@ -2844,15 +2845,27 @@ int td_graph_add_sampsyn(td_graph* g, const char* name, float gain, float angle,
         for (int i = 0; i < 2048; ++i) data[i] = (float)sin(2.0 * 3.14159265358979323846 * (double)i / 2048.0);
     }
     if (!ensure_device(g->device)) return 0;
+    // device layout: one 16-byte quad per (frame, index) holding the four samples the oscillator's two lerps read
+    // (tdk::WaveTableD): one gather per voice-frame instead of four
+    std::vector<float> quads(data.size() * 4);
+    for (uint32_t f = 0; f < nf; ++f) {
+        const uint32_t f1 = f + 1u < nf ? f + 1u : nf - 1u;
+        for (uint32_t i = 0; i < fl; ++i) {
+            const uint32_t i1 = i + 1u == fl ? 0u : i + 1u;
+            float* q = &quads[((size_t)f * fl + i) * 4];
+            q[0] = data[(size_t)f * fl + i];  q[1] = data[(size_t)f * fl + i1];
+            q[2] = data[(size_t)f1 * fl + i]; q[3] = data[(size_t)f1 * fl + i1];
+        }
+    }
     float* d_t = nullptr;
-    TD_HIP(hipMalloc(&d_t, data.size() * sizeof(float)));
-    TD_HIP(hipMemcpy(d_t, data.data(), data.size() * sizeof(float), hipMemcpyHostToDevice));
+    TD_HIP(hipMalloc(&d_t, quads.size() * sizeof(float)));
+    TD_HIP(hipMemcpy(d_t, quads.data(), quads.size() * sizeof(float), hipMemcpyHostToDevice));
     g->wavetables.push_back(d_t);
-    g->device_bytes += data.size() * sizeof(float);
+    g->device_bytes += quads.size() * sizeof(float);
     Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SAMPSYN);
     v.floww_index = floww_index;
     v.conf = c;
-    v.wavetable = WaveTableD{d_t, nf, fl, secs, 0u};
+    v.wavetable = WaveTableD{(const float4*)d_t, nf, fl, secs, 0u};
     return 1;
 }
 int td_graph_add_adsr(td_graph* g, const char* name, float gain, float angle, float wet, size_t floww_index,

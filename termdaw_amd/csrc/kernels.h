@@ -223,7 +223,7 @@ struct SynthDesc {
 // sampsyn_gen (extensions.rs:532-578) with this engine's own wavetable oscillator (the sampsyn crate is
 // un-vendored; DESIGN.md "Wavetable voice"): voice = (hz, vel, env_t at block start, rel_t)
 struct WaveTableD {
-    const float* data;      // [n_frames][frame_len]
+    const float4* quads;    // [n_frames][frame_len] of {w[f][i], w[f][i+1 wrapped], w[f+1 clamped][i], w[f+1 clamped][i+1 wrapped]}
     uint32_t n_frames, frame_len;
     float table_seconds;
     uint32_t pad;

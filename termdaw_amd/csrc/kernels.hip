@@ -1424,10 +1424,12 @@ TD_DEV float wavetable_act(const WaveTableD& w, float hz, float t) {
     if (f0 >= w.n_frames) f0 = w.n_frames - 1u;
     const float b = fp - (float)f0;
     const uint32_t f1 = f0 + 1u < w.n_frames ? f0 + 1u : w.n_frames - 1u;
-    const float* __restrict__ r0 = w.data + (size_t)f0 * w.frame_len;
-    const float* __restrict__ r1 = w.data + (size_t)f1 * w.frame_len;
-    const float s0 = lerpf(r0[i0], r0[i1], a);
-    const float s1 = lerpf(r1[i0], r1[i1], a);
+    // ONE 16-byte gather per voice-frame: the table is held as quads {w[f][i], w[f][i+1 wrapped], w[f+1 clamped][i],
+    // w[f+1 clamped][i+1 wrapped]} (four scattered dwords cost four L1 line look-ups per lane, which bounded this kernel)
+    (void)i1; (void)f1;
+    const float4 q = w.quads[(size_t)f0 * w.frame_len + i0];
+    const float s0 = lerpf(q.x, q.y, a);
+    const float s1 = lerpf(q.z, q.w, a);
     return lerpf(s0, s1, b);
 }
 TD_DEV float sampsyn_frame(const SampsynDesc& d, uint32_t m) {
@@ -1446,18 +1448,50 @@ TD_DEV float sampsyn_frame(const SampsynDesc& d, uint32_t m) {
     }
     return acc;
 }
+// one voice's contribution to frame m (extensions.rs:556-570): the same f32 operations as sampsyn_frame's loop body
+TD_DEV float sampsyn_voice(const SampsynDesc& d, const float4 n, float off) {   // n = (hz, vel, env_t at the block start, rel_t)
+    const float env_time = n.z + off;
+    const float env = n.w == 0.0f ? apply_ads(d.adsr, env_time) : apply_r_rt(d.adsr, env_time, n.w);
+    float s = 0.0f;
+    const float vel = n.y * env * d.amp_multiplier;
+    s += wavetable_act(d.wt, n.x, env_time + n.w) * vel;
+    return s;
+}
 __global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restrict__ descs, uint32_t M) {
     const SampsynDesc& d = descs[blockIdx.y];
-    const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
+    // (tiles with an interval start inside them first, as in k_synth: IntervalTab::tile_order)
+    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
+    const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
-    if (m0 < M) {
-        float a = sampsyn_frame(d, m0), b = (m0 + 1 < M) ? sampsyn_frame(d, m0 + 1) : 0.0f;
-        store_pair(d.out, m0, M, epilogue4(make_float4(a, a, b, b), d.pg));
+    // A wave's frames nearly always lie in ONE interval: the voice records then come in through scalar loads, once per wave,
+    // and the per-frame interval walk (two dependent loads and a loop per frame) is paid once.  Frames at or beyond M are
+    // computed on clamped indices and not stored.  Same f32 operations per frame and voice, in the same order: bit-exact.
+    const uint32_t mc[4] = {min(m0, M - 1u), min(m0 + 1u, M - 1u), min(m1, M - 1u), min(m1 + 1u, M - 1u)};
+    uint32_t it[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) it[e] = find_interval(d.tab, mc[e]);
+    const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)it[0]);
+    float v[4];
+    if (__all((it[0] == it0 && it[1] == it0 && it[2] == it0 && it[3] == it0) ? 1 : 0)) {
+        const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
+        const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
+        typedef float f4c __attribute__((ext_vector_type(4)));
+        const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
+        float off[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { off[e] = (float)(mc[e] % d.bl) / (float)d.sr; v[e] = 0.0f; }
+        for (uint32_t vi = v0; vi < v1; ++vi) {
+            const f4c q = vc[vi];
+            const float4 n = make_float4(q.x, q.y, q.z, q.w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += sampsyn_voice(d, n, off[e]);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sampsyn_frame(d, mc[e]);
     }
-    if (m1 < M) {
-        float a = sampsyn_frame(d, m1), b = (m1 + 1 < M) ? sampsyn_frame(d, m1 + 1) : 0.0f;
-        store_pair(d.out, m1, M, epilogue4(make_float4(a, a, b, b), d.pg));
-    }
+    if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(v[0], v[0], m0 + 1 < M ? v[1] : 0.0f, m0 + 1 < M ? v[1] : 0.0f), d.pg));
+    if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(v[2], v[2], m1 + 1 < M ? v[3] : 0.0f, m1 + 1 < M ? v[3] : 0.0f), d.pg));
 }
 
 // ------------------------------------------------------------------------------------------------
