@@ -1994,7 +1994,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             sp.pw_off = it->second;
                             if (piece.size() > 1) {   // k_band_chain: per-frame and per-wave-tile powers
                                 for (int c = 0; c < 2; ++c)
-                                    for (int n2 = 0; n2 < 16; ++n2) x.pn[c][n2] = (float)pow(q[c], (double)(n2 + 1));
+                                    for (int n2 = 0; n2 < 16; ++n2) x.pn[n2][c] = (float)pow(q[c], (double)(n2 + 1));
                                 x.Kw = sp.Kw;
                                 key.push_back('k');
                                 auto ik = scan_pw_off.find(key);

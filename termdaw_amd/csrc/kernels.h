@@ -362,7 +362,7 @@ struct BandStageDesc {          // one band-pass vertex
     uint32_t n_post, pad;
     BandPost post[3];
     // k_band_chain (a chain's launch; `pass` vertices only)
-    float pn[2][16];            // (1 - gamma)^(n + 1), n = 0 .. NF - 1: what an entry state still weighs after n + 1 frames
+    float pn[16][2];            // (1 - gamma)^(n + 1), n = 0 .. NF - 1, {low, high} smoother: what an entry state still weighs after n + 1 frames
     const double* pk;           // [2][kScanMaxK]: (1 - gamma)^(NF * 256 * j): the weight of the tile j + 1 tiles back
     uint32_t Kw, pad3;          // (= K)
 };

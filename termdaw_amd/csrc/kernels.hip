@@ -2871,6 +2871,18 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
 // (Tried and dropped, both bit-identical: every WAVE handing over for itself -- no barriers, but 2 816 pollers with a
 // four times deeper look-back: 0.71 ms for BASELINE config 4's 84 stages against 0.60; a wave owning two wave-tiles half
 // a timeline apart so that one's hand-off passes under the other's arithmetic -- 256 registers, two waves per SIMD: 1.22 ms.)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A double moved across lanes by DPP (two 32-bit moves on the VALU; no trip through the LDS crossbar as __shfl takes).
+// Lanes whose source lies outside the row / wave, or that the row mask leaves out, receive 0.
+template <int CTRL, int ROW_MASK>
+TD_DEV double dpp_f64(double v) {
+    const long long u = __double_as_longlong(v);
+    constexpr bool kAll = ROW_MASK == 0xF;   // (every row written: "no source -> 0" is the instruction's own bound_ctrl, no 0 to pre-load)
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, ROW_MASK, 0xF, kAll);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xF, kAll);
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+constexpr int kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 template <int TMODE>
 __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M) {
     constexpr int NF = 16, NP = NF / 2;
@@ -2924,10 +2936,26 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     const double* pw_cur = nullptr;
     const double* pk_cur = nullptr;
     double pwl = 1.0, pwh = 1.0;     // (1 - gamma)^(NF lane)
+    double w16l = 0.0, w16h = 0.0;   // (1 - gamma)^(NF ((lane % 16) + 1)): what the row before still weighs at this lane
+    double w32l = 0.0, w32h = 0.0;   // (1 - gamma)^(NF ((lane % 32) + 1)): ... the half wave before
     double pkl = 0.0, pkh = 0.0;     // (1 - gamma)^(NF 64 lane): the weight of the predecessor `lane` wave-tiles back
     double pkl2 = 0.0, pkh2 = 0.0;   // ... and of predecessor 64 + lane
     const bool tail = wt0 + WT > M;  // (uniform: only the chunk's last wave-tiles have frames beyond M)
     const bool fin_here = mlast >= wt0 && mlast - wt0 < WT;
+    // pan / gain over the lane's frames, each behind ONE uniform branch (written as per-element conditions they become
+    // a multiply AND a select per element whatever the flags are; the empty asm keeps the branch a branch)
+    auto pan_gain = [&x](float l_amp, float r_amp, float gain, uint32_t flags) {
+        if (flags & 1u) {
+            asm volatile("");
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { x[j].x *= l_amp; x[j].y *= r_amp; x[j].z *= l_amp; x[j].w *= r_amp; }
+        }
+        if (flags & 2u) {
+            asm volatile("");
+#pragma unroll
+            for (int j = 0; j < NP; ++j) { x[j].x *= gain; x[j].y *= gain; x[j].z *= gain; x[j].w *= gain; }
+        }
+    };
 
     for (uint32_t s = 0; s < n_stages; ++s) {
         const BandStageDesc TD_CONST* const sp = stages + s;
@@ -2936,6 +2964,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             pw_cur = sp->pw;
             pwl = pw_cur[lane];
             pwh = pw_cur[64u + lane];
+            w16l = pw_cur[(lane & 15u) + 1u]; w16h = pw_cur[64u + (lane & 15u) + 1u];
+            w32l = pw_cur[(lane & 31u) + 1u]; w32h = pw_cur[64u + (lane & 31u) + 1u];
         }
         if (sp->pk != pk_cur) {
             pk_cur = sp->pk;
@@ -2949,29 +2979,27 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         for (int q = 0; q < NP / 2; ++q)
             envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
         // ---- zero-state responses inside the lane's run
-        float zl[NF], zh[NF];
+        // (the {low, high} smoother pair of a frame is one packed operand from here to the output)
+        f32x2 z[NF];
         {
-            float a = 0.0f, b = 0.0f;
+            const f32x2 gam = {lgam, hgam};
+            f32x2 a = {0.0f, 0.0f};
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
-                a = __builtin_fmaf(lgam, x[j].x - a, a); b = __builtin_fmaf(hgam, x[j].x - b, b);
-                zl[2 * j] = a; zh[2 * j] = b;
-                a = __builtin_fmaf(lgam, x[j].z - a, a); b = __builtin_fmaf(hgam, x[j].z - b, b);
-                zl[2 * j + 1] = a; zh[2 * j + 1] = b;
+                a = __builtin_elementwise_fma(gam, f32x2{x[j].x, x[j].x} - a, a); z[2 * j] = a;
+                a = __builtin_elementwise_fma(gam, f32x2{x[j].z, x[j].z} - a, a); z[2 * j + 1] = a;
             }
         }
-        double b0 = (double)zl[NF - 1], b2 = (double)zh[NF - 1];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {   // inclusive scan over the wave: b_i += a^(NF * 2^q) b_(i - 2^q)
-            const uint32_t dd = 1u << q;
-            const double t0 = __shfl_up(b0, dd, 64), t2 = __shfl_up(b2, dd, 64);
-            if (lane >= dd) {
-                b0 = __builtin_fma(t0, sp->ap[0][q], b0);
-                b2 = __builtin_fma(t2, sp->ap[1][q], b2);
-            }
-        }
-        double e0 = __shfl_up(b0, 1u, 64), e2 = __shfl_up(b2, 1u, 64);   // the wave's response up to the lane's run
-        if (lane == 0u) { e0 = 0.0; e2 = 0.0; }
+        // ---- inclusive scan over the wave, on the VALU: b_i += a^(NF 2^q) b_(i - 2^q) inside the rows of 16 (a lane
+        // without a source adds a^.. * 0), then the row before (rows 1, 3), then the half wave before (rows 2, 3)
+        double b0 = (double)z[NF - 1].x, b2 = (double)z[NF - 1].y;
+        b0 = __builtin_fma(dpp_f64<kDppRowShr + 1, 0xF>(b0), sp->ap[0][0], b0); b2 = __builtin_fma(dpp_f64<kDppRowShr + 1, 0xF>(b2), sp->ap[1][0], b2);
+        b0 = __builtin_fma(dpp_f64<kDppRowShr + 2, 0xF>(b0), sp->ap[0][1], b0); b2 = __builtin_fma(dpp_f64<kDppRowShr + 2, 0xF>(b2), sp->ap[1][1], b2);
+        b0 = __builtin_fma(dpp_f64<kDppRowShr + 4, 0xF>(b0), sp->ap[0][2], b0); b2 = __builtin_fma(dpp_f64<kDppRowShr + 4, 0xF>(b2), sp->ap[1][2], b2);
+        b0 = __builtin_fma(dpp_f64<kDppRowShr + 8, 0xF>(b0), sp->ap[0][3], b0); b2 = __builtin_fma(dpp_f64<kDppRowShr + 8, 0xF>(b2), sp->ap[1][3], b2);
+        b0 = __builtin_fma(dpp_f64<kDppRowBcast15, 0xA>(b0), w16l, b0);         b2 = __builtin_fma(dpp_f64<kDppRowBcast15, 0xA>(b2), w16h, b2);
+        b0 = __builtin_fma(dpp_f64<kDppRowBcast31, 0xC>(b0), w32l, b0);         b2 = __builtin_fma(dpp_f64<kDppRowBcast31, 0xC>(b2), w32h, b2);
+        const double e0 = dpp_f64<kDppWaveShr1, 0xF>(b0), e2 = dpp_f64<kDppWaveShr1, 0xF>(b2);   // the wave's response up to the lane's run
         if (lane == 63u) { wtot[wave][0] = b0; wtot[wave][1] = b2; }
         __syncthreads();   // barrier 1: the four waves' totals
         double xw0 = 0.0, xw2 = 0.0, T0 = 0.0, T2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave / whole; a_wave^wave
@@ -3003,74 +3031,89 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 const unsigned long long u = (unsigned long long)__double_as_longlong(lane < 2u ? T0 : T2);
                 granule_store(sync + (size_t)tile * 8u + lane, (lane & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
             }
-        if (tile != 0u) {
-            const uint32_t n_pred = min(tile, sp->K);
-            for (uint32_t base = 0; base < n_pred; base += 64u) {   // (one trip unless the look-back is deeper than 64 tiles)
-                const uint32_t j = base + lane;
-                const bool mine = j < n_pred;
-                const unsigned long long* g = sync + (size_t)(tile - 1u - (mine ? j : 0u)) * 8u;
-                unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
-                for (;;) {
-                    bool ok = true;
-                    if (d.flags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
-                    if (mine) {
-                        g0 = granule_load(g); g1 = granule_load(g + 1); g2 = granule_load(g + 2); g3 = granule_load(g + 3);
-                        ok = (uint32_t)(g0 >> 32) == 1u && (uint32_t)(g1 >> 32) == 1u && (uint32_t)(g2 >> 32) == 1u && (uint32_t)(g3 >> 32) == 1u;
+            if (tile != 0u) {
+                const uint32_t n_pred = min(tile, sp->K);
+                for (uint32_t base = 0; base < n_pred; base += 64u) {   // (one trip unless the look-back is deeper than 64 tiles)
+                    const uint32_t j = base + lane;
+                    const bool mine = j < n_pred;
+                    const unsigned long long* g = sync + (size_t)(tile - 1u - (mine ? j : 0u)) * 8u;
+                    unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+                    for (;;) {
+                        bool ok = true;
+                        if (d.flags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
+                        if (mine) {
+                            g0 = granule_load(g); g1 = granule_load(g + 1); g2 = granule_load(g + 2); g3 = granule_load(g + 3);
+                            ok = (uint32_t)(g0 >> 32) == 1u && (uint32_t)(g1 >> 32) == 1u && (uint32_t)(g2 >> 32) == 1u && (uint32_t)(g3 >> 32) == 1u;
+                        }
+                        if (__all(ok ? 1 : 0)) break;
+                        __builtin_amdgcn_s_sleep(1);
                     }
-                    if (__all(ok ? 1 : 0)) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    if (mine) {
+                        const double B0 = __longlong_as_double((long long)((g0 & 0xFFFFFFFFull) | (g1 << 32)));
+                        const double B2 = __longlong_as_double((long long)((g2 & 0xFFFFFFFFull) | (g3 << 32)));
+                        C0 = __builtin_fma(base ? pkl2 : pkl, B0, C0);
+                        C2 = __builtin_fma(base ? pkh2 : pkh, B2, C2);
+                    }
                 }
-                if (mine) {
-                    const double B0 = __longlong_as_double((long long)((g0 & 0xFFFFFFFFull) | (g1 << 32)));
-                    const double B2 = __longlong_as_double((long long)((g2 & 0xFFFFFFFFull) | (g3 << 32)));
-                    C0 = __builtin_fma(base ? pkl2 : pkl, B0, C0);
-                    C2 = __builtin_fma(base ? pkh2 : pkh, B2, C2);
-                }
+                // the wave's sum into lane 63: running sums inside the rows, then row / half-wave totals passed on
+                C0 += dpp_f64<kDppRowShr + 1, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 1, 0xF>(C2);
+                C0 += dpp_f64<kDppRowShr + 2, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 2, 0xF>(C2);
+                C0 += dpp_f64<kDppRowShr + 4, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 4, 0xF>(C2);
+                C0 += dpp_f64<kDppRowShr + 8, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 8, 0xF>(C2);
+                C0 += dpp_f64<kDppRowBcast15, 0xA>(C0); C2 += dpp_f64<kDppRowBcast15, 0xA>(C2);
+                C0 += dpp_f64<kDppRowBcast31, 0xC>(C0); C2 += dpp_f64<kDppRowBcast31, 0xC>(C2);
             }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) { C0 += __shfl_xor(C0, off, 64); C2 += __shfl_xor(C2, off, 64); }
-        }
-            if (lane == 0u) { carry_s[0] = C0; carry_s[1] = C2; }
+            if (lane == 63u) { carry_s[0] = C0; carry_s[1] = C2; }
         }
         __syncthreads();   // barrier 2: the state entering the tile
         // the lane's entry state, exact arithmetic rounded once: e + a^(NF lane) (xw + a_wave^wave C)
-        const float c0 = (float)__builtin_fma(pwl, __builtin_fma(awp0, carry_s[0], xw0), e0);
-        const float c2 = (float)__builtin_fma(pwh, __builtin_fma(awp2, carry_s[1], xw2), e2);
-        // ---- output (extensions.rs:682-687 with cut_mul 0, pass_mul 1), pan / gain by uniform branches
-        PanGain pg;
-        pg.l_amp = sp->pg.l_amp; pg.r_amp = sp->pg.r_amp; pg.gain = sp->pg.gain; pg.flags = sp->pg.flags;
-        auto epi4 = [](float4 v, const PanGain& g4) {
-            if (g4.flags & 1u) { v.x *= g4.l_amp; v.y *= g4.r_amp; v.z *= g4.l_amp; v.w *= g4.r_amp; }
-            if (g4.flags & 2u) { v.x *= g4.gain; v.y *= g4.gain; v.z *= g4.gain; v.w *= g4.gain; }
-            return v;
-        };
+        const f32x2 c = {(float)__builtin_fma(pwl, __builtin_fma(awp0, carry_s[0], xw0), e0),
+                         (float)__builtin_fma(pwh, __builtin_fma(awp2, carry_s[1], xw2), e2)};
+        const f32x2 TD_CONST* const pn = (const f32x2 TD_CONST*)(const TD_CONST char*)sp->pn;
+        // ---- output (extensions.rs:682-687 with cut_mul 0, pass_mul 1), then the vertex' pan / gain
         const bool lo_on = lgam != 0.0f, hi_on = hgam != 0.0f;
-        float f0 = 0.f, f2 = 0.f;
-        bool has_fin = false;
+        if (fin_here) {   // the lane that holds the chunk's last frame carries the state over (one wave-tile of the chunk)
+            asm volatile("");
+            const uint32_t nl = mlast - mf;   // (< NF on that lane only)
+            f32x2 f = {0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            const float4 v = x[j];
-            const float ya0 = __builtin_fmaf(sp->pn[0][2 * j], c0, zl[2 * j]), ya2 = __builtin_fmaf(sp->pn[1][2 * j], c2, zh[2 * j]);
-            const float yb0 = __builtin_fmaf(sp->pn[0][2 * j + 1], c0, zl[2 * j + 1]), yb2 = __builtin_fmaf(sp->pn[1][2 * j + 1], c2, zh[2 * j + 1]);
-            const float ca = ((lo_on ? ya0 : 0.0f) + (hi_on ? v.x - ya2 : 0.0f)) * 0.5f;
-            const float cb = ((lo_on ? yb0 : 0.0f) + (hi_on ? v.z - yb2 : 0.0f)) * 0.5f;
-            if (fin_here) {
-                if (mf + 2u * (uint32_t)j == mlast) { f0 = ya0; f2 = ya2; has_fin = true; }
-                if (mf + 2u * (uint32_t)j + 1u == mlast) { f0 = yb0; f2 = yb2; has_fin = true; }
+            for (int n = 0; n < NF; ++n)
+                if (nl == (uint32_t)n) f = __builtin_elementwise_fma(pn[n], c, z[n]);
+            const bool has_fin = nl < (uint32_t)NF;
+            if (has_fin) {
+                if (!state_may_be_written) {
+                    while (__hip_atomic_load((gu32)(TD_GLOBAL char*)(d.ticket + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
+                        __builtin_amdgcn_s_sleep(8);
+                }
+                float* sf = reinterpret_cast<float*>(sp->state);
+                if (lo_on) sf[0] = f.x;
+                if (hi_on) sf[2] = f.y;
+                sp->state->first = 0u;
             }
-            x[j] = epi4(make_float4(v.x - ca, v.y - ca, v.z - cb, v.w - cb), pg);
+            state_may_be_written = state_may_be_written || __any(has_fin ? 1 : 0) != 0;
         }
-        if (has_fin) {   // the lane that holds the chunk's last frame carries the state over
-            if (!state_may_be_written) {
-                while (__hip_atomic_load((gu32)(TD_GLOBAL char*)(d.ticket + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u)
-                    __builtin_amdgcn_s_sleep(8);
+        if (lo_on && hi_on) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const float4 v = x[j];
+                const f32x2 ya = __builtin_elementwise_fma(pn[2 * j], c, z[2 * j]), yb = __builtin_elementwise_fma(pn[2 * j + 1], c, z[2 * j + 1]);
+                const float ca = (ya.x + (v.x - ya.y)) * 0.5f;
+                const float cb = (yb.x + (v.z - yb.y)) * 0.5f;
+                const f32x2 oa = f32x2{v.x, v.y} - f32x2{ca, ca}, ob = f32x2{v.z, v.w} - f32x2{cb, cb};
+                x[j] = make_float4(oa.x, oa.y, ob.x, ob.y);
             }
-            float* sf = reinterpret_cast<float*>(sp->state);
-            if (lo_on) sf[0] = f0;
-            if (hi_on) sf[2] = f2;
-            sp->state->first = 0u;
+        } else {
+            asm volatile("");
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const float4 v = x[j];
+                const f32x2 ya = __builtin_elementwise_fma(pn[2 * j], c, z[2 * j]), yb = __builtin_elementwise_fma(pn[2 * j + 1], c, z[2 * j + 1]);
+                const float ca = ((lo_on ? ya.x : 0.0f) + (hi_on ? v.x - ya.y : 0.0f)) * 0.5f;
+                const float cb = ((lo_on ? yb.x : 0.0f) + (hi_on ? v.z - yb.y : 0.0f)) * 0.5f;
+                x[j] = make_float4(v.x - ca, v.y - ca, v.z - cb, v.w - cb);
+            }
         }
-        if (fin_here) state_may_be_written = state_may_be_written || __any(has_fin ? 1 : 0) != 0;
+        pan_gain(sp->pg.l_amp, sp->pg.r_amp, sp->pg.gain, sp->pg.flags);
         if (s + 1u < n_stages) {
             // The links to the next band-pass vertex: an Adsr vertex multiplies by its gain of the frame (k_adsr_env), then
             // pan / gain; a single-input Sum is pan / gain only.  Every link and the next vertex start with their own
@@ -3079,8 +3122,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             const uint32_t np = sp->n_post;
             for (uint32_t p = 0; p < np; ++p) {
                 const float* env = sp->post[p].env;
-                PanGain lp;
-                lp.l_amp = sp->post[p].pg.l_amp; lp.r_amp = sp->post[p].pg.r_amp; lp.gain = sp->post[p].pg.gain; lp.flags = sp->post[p].pg.flags;
                 if (env) {
 #pragma unroll
                     for (int q = 0; q < NP / 2; ++q) {
@@ -3091,10 +3132,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                         x[2 * q + 1] = make_float4(b.x * e.z, b.y * e.z, b.z * e.w, b.w * e.w);
                     }
                 }
-                if (lp.flags) {
-#pragma unroll
-                    for (int j = 0; j < NP; ++j) x[j] = epi4(x[j], lp);
-                }
+                pan_gain(sp->post[p].pg.l_amp, sp->post[p].pg.r_amp, sp->post[p].pg.gain, sp->post[p].pg.flags);
             }
 #pragma unroll
             for (int j = 0; j < NP; ++j) x[j] = add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]);
