@@ -1104,7 +1104,9 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
 }
 
 // Tolerance-class band-pass (engine option "band_mode" 1, kernels.h BandScanDesc): tile = nf * 256 frames, look-back depth
-// K = tiles after which (1 - gamma)^(tile K) <= e^-band_depth for the slower smoother.  Not usable (-> the exact kernels)
+// K = tiles after which (1 - gamma)^(tile K) <= e^-band_scan_depth for the slower smoother (40 nats by default: what is cut
+// off is below 5e-18 of the largest state the chunk has seen -- this mode answers to an RMS bound on the output, not to the
+// exact kernels' bit-for-bit guess, which prices a past burst against the whole f32 exponent range: band_depth).  Not usable (-> the exact kernels)
 // when that takes more than kScanMaxK tiles (cut-offs below ~1.5 Hz) or the chunk is too long for 32-bit tile frames.
 struct ScanPlan {
     int nf = 16;
@@ -1123,7 +1125,7 @@ static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPla
         const double q = 1.0 - (double)gamma;
         if (!(q > 0.0)) continue;               // gamma = 1: the state is the last input frame
         const double per_tile = -tile * log(q); // nats of decay per tile
-        kmax = std::max(kmax, ceil((double)g->band_depth / per_tile));
+        kmax = std::max(kmax, ceil((double)g->band_scan_depth / per_tile));
     }
     if (!(kmax <= (double)kScanMaxK)) return false;
     sp->K = (uint32_t)kmax;
@@ -3180,6 +3182,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "band_medium") { g->band_medium = value > 0 ? (unsigned)value : 30u; return 1; }
     if (k == "band_guess_min") { g->band_guess_min = value > 0 ? (unsigned)value : 0u; return 1; }
     if (k == "band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
+    if (k == "band_scan_depth") { g->band_scan_depth = value > 0 ? (unsigned)value : 40u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }

@@ -2938,10 +2938,20 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     double pwl = 1.0, pwh = 1.0;     // (1 - gamma)^(NF lane)
     double w16l = 0.0, w16h = 0.0;   // (1 - gamma)^(NF ((lane % 16) + 1)): what the row before still weighs at this lane
     double w32l = 0.0, w32h = 0.0;   // (1 - gamma)^(NF ((lane % 32) + 1)): ... the half wave before
-    double pkl = 0.0, pkh = 0.0;     // (1 - gamma)^(NF 64 lane): the weight of the predecessor `lane` wave-tiles back
-    double pkl2 = 0.0, pkh2 = 0.0;   // ... and of predecessor 64 + lane
+    double pkl = 0.0, pkh = 0.0;     // (1 - gamma)^(NF 256 lane): the weight of the tile lane + 1 tiles back
+    double pkl2 = 0.0, pkh2 = 0.0;   // ... and of tile 65 + lane back
     const bool tail = wt0 + WT > M;  // (uniform: only the chunk's last wave-tiles have frames beyond M)
     const bool fin_here = mlast >= wt0 && mlast - wt0 < WT;
+    // (timing experiments, flags bit 2: the wave's clock at eight points of every stage, written over its frames of the
+    // output instead of the result -- tools/band_chain_phases.py)
+    const bool prof = (d.flags & 4u) != 0u;
+    unsigned long long* const pb = reinterpret_cast<unsigned long long*>(d.out + wt0);
+    if (prof && lane == 0u && wt0 + WT <= M) {   // where the wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, and its tile
+        pb[WT - 1u] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                      (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+        pb[WT - 2u] = tile;
+    }
+    auto stamp = [&](uint32_t s, uint32_t k) { if (prof && lane == 0u && s < WT / 8u && wt0 + WT <= M) pb[s * 8u + k] = __builtin_readcyclecounter(); };
     // pan / gain over the lane's frames, each behind ONE uniform branch (written as per-element conditions they become
     // a multiply AND a select per element whatever the flags are; the empty asm keeps the branch a branch)
     auto pan_gain = [&x](float l_amp, float r_amp, float gain, uint32_t flags) {
@@ -2959,6 +2969,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
 
     for (uint32_t s = 0; s < n_stages; ++s) {
         const BandStageDesc TD_CONST* const sp = stages + s;
+        stamp(s, 0u);
         const float lgam = sp->lgamma, hgam = sp->hgamma;
         if (sp->pw != pw_cur) {   // (uniform; the stages of a chain of identical filters share their tables: loaded once)
             pw_cur = sp->pw;
@@ -2990,6 +3001,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 a = __builtin_elementwise_fma(gam, f32x2{x[j].z, x[j].z} - a, a); z[2 * j + 1] = a;
             }
         }
+        stamp(s, 1u);
         // ---- inclusive scan over the wave, on the VALU: b_i += a^(NF 2^q) b_(i - 2^q) inside the rows of 16 (a lane
         // without a source adds a^.. * 0), then the row before (rows 1, 3), then the half wave before (rows 2, 3)
         double b0 = (double)z[NF - 1].x, b2 = (double)z[NF - 1].y;
@@ -3001,7 +3013,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         b0 = __builtin_fma(dpp_f64<kDppRowBcast31, 0xC>(b0), w32l, b0);         b2 = __builtin_fma(dpp_f64<kDppRowBcast31, 0xC>(b2), w32h, b2);
         const double e0 = dpp_f64<kDppWaveShr1, 0xF>(b0), e2 = dpp_f64<kDppWaveShr1, 0xF>(b2);   // the wave's response up to the lane's run
         if (lane == 63u) { wtot[wave][0] = b0; wtot[wave][1] = b2; }
+        stamp(s, 2u);
         __syncthreads();   // barrier 1: the four waves' totals
+        stamp(s, 3u);
         double xw0 = 0.0, xw2 = 0.0, T0 = 0.0, T2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave / whole; a_wave^wave
 #pragma unroll
         for (uint32_t w = 0; w < 4u; ++w) {
@@ -3031,6 +3045,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 const unsigned long long u = (unsigned long long)__double_as_longlong(lane < 2u ? T0 : T2);
                 granule_store(sync + (size_t)tile * 8u + lane, (lane & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u);
             }
+            stamp(s, 4u);
             if (tile != 0u) {
                 const uint32_t n_pred = min(tile, sp->K);
                 for (uint32_t base = 0; base < n_pred; base += 64u) {   // (one trip unless the look-back is deeper than 64 tiles)
@@ -3038,10 +3053,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                     const bool mine = j < n_pred;
                     const unsigned long long* g = sync + (size_t)(tile - 1u - (mine ? j : 0u)) * 8u;
                     unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
+                    bool ok = !mine;
                     for (;;) {
-                        bool ok = true;
                         if (d.flags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
-                        if (mine) {
+                        if (!ok) {   // (a lane whose four words have arrived reads no more: the queue is left to the late ones)
                             g0 = granule_load(g); g1 = granule_load(g + 1); g2 = granule_load(g + 2); g3 = granule_load(g + 3);
                             ok = (uint32_t)(g0 >> 32) == 1u && (uint32_t)(g1 >> 32) == 1u && (uint32_t)(g2 >> 32) == 1u && (uint32_t)(g3 >> 32) == 1u;
                         }
@@ -3064,8 +3079,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 C0 += dpp_f64<kDppRowBcast31, 0xC>(C0); C2 += dpp_f64<kDppRowBcast31, 0xC>(C2);
             }
             if (lane == 63u) { carry_s[0] = C0; carry_s[1] = C2; }
+            stamp(s, 5u);
         }
         __syncthreads();   // barrier 2: the state entering the tile
+        stamp(s, 6u);
         // the lane's entry state, exact arithmetic rounded once: e + a^(NF lane) (xw + a_wave^wave C)
         const f32x2 c = {(float)__builtin_fma(pwl, __builtin_fma(awp0, carry_s[0], xw0), e0),
                          (float)__builtin_fma(pwh, __builtin_fma(awp2, carry_s[1], xw2), e2)};
@@ -3097,9 +3114,10 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             for (int j = 0; j < NP; ++j) {
                 const float4 v = x[j];
                 const f32x2 ya = __builtin_elementwise_fma(pn[2 * j], c, z[2 * j]), yb = __builtin_elementwise_fma(pn[2 * j + 1], c, z[2 * j + 1]);
-                const float ca = (ya.x + (v.x - ya.y)) * 0.5f;
-                const float cb = (yb.x + (v.z - yb.y)) * 0.5f;
-                const f32x2 oa = f32x2{v.x, v.y} - f32x2{ca, ca}, ob = f32x2{v.z, v.w} - f32x2{cb, cb};
+                // (l - cut, r - cut), cut = (low + (l - high)) / 2: the halving is exact, so it rides in the subtraction's fma
+                const float sa = ya.x + (v.x - ya.y), sb = yb.x + (v.z - yb.y);
+                const f32x2 mh = {-0.5f, -0.5f};
+                const f32x2 oa = __builtin_elementwise_fma(f32x2{sa, sa}, mh, f32x2{v.x, v.y}), ob = __builtin_elementwise_fma(f32x2{sb, sb}, mh, f32x2{v.z, v.w});
                 x[j] = make_float4(oa.x, oa.y, ob.x, ob.y);
             }
         } else {
@@ -3114,11 +3132,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             }
         }
         pan_gain(sp->pg.l_amp, sp->pg.r_amp, sp->pg.gain, sp->pg.flags);
+        stamp(s, 7u);
         if (s + 1u < n_stages) {
             // The links to the next band-pass vertex: an Adsr vertex multiplies by its gain of the frame (k_adsr_env), then
             // pan / gain; a single-input Sum is pan / gain only.  Every link and the next vertex start with their own
-            // sum_inputs `0.0 + x`, whose only effect is -0 -> +0; a zero stays a zero through the multiplies in between, so
-            // ONE `0.0 + x` at the end leaves the same bits.  Frames at or beyond M become 0, as sum_terms leaves them.
+            // sum_inputs `0.0 + x`, whose only effect is -0 -> +0: a zero's sign moves no value anywhere in the next stage,
+            // and what reads the chain's output starts with a `0.0 + x` of its own -- none here (tolerance class).
+            // Frames at or beyond M become 0, as sum_terms leaves them.
             const uint32_t np = sp->n_post;
             for (uint32_t p = 0; p < np; ++p) {
                 const float* env = sp->post[p].env;
@@ -3134,14 +3154,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 }
                 pan_gain(sp->post[p].pg.l_amp, sp->post[p].pg.r_amp, sp->post[p].pg.gain, sp->post[p].pg.flags);
             }
-#pragma unroll
-            for (int j = 0; j < NP; ++j) x[j] = add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]);
             if (tail) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
             }
         }
     }
+    if (prof) return;
     // the last vertex' output, back through the wave's staging for coalesced stores
 #pragma unroll
     for (int j = 0; j < NP; ++j) xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];
