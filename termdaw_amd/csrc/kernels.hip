@@ -2894,7 +2894,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     __shared__ double wtot[kThreads / 64][2];
     __shared__ double carry_s[2];
     __shared__ uint32_t tile_s;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));   // (wave: a scalar, its branches are branches)
     const uint32_t n_stages = d.n_stages;
     const BandStageDesc TD_CONST* const stages = (const BandStageDesc TD_CONST*)(const TD_CONST char*)d.stages;   // (uniform: scalar loads)
     if (tid == 0u) tile_s = atomicAdd(d.ticket, 1u);
@@ -3016,16 +3016,21 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         stamp(s, 2u);
         __syncthreads();   // barrier 1: the four waves' totals
         stamp(s, 3u);
-        double xw0 = 0.0, xw2 = 0.0, T0 = 0.0, T2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave / whole; a_wave^wave
-#pragma unroll
-        for (uint32_t w = 0; w < 4u; ++w) {
-            if (w == wave) { xw0 = T0; xw2 = T2; }
-            if (w < wave) { awp0 *= sp->aw[0]; awp2 *= sp->aw[1]; }
-            T0 = __builtin_fma(T0, sp->aw[0], wtot[w][0]);
-            T2 = __builtin_fma(T2, sp->aw[1], wtot[w][1]);
+        double xw0 = 0.0, xw2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave; a_wave^wave
+        for (uint32_t w = 0; w < wave; ++w) {   // (uniform trip count)
+            awp0 *= sp->aw[0]; awp2 *= sp->aw[1];
+            xw0 = __builtin_fma(xw0, sp->aw[0], wtot[w][0]);
+            xw2 = __builtin_fma(xw2, sp->aw[1], wtot[w][1]);
         }
         if (wave == 0u) {
-            // state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
+            // the whole tile's response (wave 0: xw is still 0), then the state at the chunk's first frame: carried, or seeded
+            // from buf[0] (extensions.rs:664-670)
+            double T0 = 0.0, T2 = 0.0;
+#pragma unroll
+            for (uint32_t w = 0; w < 4u; ++w) {
+                T0 = __builtin_fma(T0, sp->aw[0], wtot[w][0]);
+                T2 = __builtin_fma(T2, sp->aw[1], wtot[w][1]);
+            }
             double C0 = 0.0, C2 = 0.0;
             unsigned long long* const sync = sp->sync;
             if (tile == 0u) {
@@ -3143,10 +3148,15 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             for (uint32_t p = 0; p < np; ++p) {
                 const float* env = sp->post[p].env;
                 if (env) {
+                    if (env != env_pre) {   // (a second envelope link of the same hop: not prefetched)
+                        asm volatile("");
+#pragma unroll
+                        for (int q = 0; q < NP / 2; ++q)
+                            envv[q] = mf + 4u * (uint32_t)q < M ? gload4(env + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
 #pragma unroll
                     for (int q = 0; q < NP / 2; ++q) {
-                        const float4 e = env == env_pre ? envv[q]
-                                       : mf + 4u * (uint32_t)q < M ? gload4(env + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        const float4 e = envv[q];
                         const float4 a = x[2 * q], b = x[2 * q + 1];
                         x[2 * q] = make_float4(a.x * e.x, a.y * e.x, a.z * e.y, a.w * e.y);
                         x[2 * q + 1] = make_float4(b.x * e.z, b.y * e.z, b.z * e.w, b.w * e.w);
