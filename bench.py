@@ -507,10 +507,11 @@ def main():
         value = total_frames / dt / 1e6
         fused, packed = not args.no_fuse, not args.no_pack
         abf = algorithmic_bytes_per_frame(N_SRC, fused, packed)
-        single_pass = fused and "k_scale" not in ktimes and "k_norm_fix" in ktimes
+        single_pass = fused and "k_scale" not in ktimes
         if single_pass:
-            # SumDesc mode 4 (engine option single_pass_normalize): the running peak is found inside the summing launch through
-            # granules, the frames leave the registers as int16 PCM -- no raw-sum write, no pass B
+            # SumDesc modes 4 / 5 (engine option single_pass_normalize): the running peak is found inside the summing launch
+            # through granules, the frames leave the registers as int16 PCM -- no raw-sum write, no pass B (mode 4 keeps a
+            # k_norm_fix check launch for grids that are not resident at once; mode 5, the resident grid, is this ONE launch)
             abf["k_sum"] = (4.0 if packed else 8.0) * N_SRC + 4.0
         survey_abf = algorithmic_bytes_per_frame(N_SRC, False, False)   # SURVEY 8(d) edge-buffer figure
         ub = None
@@ -572,7 +573,7 @@ def main():
                                "WRITE_SIZE); fabric-side bytes: Infinity-Cache hits are included, so HBM bytes are at most this"}}
             if name == "k_sum" and fused and packed and gather_ms and gather_ms > 0:
                 ceil_gbs = bytes_per_launch / (gather_ms * 1e-3) / 1e9
-                compulsory = (int(lens.sum()) * 4 + 8 * frames) * P
+                compulsory = (int(lens.sum()) * 4 + (4 if single_pass else 8) * frames) * P
                 row.update({"bound": "cache-gather ceiling (measured)", "peak": round(ceil_gbs, 1), "frac": round(gbs / ceil_gbs, 4),
                             "ceiling_ms": round(gather_ms, 5),
                             "ceiling_l2_resident_GBs": None if not gather_l2_ms else round(bytes_per_launch / (gather_l2_ms * 1e-3) / 1e9, 1),
@@ -580,13 +581,19 @@ def main():
                             "hbm_compulsory_bytes": compulsory,
                             "hbm_compulsory_frac": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "bytes_per_frame": abf[name],
-                            "note": "source inlining: k_sum's algorithmic bytes are its own gathers, (4k+8) B/frame -- k looping samples "
-                                    "read in place in their packed 16-bit form + one raw-sum write.  The gathers re-read a %.0f MB "
-                                    "sample set ~37x per launch, so they are cache hits, not HBM traffic: `peak` is the rate at which "
-                                    "tools/ubench/ceilings.hip performs the SAME gathers and the same 8 B/frame write with the arithmetic "
-                                    "removed (best of three issue depths, same lengths, same grid, this process, this device); "
-                                    "`hbm_compulsory_frac` prices the bytes that must cross HBM once (packed samples + sum write) "
-                                    "against 8 TB/s" % (lens.sum() * 4 / 1e6)})
+                            "note": ("source inlining: k_sum's algorithmic bytes are its own gathers, %s -- k looping samples "
+                                     "read in place in their packed 16-bit form + %s.  The gathers re-read a %.0f MB "
+                                     "sample set ~37x per launch, so they are cache hits, not HBM traffic: `peak` is the rate at which "
+                                     "tools/ubench/ceilings.hip performs the SAME gathers and an 8 B/frame write with the arithmetic "
+                                     "removed (best of three issue depths, same lengths, same grid, this process, this device)%s; "
+                                     "`hbm_compulsory_frac` prices the bytes that must cross HBM once (packed samples + the output write) "
+                                     "against 8 TB/s") % (
+                                        ("(4k+4) B/frame", "one int16 PCM write (the launch also finds the running peak through in-launch "
+                                         "granules, scales and quantises: single_pass_normalize)") if single_pass else
+                                        ("(4k+8) B/frame", "one raw-sum write"),
+                                        lens.sum() * 4 / 1e6,
+                                        " -- frac = ceiling_ms / avg_ms; the ceiling kernel writes 4 B/frame more than this launch "
+                                        "(%.1f us at 8 TB/s) and does none of its peak hand-off" % (4.0 * frames * P / 8e12 * 1e6) if single_pass else "")})
             else:
                 row.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
                             "frac_of_measured_copy": round(gbs / copy_gbs, 4), "bytes_per_frame": abf.get(name)})
@@ -653,7 +660,9 @@ def main():
                                    "per GPU per step (project p of the job on rank p mod N, seed offset 64*p)" % (args.seconds, P),
                        "frames_per_project": frames, "projects_per_gpu": P, "vertices_per_project": N_SRC + 1,
                        "source_inlining": not args.no_fuse, "packed_samples": (not args.no_fuse) and (not args.no_pack),
-                       "normalize": "single pass: running peak through in-launch granules (k_sum16w mode 4) + k_norm_fix check" if single_pass
+                       "normalize": ("single pass, ONE launch: sum, running peak through in-launch granules, scale and quantise (k_sum16w mode 5)"
+                                     if "k_norm_fix" not in ktimes else
+                                     "single pass: running peak through in-launch granules (k_sum16w mode 4) + k_norm_fix check") if single_pass
                                     else "two passes: k_sum (sum + block peaks), k_scale",
                        "output": "int16 PCM in HBM (engine option output_f32 0: no f32 copy of the output vertex is kept)",
                        "parallelism": "projects sharded across GPUs; RCCL all-reduce(max) of the %d-entry peak table only" % (P * world)},

@@ -1616,7 +1616,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         uint32_t max_nseg = 0;
         for (int fam = 0; fam < F_COUNT; ++fam) {
             auto& vs = fam_v[fam];
-            if (fam == F_BAND_FIX || fam == F_BAND_FILL) vs = fam_v[F_BAND_SPEC];   // same vertices, follow-up launches
+            if (fam == F_BAND_FILL) continue;   // (the parked stretches' output is filled in by k_band_fix itself)
+            if (fam == F_BAND_FIX) vs = fam_v[F_BAND_SPEC];   // same vertices, follow-up launch
             if (vs.empty() && !(fam == F_SUM && !fam_v[F_BAND_SPEC].empty())) continue;
             size_t off = 0;
             switch (fam) {
@@ -1945,7 +1946,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         scratch_field(o, offsetof(BandSpecDesc, seg_x0), scratch((size_t)ns * 8));
                         scratch_field(o, offsetof(BandSpecDesc, jobs), scratch((size_t)ns * sizeof(BandJob)));
                         scratch_field(o, offsetof(BandSpecDesc, seg_job), scratch((size_t)ns * 4));
-                        const size_t so = scratch(32);
+                        const size_t so = scratch(256);   // counters [0..7], verdict + fill claims on a line of their own [32..33]
                         scratch_field(o, offsetof(BandSpecDesc, stats), so);
                         g->band_stats_off.push_back(so);
                     }
@@ -2295,7 +2296,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_BAND: launch_band_pass((const BandDesc*)d, L.n, L.M, s); break;
                 case F_BAND_SPEC: launch_band_spec((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
-                case F_BAND_FILL: launch_band_fill((const BandSpecDesc*)d, L.n, L.M, s); break;
+                case F_BAND_FILL: break;
                 case F_BAND_SCAN:
                     if (L.aux & 0x10000u) launch_band_chain((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, s);
                     else launch_band_scan((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)((L.aux >> 8) & 0xFFu), s);

@@ -420,7 +420,6 @@ void launch_peak_table(const float* const* src, float* table, uint32_t n_total, 
 
 void launch_band_spec(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
 void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_t max_nseg, hipStream_t s);
-void launch_band_fill(const BandSpecDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 // every descriptor of one launch_sum call has the same term_mode (the engine groups them)
 // k_norm1 (SumDesc mode 5 outside the wide all-loop sums): tiles per workgroup (1 | 2 | 4) with which the whole grid of a
 // `frames`-long chunk is resident at once, 0 if none; and its launch

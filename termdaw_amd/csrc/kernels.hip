@@ -1772,9 +1772,10 @@ TD_DEV float2 band_out(const BandCoef& k, float l, float r, float ll, float lr, 
     return make_float2(cutl * k.cut_mul + passl * k.pass_mul, cutr * k.cut_mul + passr * k.pass_mul);
 }
 
+constexpr uint32_t kNoJob = 0xFFFFFFFFu;   // BandSpecDesc::seg_job: the segment lies in no parked stretch
 __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __restrict__ descs, uint32_t M) {
     const BandSpecDesc& d = descs[blockIdx.y];
-    if (blockIdx.x == 0 && threadIdx.x < 8u) d.stats[threadIdx.x] = 0u;   // k_band_fix's counters and ticket
+    if (blockIdx.x == 0 && threadIdx.x < 40u) d.stats[threadIdx.x] = 0u;   // k_band_fix's counters and ticket [0..7]; verdict and fill claims [32..33]
     const uint32_t c = threadIdx.x & 3u;                       // chain: 0 low L, 1 low R, 2 high L, 3 high R
     const uint32_t seg_raw = blockIdx.x * (kThreads / 4) + (threadIdx.x >> 2);
     if (blockIdx.x * (kThreads / 4) >= d.nseg) return;         // whole workgroup beyond this vertex' segments
@@ -1782,6 +1783,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     // store nothing
     const bool live = seg_raw < d.nseg;
     const uint32_t seg = live ? seg_raw : d.nseg - 1u;
+    if (live && c == 0u) d.seg_job[seg_raw] = kNoJob;   // (k_band_fix parks stretches; whoever fills them finds every other segment marked free)
     const uint32_t ch = c & 1u;
     const float gam = (c & 2u) ? d.hgamma : d.lgamma;
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
@@ -2127,7 +2129,6 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
 constexpr int kFixThreads = 1024, kFixWaves = kFixThreads / 64;
 constexpr uint32_t kFixMaxSegs = 131072;   // LDS bitmap capacity (host picks S accordingly)
 constexpr uint32_t kFixMaxEvents = 2048;   // events repaired per round (the rest wait for the next round)
-constexpr uint32_t kNoJob = 0xFFFFFFFFu;
 
 // One event: wave-wide.  Lanes 0..3 = the four chains on the TRUE trajectory, lanes 4..7 re-run the
 // speculative one from the entry state pass 1 used (as soon as the two are bit-identical the rest of the
@@ -2385,23 +2386,73 @@ TD_DEV bool band_fix_range(const BandSpecDesc& d, uint32_t M, uint32_t lo, uint3
     return any;
 }
 
-// grid (G, vertices): workgroup g first settles its own slice of the segments (cascades stop at the slice
+// Output of the parked stretches recorded by k_band_fix: the four states are constants, every frame's output follows from
+// its own input frame -- fully parallel.  seg_job maps a segment to the job covering it.  Tiles are claimed from a counter
+// (stats[33]) by whoever takes part.
+TD_DEV void band_fill_tiles(const BandSpecDesc& d, uint32_t M, uint32_t* claim_s) {
+    const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
+    constexpr uint32_t kPer = 8u;            // frames per thread and claim
+    const uint32_t span = kPer * blockDim.x;
+    const uint32_t n_claims = (uint32_t)(((uint64_t)M + span - 1u) / span);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0u) *claim_s = atomicAdd(&d.stats[33], 1u);
+        __syncthreads();
+        const uint32_t t = *claim_s;
+        if (t >= n_claims) return;
+#pragma unroll
+        for (uint32_t q = 0; q < kPer; ++q) {
+            const uint64_t m64 = (uint64_t)t * span + q * blockDim.x + threadIdx.x;   // (64-bit: M may sit near 2^32)
+            if (m64 >= M) break;
+            const uint32_t m = (uint32_t)m64;
+            const uint32_t j = d.seg_job[m / d.S];
+            if (j == kNoJob) continue;
+            const BandJob jb = d.jobs[j];
+            if (m < jb.begin || m >= jb.end) continue;
+            const float2 x = d.x[m];
+            d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
+        }
+    }
+}
+constexpr uint32_t kFillHelperPolls = 4096;   // a helper that has not seen the verdict by then (~ms) leaves: the others fill
+
+// grid (G + H, vertices).  Workgroup g < G first settles its own slice of the segments (cascades stop at the slice
 // end, the slice's first event trusts whatever exit state its left neighbour shows at the time), then the
 // workgroup that finishes LAST (ticket in stats[4]; no spinning) checks the slice borders and, if one fails,
 // repeats the rounds over all segments; the slices' all-clears plus the border check (or that global all-clear)
 // are the proof for the whole vertex.  stats[] is zeroed by k_band_spec.
-__global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __restrict__ descs, uint32_t M) {
+// That last workgroup then gives the verdict in stats[32] (a cache line of its own: the cascades' counters are busy): 1 = no parked stretch (nearly always), 2 = parked stretches
+// recorded -- their output is filled in right here instead of by a launch of its own (84 launches of config 4's 341):
+// by that workgroup and by the H helper workgroups (blockIdx.x >= G), which have done nothing but poll that word since they
+// started.  Tiles are claimed from a counter, so the fill is complete when the last workgroup's loop ends whether or
+// not a helper ever shows up (no assumption on dispatch order or residency); a helper that never sees a verdict leaves.
+__global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __restrict__ descs, uint32_t M, uint32_t G) {
     const BandSpecDesc& d = descs[blockIdx.y];
     __shared__ BandFixLds L;
     __shared__ uint32_t ticket_s;
     const uint32_t tid = threadIdx.x;
-    const uint32_t G = gridDim.x;
+    if (blockIdx.x >= G) {   // helper
+        if (tid == 0u) {
+            uint32_t v = 0u;
+            for (uint32_t i = 0; i < kFillHelperPolls; ++i) {
+                v = __hip_atomic_load(&d.stats[32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v) break;
+                __builtin_amdgcn_s_sleep(64);
+            }
+            ticket_s = v;
+        }
+        __syncthreads();
+        if (ticket_s != 2u) return;
+        if (tid == 0u) __threadfence();   // acquire the jobs: ONE lane's fence (it empties this CU's L1), the barrier hands it on
+        __syncthreads();
+        band_fill_tiles(d, M, &ticket_s);
+        return;
+    }
     const uint32_t per = (((d.nseg + G - 1u) / G) + 63u) & ~63u;
     const uint32_t lo = min(blockIdx.x * per, d.nseg), hi = min(lo + per, d.nseg);
-    for (uint32_t s = lo + tid; s < hi; s += kFixThreads) d.seg_job[s] = kNoJob;
     if (G > 1u) {
         const bool any = lo < hi && band_fix_range(d, M, lo, hi, L);
-        if (any) __threadfence();   // release what this slice's repairs stored
+        if (any) __threadfence();   // release what this slice's repairs stored (and the jobs they parked)
         __syncthreads();
         if (tid == 0) ticket_s = atomicAdd(&d.stats[4], any ? 0x10001u : 1u);
         __syncthreads();
@@ -2431,26 +2482,14 @@ __global__ __launch_bounds__(kFixThreads) void k_band_fix(const BandSpecDesc* __
     __syncthreads();
     if (tid < 4u) reinterpret_cast<uint32_t*>(d.state)[tid] = reinterpret_cast<const uint32_t*>(d.seg_final)[(d.nseg - 1u) * 4u + tid];
     if (tid == 0u) d.state->first = 0u;
-}
-
-// Output of the parked stretches recorded by k_band_fix: the four states are constants, every frame's
-// output follows from its own input frame -- fully parallel.  seg_job maps a segment to the job covering it.
-__global__ __launch_bounds__(kThreads) void k_band_fill(const BandSpecDesc* __restrict__ descs, uint32_t M) {
-    const BandSpecDesc& d = descs[blockIdx.y];
-    if (d.stats[3] == 0u) return;   // (no job: the usual case -- which is why the grid is a few hundred workgroups, not one per tile)
-    const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
-    for (uint64_t tile0 = (uint64_t)blockIdx.x * kTileFrames; tile0 < M; tile0 += (uint64_t)gridDim.x * kTileFrames)   // (64-bit: M may sit near 2^32)
-        for (uint32_t f = threadIdx.x; f < (uint32_t)kTileFrames; f += kThreads) {
-            if (tile0 + f >= M) break;
-            const uint32_t m = (uint32_t)tile0 + f;
-            if (m >= M) break;
-            const uint32_t j = d.seg_job[m / d.S];
-            if (j == kNoJob) continue;
-            const BandJob jb = d.jobs[j];
-            if (m < jb.begin || m >= jb.end) continue;
-            const float2 x = d.x[m];
-            d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
-        }
+    // ---- the verdict, and the parked stretches' output
+    if (tid == 0u) ticket_s = __hip_atomic_load(&d.stats[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const bool jobs = ticket_s != 0u;
+    if (jobs && tid == 0u) __threadfence();   // (release this workgroup's own jobs -- stored before the barrier above --, acquire everybody else's)
+    __syncthreads();
+    if (tid == 0u) __hip_atomic_store(&d.stats[32], jobs ? 2u : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (jobs) band_fill_tiles(d, M, &ticket_s);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2884,11 +2923,14 @@ TD_DEV double dpp_f64(double v) {
 }
 constexpr int kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 template <int TMODE>
-__global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M) {
+__global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M, uint32_t chains_in_x) {
     constexpr int NF = 16, NP = NF / 2;
     constexpr uint32_t WT = (uint32_t)NF * 64u;         // frames per wave-tile
-    const BandScanDesc& d = descs[blockIdx.y];
-    if (blockIdx.x >= d.n_tiles) return;
+    // Several chains in one launch (a batch of projects): the chain index is the FAST grid dimension, so the workgroups
+    // the device holds at a time belong to all of them -- chains are independent of each other and each one's tiles move in
+    // lockstep from hop to hop; side by side on a CU, one's arithmetic runs under another's hop.
+    const BandScanDesc& d = descs[chains_in_x ? blockIdx.x : blockIdx.y];
+    if ((chains_in_x ? blockIdx.y : blockIdx.x) >= d.n_tiles) return;
     __shared__ float4 xt[kThreads * (NP + 1)];          // staging, one quarter per wave: lane-major, one pad word per lane run
     __shared__ float st_l[kScanMaxStages][5];           // tile 0: every stage's carried state {y[4], first} as the launch found it
     __shared__ double wtot[kThreads / 64][2];
@@ -3490,14 +3532,14 @@ void launch_band_spec(const BandSpecDesc* d, int n, uint32_t frames, uint32_t ma
     if (!n || !frames) return;
     TD_BATCHED(k_band_spec, (max_nseg + kThreads / 4 - 1) / (kThreads / 4), kThreads, d, n, frames);
 }
-void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max_nseg, hipStream_t s) {    // (slice, vertex)
+void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max_nseg, hipStream_t s) {    // (slice + helpers, vertex)
     if (n <= 0) return;
     const uint32_t G = std::max(1u, std::min(16u, max_nseg / 512u));
-    hipLaunchKernelGGL(k_band_fix, dim3(G, n), dim3(kFixThreads), 0, s, d, frames);
-}
-void launch_band_fill(const BandSpecDesc* d, int n, uint32_t frames, hipStream_t s) {
-    if (!n || !frames) return;
-    TD_BATCHED(k_band_fill, std::min(tiles(frames), 1024u), kThreads, d, n, frames);
+    // helpers for the parked stretches' output (k_band_fix): enough workgroups to stream a long timeline, none for a block pull
+    static const int h_env = getenv("TD_FILL_HELPERS") ? atoi(getenv("TD_FILL_HELPERS")) : -1;   // (experiments)
+    const uint32_t H = h_env >= 0 ? (uint32_t)h_env : std::min(240u, tiles(frames) / 8u);
+    for (int o = 0; o < n; o += kMaxGridY)
+        hipLaunchKernelGGL(k_band_fix, dim3(G + H, std::min(n - o, kMaxGridY)), dim3(kFixThreads), 0, s, d + o, frames, G);
 }
 template <int MODE>
 static void launch_band_scan_mode(const BandScanDesc* d, int n, uint32_t frames, uint32_t gx, int nf, hipStream_t s) {
@@ -3520,12 +3562,19 @@ void launch_band_scan(const BandScanDesc* d, int n, uint32_t frames, uint32_t te
 void launch_band_chain(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tile = band_scan_tile_frames(16), gx = (frames + tile - 1u) / tile;
+    void (*k)(const BandScanDesc*, uint32_t, uint32_t) = nullptr;
     switch (term_mode) {
-        case TERMS_EDGE_FEW: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_EDGE_FEW>), gx, kThreads, d, n, frames); break;
-        case TERMS_ALL_EDGE: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_ALL_EDGE>), gx, kThreads, d, n, frames); break;
-        case TERMS_ADSR1: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_ADSR1>), gx, kThreads, d, n, frames); break;
-        case TERMS_WITH_ADSR: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_WITH_ADSR>), gx, kThreads, d, n, frames); break;
-        default: TD_BATCHED(HIP_KERNEL_NAME(k_band_chain<TERMS_MIXED>), gx, kThreads, d, n, frames); break;
+        case TERMS_EDGE_FEW: k = k_band_chain<TERMS_EDGE_FEW>; break;
+        case TERMS_ALL_EDGE: k = k_band_chain<TERMS_ALL_EDGE>; break;
+        case TERMS_ADSR1: k = k_band_chain<TERMS_ADSR1>; break;
+        case TERMS_WITH_ADSR: k = k_band_chain<TERMS_WITH_ADSR>; break;
+        default: k = k_band_chain<TERMS_MIXED>; break;
+    }
+    if (gx <= (uint32_t)kMaxGridY) {   // chains along x (dispatched round-robin), tiles along y
+        hipLaunchKernelGGL(k, dim3((uint32_t)n, gx), dim3(kThreads), 0, s, d, frames, 1u);
+    } else {
+        for (int o = 0; o < n; o += kMaxGridY)
+            hipLaunchKernelGGL(k, dim3(gx, (uint32_t)std::min(n - o, kMaxGridY)), dim3(kThreads), 0, s, d + o, frames, 0u);
     }
 }
 #undef TD_BATCHED

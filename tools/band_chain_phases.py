@@ -24,7 +24,7 @@ def project(seconds=60.0):
     return p
 
 if __name__ == "__main__":
-    p = project()
+    p = project(float(os.environ.get("SECONDS_", "60")))
     sb, fb, g = p.build(api)
     g.set_option("band_mode", 1)
     def render():
