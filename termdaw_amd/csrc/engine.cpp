@@ -1375,6 +1375,40 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             }
         }
     }
+    // ---- a Normalize vertex whose one input is the last vertex of a scan launch (directly or through such links) is
+    // evaluated by that launch's epilogue in its fresh-render form (k_band_chain, BandScanDesc::norm): the conditions of
+    // SumDesc mode 5 (k_norm1), with the wave-tile as the reference block.  A single band-pass vertex takes the chain kernel
+    // as a chain of one for this.
+    std::map<size_t, size_t> norm_of;                           // scan launch vertex -> the Normalize vertex it evaluates
+    std::map<size_t, size_t> fused_norm;                        // ... and back
+    std::map<size_t, std::vector<ChainLink>> links_after;       // scan launch vertex -> the links between it and that Normalize vertex
+    if (g->band_mode == 1 && g->band_chain && g->fuse_sources && g->fuse_normalize && g->spec_normalize && g->single_pass_normalize && !is_scan &&
+        bl == (size_t)kTileFrames && M < ((size_t)1 << 31)) {
+        for (auto& kv : scan_plan) {
+            const size_t L = kv.first;
+            if (inlined[L] == 5 || (long)L == g->output_vertex || cons[L].size() != 1) continue;   // (only a launch's last vertex)
+            const std::vector<size_t> piece = chain_of.count(L) ? chain_of[L] : std::vector<size_t>{L};
+            bool ok = true;
+            for (size_t b : piece) ok = ok && g->vertices[b].pass && scan_plan[b].Kw != 0u;
+            if (!ok) continue;
+            std::vector<ChainLink> links;
+            size_t u = cons[L][0];
+            while (links.size() < 3 && (inlined[u] == 2 || inlined[u] == 3 || inlined[u] == 4) && cons[u].size() == 1 &&
+                   (long)u != g->output_vertex) {
+                links.push_back(ChainLink{u, inlined[u] == 3});
+                u = cons[u][0];
+            }
+            const Vertex& nv2 = g->vertices[u];
+            if (nv2.kind != K_NORMALIZE || inlined[u] || g->edges[u].size() != 1) continue;
+            if (nv2.peak_known && !nv2.has_init_override) continue;   // (after a scan: the speculative single pass of its own)
+            // the walk must have come up the Normalize vertex' own input chain
+            if (buffer_behind(g->edges[u][0]) != L) continue;
+            norm_of[L] = u;
+            fused_norm[u] = L;
+            links_after[L] = links;
+            if (!chain_of.count(L)) chain_of[L] = piece;   // a chain of one
+        }
+    }
     // ---- gain buffers of the Adsr vertices that are read through (k_adsr_env), before everything else: they depend on
     // the event tables only, and a chain launch needs those of its links however deep they sit in the graph
     {
@@ -1455,8 +1489,13 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         for (size_t vi : by_level[lv]) {
             Vertex& v = g->vertices[vi];
             if (inlined[vi]) continue;
+            if (fused_norm.count(vi)) continue;   // (evaluated, and its buffer taken, at its scan launch's level)
             g->vbuf[vi] = take_buffer(g);
             if (!g->vbuf[vi]) return fail("termdaw_amd: out of device memory for edge buffers");
+            if (norm_of.count(vi)) {
+                g->vbuf[norm_of[vi]] = take_buffer(g);
+                if (!g->vbuf[norm_of[vi]]) return fail("termdaw_amd: out of device memory for edge buffers");
+            }
             switch (v.kind) {
                 case K_SAMPLE_LOOP: fam_v[F_LOOP].push_back(vi); break;
                 case K_SAMPLE_MULTI: fam_v[F_MULTI].push_back(vi); break;
@@ -1497,7 +1536,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::map<size_t, size_t> ins_off;
         std::map<size_t, uint32_t> term_mode;
         for (size_t vl : by_level[lv]) {
-            if (!g->vertices[vl].has_input() || inlined[vl]) continue;   // (an inlined vertex' terms belong to its consumers)
+            if (!g->vertices[vl].has_input() || inlined[vl] || fused_norm.count(vl)) continue;   // (an inlined vertex' terms belong to its consumers)
             // (the launch of a band-pass chain sits at its last vertex and evaluates the first vertex' input terms)
             const size_t vi = chain_of.count(vl) ? chain_of[vl][0] : vl;
             std::vector<InTerm> ins;
@@ -1963,7 +2002,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     auto launch_key = [&](size_t vi) { return term_mode[first_of(vi)] | (chain_of.count(vi) ? 0x10000u : 0u); };
                     std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return launch_key(a) < launch_key(b); });
                     std::vector<BandScanDesc> d;
-                    std::vector<size_t> stages_off;
+                    std::vector<size_t> stages_off, norm_desc_off;
                     for (size_t vi : vs) {
                         const std::vector<size_t> piece = chain_of.count(vi) ? chain_of[vi] : std::vector<size_t>{vi};
                         const ScanPlan& sp0 = scan_plan[piece[0]];
@@ -1995,7 +2034,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 it = scan_pw_off.emplace(key, st.put(pw)).first;
                             }
                             sp.pw_off = it->second;
-                            if (piece.size() > 1) {   // k_band_chain: per-frame and per-wave-tile powers
+                            if (chain_of.count(vi)) {   // k_band_chain: per-frame and per-wave-tile powers
                                 for (int c = 0; c < 2; ++c)
                                     for (int n2 = 0; n2 < 16; ++n2) x.pn[n2][c] = (float)pow(q[c], (double)(n2 + 1));
                                 x.Kw = sp.Kw;
@@ -2009,8 +2048,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 }
                                 sp.pk_off = ik->second;
                             }
-                            if (i + 1 < piece.size()) {   // the links to the next vertex of the chain
-                                const std::vector<ChainLink>& links = links_before[piece[i + 1]];
+                            if (i + 1 < piece.size() || norm_of.count(vi)) {   // the links to the next vertex of the chain / to the Normalize vertex
+                                const std::vector<ChainLink>& links = i + 1 < piece.size() ? links_before[piece[i + 1]] : links_after[vi];
                                 x.n_post = (uint32_t)links.size();
                                 for (size_t l = 0; l < links.size(); ++l) {
                                     const Vertex& lv2 = g->vertices[links[l].vertex];
@@ -2025,7 +2064,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         for (size_t i = 0; i < piece.size(); ++i) {
                             const size_t o = so + i * sizeof(BandStageDesc);
                             ptr_field(o, offsetof(BandStageDesc, pw), scan_plan[piece[i]].pw_off);
-                            if (piece.size() > 1) ptr_field(o, offsetof(BandStageDesc, pk), scan_plan[piece[i]].pk_off);
+                            if (chain_of.count(vi)) ptr_field(o, offsetof(BandStageDesc, pk), scan_plan[piece[i]].pk_off);
                             cb.sync_fix.push_back({o + offsetof(BandStageDesc, sync), cb.sync_bytes});
                             cb.sync_bytes += (size_t)sp0.n_tiles * 128;   // 8 granules per tile, or 4 per wave-tile (chain)
                         }
@@ -2037,12 +2076,42 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.n_tiles = sp0.n_tiles;
                         x.flags = (uint32_t)g->band_scan_debug;
                         d.push_back(x);
+                        if (norm_of.count(vi)) {   // the Normalize vertex behind the launch: its descriptor as k_norm1 would get it (mode 5)
+                            const size_t ni = norm_of[vi];
+                            Vertex& nv = g->vertices[ni];
+                            SumDesc y{};
+                            y.out = g->vbuf[ni];
+                            y.k = 1u;
+                            y.mode = 5u;
+                            if ((long)ni == g->output_vertex && pcm_dst && qmode) {
+                                y.pcm = pcm_dst;
+                                y.amplitude = amplitude;
+                                y.qmode = (uint32_t)qmode;
+                                if (!g->output_f32) y.out = nullptr;
+                            }
+                            y.pg = make_pg(nv.gain, nv.angle);
+                            y.state = &g->dstate[nv.state_slot].norm;
+                            y.use_init = nv.has_init_override ? 1u : 0u;   // reset_normalization consumed here
+                            y.init_max = nv.init_override;
+                            nv.has_init_override = false;
+                            const size_t no = st.put(std::vector<SumDesc>{y});
+                            norm_desc_off.push_back(no);
+                            const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
+                            scratch_field(no, offsetof(SumDesc, peaks), pk);
+                            scratch_field(no, offsetof(SumDesc, init_copy), ic);
+                            if (peaks_need_zero) cb.zero.push_back({pk, nb * sizeof(float)});
+                            cb.sync_fix.push_back({no + offsetof(SumDesc, sync), cb.sync_bytes});   // one granule per tile
+                            cb.sync_bytes += ((size_t)sp0.n_tiles * 8 + 63) & ~(size_t)63;
+                        } else {
+                            norm_desc_off.push_back((size_t)-1);
+                        }
                     }
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(BandScanDesc);
                         ptr_field(o, offsetof(BandScanDesc, ins), ins_off[first_of(vs[i])]);
                         ptr_field(o, offsetof(BandScanDesc, stages), stages_off[i]);
+                        if (norm_desc_off[i] != (size_t)-1) ptr_field(o, offsetof(BandScanDesc, norm), norm_desc_off[i]);
                         cb.sync_fix.push_back({o + offsetof(BandScanDesc, ticket), cb.sync_bytes});   // {tile counter, "states read"}
                         cb.sync_bytes += 64;
                     }
@@ -3189,6 +3258,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }
     if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
     if (k == "single_pass_normalize") { g->single_pass_normalize = value != 0; return 1; }
+    if (k == "fuse_normalize") { g->fuse_normalize = value != 0; return 1; }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "table_cache") { g->table_cache = value != 0; return 1; }
     if (k == "graph_replay") { g->graph_replay = value != 0; return 1; }

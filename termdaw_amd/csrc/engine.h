@@ -307,6 +307,7 @@ struct td_graph {
     bool graph_replay = false;                 // replay the captured launch sequence of an unchanged submission (measured: no gain)
     bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
+    bool fuse_normalize = true;                // band_mode 1: a Normalize vertex right behind a scan launch is evaluated by that launch (BandScanDesc::norm)
     bool single_pass_normalize = true;         // fresh renders of wide all-loop sums find the running peak inside the sum launch (SumDesc mode 4)
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
     unsigned band_guess_min = 4096;            // the guess is used where the short warm-up is at least this long (frames)

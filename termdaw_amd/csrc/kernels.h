@@ -374,7 +374,11 @@ struct BandScanDesc {
     uint32_t n_stages;
     uint32_t k, term_mode, n_tiles;
     uint32_t flags;             // bit 0: (tests) every poll times out at once -> all predecessors recomputed (n_stages 1)
-    uint32_t pad[3];
+    uint32_t pad;
+    // k_band_chain: a Normalize vertex whose one input is the chain's last vertex (through that stage's `post` links) is
+    // evaluated by the launch itself, fresh-render form (SumDesc mode 5 fields: state, init, peaks, init_copy, sync with one
+    // granule per tile, pg, out / pcm / qmode / amplitude); the host has checked block length == 1 024 frames = one wave-tile
+    const SumDesc* norm;
 };
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
 void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);   // n_stages >= 2, NF 16

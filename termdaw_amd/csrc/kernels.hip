@@ -2954,6 +2954,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         if (tid == 0u) __hip_atomic_store((gu32)(TD_GLOBAL char*)(d.ticket + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const uint32_t wt = tile * 4u + wave;               // this wave's tile
+    const SumDesc TD_CONST* const nd = (const SumDesc TD_CONST*)(const TD_CONST char*)d.norm;   // (nullptr: no Normalize vertex behind the chain)
+    // (its carried max, read before anything else: the tile holding the chunk's end replaces it once every tile has published)
+    const float norm_init = nd ? (nd->use_init ? nd->init_max : gload1(&nd->state->max)) : 0.0f;
     const uint32_t wt0 = wt * WT, mlast = M - 1u, mf = wt0 + (uint32_t)NF * lane;
     float4* const xw4 = xt + wave * 64u * (uint32_t)(NP + 1);   // the wave's quarter of the staging
     auto slot = [](uint32_t p) { return p + p / (uint32_t)NP; };
@@ -3026,7 +3029,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             pkl2 = pk_cur[64u + lane]; pkh2 = pk_cur[kScanMaxK + 64u + lane];
         }
         // the next link's envelope gains for the lane's frames: issued now, used after the output
-        const float* env_pre = (s + 1u < n_stages && sp->n_post) ? (sp->post[0].env ? sp->post[0].env : (sp->n_post > 1u ? sp->post[1].env : nullptr)) : nullptr;
+        const float* env_pre = ((s + 1u < n_stages || nd) && sp->n_post) ? (sp->post[0].env ? sp->post[0].env : (sp->n_post > 1u ? sp->post[1].env : nullptr)) : nullptr;
         float4 envv[NP / 2];
 #pragma unroll
         for (int q = 0; q < NP / 2; ++q)
@@ -3180,8 +3183,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         }
         pan_gain(sp->pg.l_amp, sp->pg.r_amp, sp->pg.gain, sp->pg.flags);
         stamp(s, 7u);
-        if (s + 1u < n_stages) {
-            // The links to the next band-pass vertex: an Adsr vertex multiplies by its gain of the frame (k_adsr_env), then
+        if (s + 1u < n_stages || nd) {
+            // The links to the next band-pass vertex (after the last stage: to the Normalize vertex): an Adsr vertex multiplies by its gain of the frame (k_adsr_env), then
             // pan / gain; a single-input Sum is pan / gain only.  Every link and the next vertex start with their own
             // sum_inputs `0.0 + x`, whose only effect is -0 -> +0: a zero's sign moves no value anywhere in the next stage,
             // and what reads the chain's output starts with a `0.0 + x` of its own -- none here (tolerance class).
@@ -3213,6 +3216,71 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         }
     }
     if (prof) return;
+    if (nd) {
+        // ---- the Normalize vertex behind the chain (extensions.rs:310-329), fresh-render form as in k_norm1: its block is this
+        // wave's 1 024 frames.  buf = 0.0 + x; max = buf_max.max(max) over the blocks so far; buf * (1.0 / max); pan / gain;
+        // the sink's quantiser when it is the output.  A tile's maximum goes out as one granule, the earlier tiles' come in
+        // the same way (every lower ticket is running or done).
+        __shared__ float nwm[kThreads / 64], npm[kThreads / 64];
+        float pk = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            x[j] = add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]);
+            const uint32_t m = mf + 2u * (uint32_t)j;
+            if (m < M) pk = fmaxf(fmaxf(pk, fabsf(x[j].x)), fabsf(x[j].y));   // (absmaxlen's fold: NaNs never win)
+            if (m + 1u < M) pk = fmaxf(fmaxf(pk, fabsf(x[j].z)), fabsf(x[j].w));
+        }
+        pk = wave_max(pk);
+        if (lane == 0u) {
+            nwm[wave] = pk;
+            if (wt0 < M) nd->peaks[wt] = pk;
+        }
+        __syncthreads();
+        if (tid == 0u) {
+            asm volatile("" ::"v"(norm_init));   // (the carried max has been READ before this tile counts as published)
+            granule_store(nd->sync + tile, __float_as_uint(fmaxf(fmaxf(nwm[0], nwm[1]), fmaxf(nwm[2], nwm[3]))));
+            if (tile == 0u) {
+                nd->init_copy[0] = norm_init;
+                nd->init_copy[1] = nd->state->scan_max;
+            }
+        }
+        float pm = 0.0f;
+        for (uint32_t idx = tid; idx < tile; idx += kThreads) {
+            unsigned long long g = granule_load(nd->sync + idx);
+            for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < 0x400000u; ++spin) {
+                __builtin_amdgcn_s_sleep(2);
+                g = granule_load(nd->sync + idx);
+            }
+            if ((uint32_t)(g >> 32) != 1u) __builtin_trap();   // (seconds without a lower ticket publishing: not a state to compute on)
+            pm = fmaxf(pm, __uint_as_float((uint32_t)g));
+        }
+        pm = wave_max(pm);
+        if (lane == 0u) npm[wave] = pm;
+        __syncthreads();
+        float run = fmaxf(fmaxf(fmaxf(npm[0], npm[1]), fmaxf(npm[2], npm[3])), norm_init);   // max_(b-1) entering the tile's first block
+        for (uint32_t w = 0; w <= wave; ++w) run = fmaxf(nwm[w], run);                   // *max = buf_max.max(*max)
+        const float r = 1.0f / run;
+        PanGain npg;
+        npg.l_amp = nd->pg.l_amp; npg.r_amp = nd->pg.r_amp; npg.gain = nd->pg.gain; npg.flags = nd->pg.flags;
+#pragma unroll
+        for (int j = 0; j < NP; ++j)
+            xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j] = epilogue4(make_float4(x[j].x * r, x[j].y * r, x[j].z * r, x[j].w * r), npg);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        float2* const nout = nd->out;
+        void* const npcm = nd->pcm;
+        const uint32_t nq = nd->qmode;
+        const float namp = nd->amplitude;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const uint32_t m = wt0 + 2u * ((uint32_t)q * 64u + lane);
+            const float4 v = xw4[slot((uint32_t)q * 64u + lane)];
+            if (nout) store_pair(nout, m, M, v);
+            if (nq) store_quant_pair(npcm, nq, m, M, v, namp);
+        }
+        // the wave holding the chunk's last frame has the running max of the chunk's last block
+        if (fin_here && lane == 0u) const_cast<NormState*>((const NormState*)nd->state)->max = run;
+        return;
+    }
     // the last vertex' output, back through the wave's staging for coalesced stores
 #pragma unroll
     for (int j = 0; j < NP; ++j) xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];

@@ -217,3 +217,37 @@ def test_chain_after_set_time_reseeds_every_stage(gpu_api, oracle):
         b[1].set_time(0)
         b[2].set_time(0)
     assert_close(p.render(gpu_api, built=gb), p.render(oracle, built=ob))
+
+
+@pytest.mark.parametrize("which", ["config3", "config4", "chunked", "twice"])
+def test_normalize_behind_a_scan_launch_is_value_identical(gpu_api, oracle, which):
+    """A Normalize vertex right behind a scan launch is evaluated by that launch's epilogue (BandScanDesc::norm, engine option
+    `fuse_normalize`, default 1): the same operations on the same values as the launch of its own it replaces -- behind a chain
+    bit for bit the unfused result, and always within the mode's bar of the oracle; the carried max survives chunk boundaries and renders."""
+    if which == "config3":
+        p, chunk = W.config3(seconds=6.0), 0
+    elif which == "config4":
+        p, chunk = W.config4(seconds=5.0, depth=24), 0
+    else:
+        p, chunk = W.config4(seconds=7.0, depth=12), (20 * 1024 if which == "chunked" else 0)
+    outs = []
+    for fuse in (1, 0):
+        built = _scan_build(p, gpu_api, fuse_normalize=fuse)
+        if chunk:
+            built[2].set_option("max_chunk_frames", chunk)
+        built[2].set_profiling(1)
+        got = p.render(gpu_api, built=built)
+        if which == "twice":   # (a second render without a reset: one-shot state and the running max carry over, quirk Q4)
+            got = p.render(gpu_api, built=built)
+        fam = set(built[2].kernel_times())
+        built[2].set_profiling(0)
+        if which == "config3":   # (synth -> adsr -> band-pass -> normalize: the Normalize vertex' own launch is the only k_sum)
+            assert ("k_sum" in fam) == (fuse == 0), fam
+        outs.append(got)
+    if which == "config3":   # (unfused, a single band-pass vertex takes k_band_scan, whose zero-state runs are in double: other roundings)
+        assert _rms(outs[0][1], outs[1][1]) <= 1e-7 and np.abs(outs[0][0].astype(np.int64) - outs[1][0].astype(np.int64)).max() <= 1
+    else:
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert np.array_equal(_bits(outs[0][1]), _bits(outs[1][1]))
+    if which != "twice":
+        assert_close(outs[0], p.render(oracle))
