@@ -1409,6 +1409,32 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             if (!chain_of.count(L)) chain_of[L] = piece;   // a chain of one
         }
     }
+    // ---- ... and a Sum vertex with several inputs whose one consumer is the first vertex of a chain launch is evaluated by
+    // that launch's input phase (its terms summed, its pan / gain applied: BandScanDesc::pre) instead of a launch of its own
+    std::map<size_t, size_t> presum_of;   // first vertex of a chain launch -> that Sum vertex
+    std::map<size_t, size_t> presum_stage;   // ... -> the gain / pan stage between the two, if any (only meaningful with presum_of)
+    if (g->band_mode == 1 && g->fuse_sources && g->band_chain && g->fuse_normalize)
+        for (auto& kv : chain_of) {
+            const size_t first = kv.second[0], last = kv.first;
+            if (g->edges[first].size() != 1) continue;
+            size_t u = g->edges[first][0];
+            if (inlined[u] == 2 && cons[u].size() == 1) {   // a gain / pan stage in between
+                presum_stage[first] = u;
+                u = g->edges[u][0];
+            }
+            const Vertex& uv = g->vertices[u];
+            if (inlined[u] || uv.kind != K_SUM || g->edges[u].size() < 2 || cons[u].size() != 1 || (long)u == g->output_vertex) continue;
+            bool ok = true;
+            for (size_t w : g->edges[u]) ok = ok && inlined[w] < 3;   // (edge buffers, loop sources, gain / pan stages: kinds 0 .. 4)
+            if (!ok) continue;
+            presum_of[first] = u;
+            inlined[u] = 7;
+            for (size_t w : g->edges[u]) {   // its inputs are read at the LAST vertex' level
+                size_t bw = w;
+                if (inlined[bw] == 2) bw = g->edges[bw][0];
+                if (!inlined[bw]) last_use[bw] = std::max(last_use[bw], g->level[last]);
+            }
+        }
     // ---- gain buffers of the Adsr vertices that are read through (k_adsr_env), before everything else: they depend on
     // the event tables only, and a chain launch needs those of its links however deep they sit in the graph
     {
@@ -1569,7 +1595,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 }
                 return t;
             };
-            for (size_t u : g->edges[vi]) {
+            const std::vector<size_t>& in_edges = presum_of.count(vi) ? g->edges[presum_of[vi]] : g->edges[vi];
+            for (size_t u : in_edges) {
                 InTerm t{};
                 if (inlined[u] == 3 || inlined[u] == 4) {   // Adsr vertex (and the stage behind it), evaluated here
                     const size_t a = inlined[u] == 4 ? g->edges[u][0] : u;
@@ -2071,7 +2098,15 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         BandScanDesc x{};
                         x.out = g->vbuf[vi];
                         x.n_stages = (uint32_t)piece.size();
-                        x.k = (uint32_t)g->edges[piece[0]].size();
+                        x.k = (uint32_t)(presum_of.count(piece[0]) ? g->edges[presum_of[piece[0]]].size() : g->edges[piece[0]].size());
+                        if (presum_of.count(piece[0])) {
+                            const Vertex& pv = g->vertices[presum_of[piece[0]]];
+                            x.pre = make_pg(pv.gain, pv.angle);
+                            if (presum_stage.count(piece[0])) {
+                                const Vertex& sv = g->vertices[presum_stage[piece[0]]];
+                                x.pre2 = make_pg(sv.gain, sv.angle);
+                            }
+                        }
                         x.term_mode = term_mode[piece[0]];
                         x.n_tiles = sp0.n_tiles;
                         x.flags = (uint32_t)g->band_scan_debug;

@@ -379,6 +379,10 @@ struct BandScanDesc {
     // evaluated by the launch itself, fresh-render form (SumDesc mode 5 fields: state, init, peaks, init_copy, sync with one
     // granule per tile, pg, out / pcm / qmode / amplitude); the host has checked block length == 1 024 frames = one wave-tile
     const SumDesc* norm;
+    // k_band_chain: the first vertex' one input is a Sum vertex evaluated right here -- `ins` / `k` / `term_mode` are THAT
+    // vertex' terms, `pre` its pan / gain, `pre2` those of a gain / pan stage between it and the band-pass vertex (flags 0:
+    // nothing to apply -- no such vertex, or one without pan and gain)
+    PanGain pre, pre2;
 };
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
 void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);   // n_stages >= 2, NF 16

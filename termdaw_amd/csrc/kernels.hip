@@ -2965,11 +2965,17 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     {
         const TermTab ins = term_tab(d.ins);
         const uint32_t k = d.k;
+        PanGain pre;
+        pre.l_amp = d.pre.l_amp; pre.r_amp = d.pre.r_amp; pre.gain = d.pre.gain; pre.flags = d.pre.flags;
+        PanGain pre2;
+        pre2.l_amp = d.pre2.l_amp; pre2.r_amp = d.pre2.r_amp; pre2.gain = d.pre2.gain; pre2.flags = d.pre2.flags;
+        const bool pre_on = (pre.flags | pre2.flags) != 0u;
 #pragma unroll
         for (int r = 0; r < NP / 2; ++r) {
             const uint32_t m0 = wt0 + (uint32_t)(2 * r) * 128u + 2u * lane, m1 = m0 + 128u;
             float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0;
             sum_terms<TMODE>(ins, k, m0, m1, M, a0, a1);   // sum_inputs (extensions.rs:310-319): zero, += in edge order
+            if (pre_on) { a0 = epilogue4(epilogue4(a0, pre), pre2); a1 = epilogue4(epilogue4(a1, pre), pre2); }   // (the Sum vertex in front, the stage behind it: their pan / gain)
             xw4[slot((uint32_t)(2 * r) * 64u + lane)] = a0;
             xw4[slot((uint32_t)(2 * r + 1) * 64u + lane)] = a1;
         }
