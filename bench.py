@@ -588,9 +588,9 @@ def main():
                                      "removed (best of three issue depths, same lengths, same grid, this process, this device)%s; "
                                      "`hbm_compulsory_frac` prices the bytes that must cross HBM once (packed samples + the output write) "
                                      "against 8 TB/s") % (
-                                        ("(4k+4) B/frame", "one int16 PCM write (the launch also finds the running peak through in-launch "
-                                         "granules, scales and quantises: single_pass_normalize)") if single_pass else
-                                        ("(4k+8) B/frame", "one raw-sum write"),
+                                        "(4k+4) B/frame" if single_pass else "(4k+8) B/frame",
+                                        ("one int16 PCM write (the launch also finds the running peak through in-launch "
+                                         "granules, scales and quantises: single_pass_normalize)") if single_pass else "one raw-sum write",
                                         lens.sum() * 4 / 1e6,
                                         " -- frac = ceiling_ms / avg_ms; the ceiling kernel writes 4 B/frame more than this launch "
                                         "(%.1f us at 8 TB/s) and does none of its peak hand-off" % (4.0 * frames * P / 8e12 * 1e6) if single_pass else "")})
