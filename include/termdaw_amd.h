@@ -185,7 +185,7 @@ size_t td_graph_device_bytes(const td_graph* g);
  * smoothers never reach an output (extensions.rs:685) and are not run in this mode);
  * "band_chain" 0|1 (default 1; 0: scan mode launches every band-pass vertex on its own) / "fuse_normalize" 0|1 (default 1:
  * in scan mode a Normalize vertex whose one input is a scan launch's last vertex is evaluated by that launch) / "band_scan_nf" 8|16 (frames
- * per lane of a single vertex' launch) / "band_scan_depth" n (default 40: the look-back reaches back until what a tile
+ * per lane of a single vertex' launch) / "band_scan_depth" n (default 64: the look-back reaches back until what a tile
  * still weighs is below e^-n) / "band_scan_debug" n (tests: bit 0 forces the bounded-wait fallback);
  * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
  * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed

@@ -1104,8 +1104,9 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
 }
 
 // Tolerance-class band-pass (engine option "band_mode" 1, kernels.h BandScanDesc): tile = nf * 256 frames, look-back depth
-// K = tiles after which (1 - gamma)^(tile K) <= e^-band_scan_depth for the slower smoother (40 nats by default: what is cut
-// off is below 5e-18 of the largest state the chunk has seen -- this mode answers to an RMS bound on the output, not to the
+// K = tiles after which (1 - gamma)^(tile K) <= e^-band_scan_depth for the slower smoother (64 nats by default: what is cut
+// off is below 2e-28 of the largest state the chunk has seen, so a decaying tail keeps its RELATIVE accuracy down to 1e-22 of
+// the peak -- this mode answers to an RMS bound on the output, not to the
 // exact kernels' bit-for-bit guess, which prices a past burst against the whole f32 exponent range: band_depth).  Not usable (-> the exact kernels)
 // when that takes more than kScanMaxK tiles (cut-offs below ~1.5 Hz) or the chunk is too long for 32-bit tile frames.
 struct ScanPlan {
@@ -1375,6 +1376,12 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
             }
         }
     }
+    // ---- a `pass` band-pass vertex that is in no chain takes the chain kernel too, as a chain of one: that kernel keeps a
+    // non-finite state non-finite for the rest of the chunk (BandScanDesc::poison), and can take the vertices on either side in
+    if (g->band_mode == 1 && g->band_chain)
+        for (auto& kv : scan_plan)
+            if (inlined[kv.first] != 5 && !chain_of.count(kv.first) && g->vertices[kv.first].pass && kv.second.Kw)
+                chain_of[kv.first] = std::vector<size_t>{kv.first};
     // ---- a Normalize vertex whose one input is the last vertex of a scan launch (directly or through such links) is
     // evaluated by that launch's epilogue in its fresh-render form (k_band_chain, BandScanDesc::norm): the conditions of
     // SumDesc mode 5 (k_norm1), with the wave-tile as the reference block.  A single band-pass vertex takes the chain kernel
@@ -1435,6 +1442,15 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 if (!inlined[bw]) last_use[bw] = std::max(last_use[bw], g->level[last]);
             }
         }
+    // ---- a vertex left on k_band_scan (not `pass`, 8 frames per lane, chains switched off) ends with a gather over ALL
+    // earlier tiles that waits without bound (BandScanDesc::poison): only where its grid is resident at once -- a longer
+    // chunk of such a vertex takes the exact kernels
+    for (auto it = scan_plan.begin(); it != scan_plan.end();) {
+        const size_t vi = it->first;
+        const bool chained = inlined[vi] == 5 || chain_of.count(vi) != 0;
+        if (!chained && (int)it->second.n_tiles > band_scan_resident_capacity(it->second.nf)) it = scan_plan.erase(it);
+        else ++it;
+    }
     // ---- gain buffers of the Adsr vertices that are read through (k_adsr_env), before everything else: they depend on
     // the event tables only, and a chain launch needs those of its links however deep they sit in the graph
     {
@@ -2149,6 +2165,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         if (norm_desc_off[i] != (size_t)-1) ptr_field(o, offsetof(BandScanDesc, norm), norm_desc_off[i]);
                         cb.sync_fix.push_back({o + offsetof(BandScanDesc, ticket), cb.sync_bytes});   // {tile counter, "states read"}
                         cb.sync_bytes += 64;
+                        {   // one granule per tile: the stage it went non-finite at
+                            cb.sync_fix.push_back({o + offsetof(BandScanDesc, poison), cb.sync_bytes});
+                            cb.sync_bytes += ((size_t)scan_plan[vs[i]].n_tiles * 8 + 63) & ~(size_t)63;
+                        }
                     }
                     size_t b = 0;   // one launch per term mode (vs is sorted by it)
                     while (b < vs.size()) {
@@ -3282,12 +3302,12 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "band_scan_debug") { g->band_scan_debug = (int)value; return 1; }
     if (k == "band_chain") { g->band_chain = value != 0; return 1; }   // scan mode: chains of band-pass vertices in one launch
     if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
-    if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 40u; return 1; }
+    if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 64u; return 1; }
     if (k == "band_quick") { g->band_quick = value > 0 ? (unsigned)value : 0u; return 1; }
     if (k == "band_medium") { g->band_medium = value > 0 ? (unsigned)value : 30u; return 1; }
     if (k == "band_guess_min") { g->band_guess_min = value > 0 ? (unsigned)value : 0u; return 1; }
     if (k == "band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
-    if (k == "band_scan_depth") { g->band_scan_depth = value > 0 ? (unsigned)value : 40u; return 1; }
+    if (k == "band_scan_depth") { g->band_scan_depth = value > 0 ? (unsigned)value : 64u; return 1; }
     if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
     if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
     if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }

@@ -311,7 +311,7 @@ struct td_graph {
     bool single_pass_normalize = true;         // fresh renders of wide all-loop sums find the running peak inside the sum launch (SumDesc mode 4)
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
     unsigned band_guess_min = 4096;            // the guess is used where the short warm-up is at least this long (frames)
-    unsigned band_scan_depth = 40;             // band_mode 1: look-back until (1 - gamma)^(tile K) <= e^-band_scan_depth
+    unsigned band_scan_depth = 64;             // band_mode 1: look-back until (1 - gamma)^(tile K) <= e^-band_scan_depth
     unsigned band_depth = 100;                 // the guess chains block responses until (1 - gamma)^(256 K) <= e^-band_depth
     unsigned band_medium = 30;                 // medium warm-up = band_medium / gamma frames (guess + an alive window)
     unsigned band_quick = 12;                  // quick warm-up = band_quick / gamma frames, taken with the block-response guess (0: no guess)

@@ -383,8 +383,14 @@ struct BandScanDesc {
     // vertex' terms, `pre` its pan / gain, `pre2` those of a gain / pan stage between it and the band-pass vertex (flags 0:
     // nothing to apply -- no such vertex, or one without pan and gain)
     PanGain pre, pre2;
+    // [n_tiles] granules, zeroed before the launch -- the first stage at which a tile's state went non-finite
+    // (n_stages: never).  The reference's state stays NaN for good once it is; the look-back forgets a tile after K tiles,
+    // so every tile learns at the end of the chain whether ANY earlier tile was poisoned and turns NaN itself if so
+    unsigned long long* poison;
+    unsigned long long pad2;
 };
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
+int band_scan_resident_capacity(int nf);   // workgroups of k_band_scan resident at once (0: unknown)
 void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);   // n_stages >= 2, NF 16
 inline uint32_t band_scan_tile_frames(int nf) { return (uint32_t)nf * (uint32_t)kThreads; }
 

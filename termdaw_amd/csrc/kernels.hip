@@ -117,6 +117,61 @@ TD_DEV unsigned long long granule_load(const unsigned long long* p) {
     return __hip_atomic_load((gu64)(TD_GLOBAL char*)const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 constexpr uint32_t kScanSpinLimitSum = 20000;   // polls (~1 us each) of one earlier tile's granule before k_sum16w mode 4 gives up
+// The granules of ALL tiles below `n`, a workgroup's threads striding over them: f(index, value) for each; false when one
+// did not show within `limit` polls.  Four loads per thread are in flight before the first is looked at -- a thread's
+// granules, one dependent round trip after the other, were 2 - 3 us of every launch that ends in such a gather.
+template <typename F>
+TD_DEV bool for_lower_granules(const unsigned long long* sync, uint32_t n, uint32_t limit, F f) {
+    bool ok = true;
+    for (uint32_t base = threadIdx.x; base < n; base += 4u * (uint32_t)kThreads) {
+        unsigned long long g[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t idx = base + u * (uint32_t)kThreads;
+            g[u] = idx < n ? granule_load(sync + idx) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t idx = base + u * (uint32_t)kThreads;
+            if (idx >= n) continue;
+            for (uint32_t spin = 0; (uint32_t)(g[u] >> 32) != 1u && spin < limit; ++spin) {
+                __builtin_amdgcn_s_sleep(2);
+                g[u] = granule_load(sync + idx);
+            }
+            if ((uint32_t)(g[u] >> 32) == 1u) f(idx, (uint32_t)g[u]);
+            else ok = false;
+        }
+    }
+    return ok;
+}
+
+// ... the same over two granule arrays at once: f(index, value_a, value_b)
+template <typename F>
+TD_DEV bool for_lower_granules2(const unsigned long long* sa, const unsigned long long* sb, uint32_t n, uint32_t limit, F f) {
+    bool ok = true;
+    for (uint32_t base = threadIdx.x; base < n; base += 2u * (uint32_t)kThreads) {
+        unsigned long long ga[2], gb[2];
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; ++u) {
+            const uint32_t idx = base + u * (uint32_t)kThreads;
+            ga[u] = idx < n ? granule_load(sa + idx) : 0ull;
+            gb[u] = idx < n ? granule_load(sb + idx) : 0ull;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 2u; ++u) {
+            const uint32_t idx = base + u * (uint32_t)kThreads;
+            if (idx >= n) continue;
+            for (uint32_t spin = 0; ((uint32_t)(ga[u] >> 32) != 1u || (uint32_t)(gb[u] >> 32) != 1u) && spin < limit; ++spin) {
+                __builtin_amdgcn_s_sleep(2);
+                ga[u] = granule_load(sa + idx);
+                gb[u] = granule_load(sb + idx);
+            }
+            if ((uint32_t)(ga[u] >> 32) == 1u && (uint32_t)(gb[u] >> 32) == 1u) f(idx, (uint32_t)ga[u], (uint32_t)gb[u]);
+            else ok = false;
+        }
+    }
+    return ok;
+}
 
 template <typename IDX>
 TD_DEV float4 loop_pair(const float2* s, IDX len, IDX idx) {
@@ -673,18 +728,9 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
             granule_store(sync + blockIdx.x, __float_as_uint(T));
         }
         float pm = 0.0f;
-        bool ok = true;
-        for (uint32_t idx = threadIdx.x; idx < blockIdx.x; idx += kThreads) {
-            unsigned long long g = granule_load(sync + idx);
-            const uint32_t limit = d.mode == 5 ? 0x400000u : kScanSpinLimitSum;
-            for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < limit; ++spin) {
-                __builtin_amdgcn_s_sleep(2);
-                g = granule_load(sync + idx);
-            }
-            if (d.mode == 5 && (uint32_t)(g >> 32) != 1u) __builtin_trap();   // (seconds without a resident tile publishing: not a state to compute on)
-            ok = ok && (uint32_t)(g >> 32) == 1u;
-            pm = fmaxf(pm, __uint_as_float((uint32_t)g));
-        }
+        const bool ok = for_lower_granules(sync, blockIdx.x, d.mode == 5 ? 0x400000u : kScanSpinLimitSum,
+                                           [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); });
+        if (d.mode == 5 && !ok) __builtin_trap();   // (seconds without a resident tile publishing: not a state to compute on)
         pm = wave_max(pm);
         if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
         if (!ok) bad4 = 1u;
@@ -827,15 +873,8 @@ __global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ 
         }
     }
     float pm = 0.0f;
-    for (uint32_t idx = threadIdx.x; idx < blockIdx.x; idx += kThreads) {
-        unsigned long long g = granule_load(d.sync + idx);
-        for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < 0x400000u; ++spin) {
-            __builtin_amdgcn_s_sleep(2);
-            g = granule_load(d.sync + idx);
-        }
-        if ((uint32_t)(g >> 32) != 1u) __builtin_trap();   // (seconds without a resident workgroup publishing: not a state to compute on)
-        pm = fmaxf(pm, __uint_as_float((uint32_t)g));
-    }
+    if (!for_lower_granules(d.sync, blockIdx.x, 0x400000u, [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); }))
+        __builtin_trap();   // (seconds without a resident workgroup publishing: not a state to compute on)
     pm = wave_max(pm);
     if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
     __syncthreads();
@@ -2658,6 +2697,7 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         return (q & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u;
     };
     bool state_may_be_written = tile == 0u;   // (this workgroup has seen "tile 0 has read the carried states")
+    uint32_t poisoned_at = n_stages;          // the first stage at which this tile's response or entry state was not finite (uniform)
 
     const double* pw_cur = nullptr;
     double pwl = 1.0, pwh = 1.0;   // (1 - gamma)^(NF lane), low / high
@@ -2789,6 +2829,12 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
             carry_s[tid] = C;
         }
         __syncthreads();
+        // (x - x == 0 only for finite x: the tile's own response and the state entering it -- once either is not finite the
+        // reference's state stays NaN for the rest of the chunk, see the end of the kernel)
+        if (poisoned_at == n_stages &&
+            (!(B[0] - B[0] == 0.0) || !(B[1] - B[1] == 0.0) || !(B[2] - B[2] == 0.0) || !(B[3] - B[3] == 0.0) || !(carry_s[0] - carry_s[0] == 0.0) ||
+             !(carry_s[1] - carry_s[1] == 0.0) || !(carry_s[2] - carry_s[2] == 0.0) || !(carry_s[3] - carry_s[3] == 0.0)))
+            poisoned_at = s;
         // entry state of the lane's run, exact arithmetic rounded once: excl + a^(NF lane) (xw + a_wave^wave C)
         double awpl = 1.0, awph = 1.0;
         for (uint32_t w = 0; w < wave; ++w) { awpl *= awl; awph *= awh; }
@@ -2883,6 +2929,33 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
             if (tile0 + TILE > M) {   // (uniform: only the chunk's last tile has frames beyond M)
 #pragma unroll
                 for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
+            }
+        }
+    }
+    if (d.poison) {
+        // ---- once NaN, always NaN (the reference's smoother state never recovers; the look-back forgets a tile after K tiles):
+        // every tile says at which stage it went non-finite and learns the same of ALL earlier tiles.  The host sets `poison`
+        // only where the whole grid is resident at once, so every tile does get here (trap otherwise, as in k_norm1).
+        __shared__ uint32_t pz[kThreads / 64];
+        if (tid == 0u) granule_store(d.poison + tile, poisoned_at);
+        uint32_t pmin = n_stages;
+        if (!for_lower_granules(d.poison, tile, 0x400000u, [&pmin](uint32_t, uint32_t v) { pmin = min(pmin, v); })) __builtin_trap();
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off, 64));
+        if (lane == 0u) pz[wave] = pmin;
+        __syncthreads();
+        pmin = min(min(pz[0], pz[1]), min(pz[2], pz[3]));
+        if (pmin < n_stages) {   // (rare)
+            const float qnan = __uint_as_float(0x7FC00000u);
+#pragma unroll
+            for (int j = 0; j < NP; ++j) x[j] = make_float4(qnan, qnan, qnan, qnan);
+            if (mlast - tile0 < TILE && wave == 0u) {   // (the tile with the chunk's last frame: the states carried out of the chunk)
+                for (uint32_t s = pmin + lane; s < n_stages; s += 64u) {
+                    float* sf = reinterpret_cast<float*>(stages[s].state);
+                    const bool rr = stages[s].pass == 0u;
+                    if (stages[s].lgamma != 0.0f) { sf[0] = qnan; if (rr) sf[1] = qnan; }
+                    if (stages[s].hgamma != 0.0f) { sf[2] = qnan; if (rr) sf[3] = qnan; }
+                }
             }
         }
     }
@@ -2984,6 +3057,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         for (int j = 0; j < NP; ++j) x[j] = xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j];
     }
     bool state_may_be_written = tile == 0u;
+    uint32_t poisoned_at = n_stages;   // (wave 0) the first stage at which this tile's totals or entry state were not finite
     const double* pw_cur = nullptr;
     const double* pk_cur = nullptr;
     double pwl = 1.0, pwh = 1.0;     // (1 - gamma)^(NF lane)
@@ -3134,6 +3208,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 C0 += dpp_f64<kDppRowBcast15, 0xA>(C0); C2 += dpp_f64<kDppRowBcast15, 0xA>(C2);
                 C0 += dpp_f64<kDppRowBcast31, 0xC>(C0); C2 += dpp_f64<kDppRowBcast31, 0xC>(C2);
             }
+            // (x - x == 0 only for finite x: the tile's response -- every lane's run feeds it -- and, in lane 63, the state entering it)
+            if (poisoned_at == n_stages && __any((!(T0 - T0 == 0.0) || !(T2 - T2 == 0.0) || !(C0 - C0 == 0.0) || !(C2 - C2 == 0.0)) ? 1 : 0)) poisoned_at = s;
             if (lane == 63u) { carry_s[0] = C0; carry_s[1] = C2; }
             stamp(s, 5u);
         }
@@ -3222,12 +3298,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         }
     }
     if (prof) return;
+    // ---- the chain's end.  Once NaN, always NaN: the reference's smoother state never recovers, the look-back above forgets a
+    // tile after K tiles -- so every tile says at which stage it first went non-finite (one granule) and learns the same of ALL
+    // earlier tiles: if one did, every frame here is NaN from that stage on, and so are the states carried out of the chunk.
+    // With a Normalize vertex behind the chain (extensions.rs:310-329; fresh-render form as in k_norm1, its block is this wave's
+    // 1 024 frames: buf = 0.0 + x; max = buf_max.max(max) over the blocks so far; buf * (1.0 / max); pan / gain; the sink's
+    // quantiser when it is the output) the tile's maximum goes out beside that granule and ONE gather brings both in.
+    __shared__ uint32_t pz[kThreads / 64], pt[kThreads / 64];
+    __shared__ float nwm[kThreads / 64], npm[kThreads / 64];
+    const float qnan = __uint_as_float(0x7FC00000u);
     if (nd) {
-        // ---- the Normalize vertex behind the chain (extensions.rs:310-329), fresh-render form as in k_norm1: its block is this
-        // wave's 1 024 frames.  buf = 0.0 + x; max = buf_max.max(max) over the blocks so far; buf * (1.0 / max); pan / gain;
-        // the sink's quantiser when it is the output.  A tile's maximum goes out as one granule, the earlier tiles' come in
-        // the same way (every lower ticket is running or done).
-        __shared__ float nwm[kThreads / 64], npm[kThreads / 64];
         float pk = 0.0f;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
@@ -3237,12 +3317,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             if (m + 1u < M) pk = fmaxf(fmaxf(pk, fabsf(x[j].z)), fabsf(x[j].w));
         }
         pk = wave_max(pk);
-        if (lane == 0u) {
-            nwm[wave] = pk;
-            if (wt0 < M) nd->peaks[wt] = pk;
-        }
+        if (lane == 0u) nwm[wave] = pk;
         __syncthreads();
-        if (tid == 0u) {
+    }
+    if (tid == 0u) {
+        granule_store(d.poison + tile, poisoned_at);
+        if (nd) {
             asm volatile("" ::"v"(norm_init));   // (the carried max has been READ before this tile counts as published)
             granule_store(nd->sync + tile, __float_as_uint(fmaxf(fmaxf(nwm[0], nwm[1]), fmaxf(nwm[2], nwm[3]))));
             if (tile == 0u) {
@@ -3250,21 +3330,59 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 nd->init_copy[1] = nd->state->scan_max;
             }
         }
-        float pm = 0.0f;
-        for (uint32_t idx = tid; idx < tile; idx += kThreads) {
-            unsigned long long g = granule_load(nd->sync + idx);
-            for (uint32_t spin = 0; (uint32_t)(g >> 32) != 1u && spin < 0x400000u; ++spin) {
-                __builtin_amdgcn_s_sleep(2);
-                g = granule_load(nd->sync + idx);
+    }
+    uint32_t pmin = n_stages, ptile = 0xFFFFFFFFu;   // the earliest stage an earlier tile went non-finite at; the first such tile
+    float pm = 0.0f;                                 // the largest block peak of the earlier tiles
+    {
+        const uint32_t ns = n_stages;
+        bool ok;
+        if (nd) ok = for_lower_granules2(d.poison, nd->sync, tile, 0x400000u, [&](uint32_t idx, uint32_t p, uint32_t v) {
+                pmin = min(pmin, p);
+                if (p < ns) ptile = min(ptile, idx);
+                pm = fmaxf(pm, __uint_as_float(v)); });
+        else ok = for_lower_granules(d.poison, tile, 0x400000u, [&](uint32_t idx, uint32_t p) { pmin = min(pmin, p); if (p < ns) ptile = min(ptile, idx); });
+        if (!ok) __builtin_trap();   // (seconds without a lower ticket getting here: not a state to compute on)
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off, 64));
+        ptile = min(ptile, (uint32_t)__shfl_xor((int)ptile, off, 64));
+    }
+    pm = wave_max(pm);
+    if (lane == 0u) { pz[wave] = pmin; pt[wave] = ptile; npm[wave] = pm; }
+    __syncthreads();
+    pmin = min(min(pz[0], pz[1]), min(pz[2], pz[3]));
+    ptile = min(min(pt[0], pt[1]), min(pt[2], pt[3]));
+    pm = fmaxf(fmaxf(npm[0], npm[1]), fmaxf(npm[2], npm[3]));
+    const bool poisoned = pmin < n_stages;
+    if (poisoned) {   // (rare)
+#pragma unroll
+        for (int j = 0; j < NP; ++j) x[j] = make_float4(qnan, qnan, qnan, qnan);
+        if (fin_here) {
+            for (uint32_t s = pmin + lane; s < n_stages; s += 64u) {
+                float* sf = reinterpret_cast<float*>(stages[s].state);
+                if (stages[s].lgamma != 0.0f) sf[0] = qnan;
+                if (stages[s].hgamma != 0.0f) sf[2] = qnan;
             }
-            if ((uint32_t)(g >> 32) != 1u) __builtin_trap();   // (seconds without a lower ticket publishing: not a state to compute on)
-            pm = fmaxf(pm, __uint_as_float((uint32_t)g));
         }
-        pm = wave_max(pm);
-        if (lane == 0u) npm[wave] = pm;
-        __syncthreads();
-        float run = fmaxf(fmaxf(fmaxf(npm[0], npm[1]), fmaxf(npm[2], npm[3])), norm_init);   // max_(b-1) entering the tile's first block
-        for (uint32_t w = 0; w <= wave; ++w) run = fmaxf(nwm[w], run);                   // *max = buf_max.max(*max)
+        if (nd) {
+            // this tile's blocks hold nothing but NaN: no peak; and what the tiles after the first poisoned one published
+            // was measured on frames that are NaN in truth: the maximum so far is that of the tiles up to it
+            __syncthreads();
+            if (lane == 0u) nwm[wave] = 0.0f;
+            float pm2 = 0.0f;
+            const uint32_t upto = min(ptile + 1u, tile);
+            (void)for_lower_granules(nd->sync, upto, 0x400000u, [&pm2](uint32_t, uint32_t v) { pm2 = fmaxf(pm2, __uint_as_float(v)); });
+            pm2 = wave_max(pm2);
+            if (lane == 0u) npm[wave] = pm2;
+            __syncthreads();
+            pm = fmaxf(fmaxf(npm[0], npm[1]), fmaxf(npm[2], npm[3]));
+        }
+    }
+    if (nd) {
+        if (lane == 0u && wt0 < M) nd->peaks[wt] = nwm[wave];
+        float run = fmaxf(pm, norm_init);                                   // max_(b-1) entering the tile's first block
+        for (uint32_t w = 0; w <= wave; ++w) run = fmaxf(nwm[w], run);      // *max = buf_max.max(*max)
         const float r = 1.0f / run;
         PanGain npg;
         npg.l_amp = nd->pg.l_amp; npg.r_amp = nd->pg.r_amp; npg.gain = nd->pg.gain; npg.flags = nd->pg.flags;
@@ -3621,6 +3739,20 @@ static void launch_band_scan_mode(const BandScanDesc* d, int n, uint32_t frames,
     static const auto k8 = &k_band_scan<MODE, 8>;
     if (nf == 16) TD_BATCHED(k16, gx, kThreads, d, n, frames);
     else TD_BATCHED(k8, gx, kThreads, d, n, frames);
+}
+// Workgroups of k_band_scan the device holds at once (0: unknown) -- the all-earlier-tiles gather at its end waits without
+// bound, so the engine only lets a vertex take this kernel when its grid fits (the generic-terms instantiation is the largest)
+int band_scan_resident_capacity(int nf) {
+    static int cap[2] = {-1, -1};
+    const int i = nf == 16 ? 0 : 1;
+    if (cap[i] < 0) {
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        const hipError_t e = nf == 16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_band_scan<TERMS_MIXED, 16>, kThreads, 0)
+                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_band_scan<TERMS_MIXED, 8>, kThreads, 0);
+        cap[i] = (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0;
+    }
+    return cap[i];
 }
 void launch_band_scan(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s) {
     if (!n || !frames) return;

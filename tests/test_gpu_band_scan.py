@@ -95,7 +95,9 @@ def test_block_pulls_in_scan_mode(gpu_api, oracle):
     for b in range(p.cs):
         gl, gr = gg.render(gsb, gfb)
         ol, orr = og.render(osb, ofb)
-        scale = max(1e-30, float(np.abs(ol).max()), float(np.abs(orr).max()))
+        # (relative to the block's own level, down to -120 dB: in a pure decay after the input has stopped, the state
+        # carried from pull to pull keeps whatever relative rounding difference it has, at 1e-20 of full scale)
+        scale = max(1e-6, float(np.abs(ol).max()), float(np.abs(orr).max()))
         assert _rms(gl, ol) <= 1e-6 * scale and _rms(gr, orr) <= 1e-6 * scale, "block %d" % b
         gfb.set_time_to_next_block()
         ofb.set_time_to_next_block()
@@ -251,3 +253,53 @@ def test_normalize_behind_a_scan_launch_is_value_identical(gpu_api, oracle, whic
         assert np.array_equal(_bits(outs[0][1]), _bits(outs[1][1]))
     if which != "twice":
         assert_close(outs[0], p.render(oracle))
+
+
+def _nan_burst_project(shape, bl, seconds=3.0):
+    """Noise, plus ONE drum hit at 0.5 s amplified beyond the f32 range (inf on the hit's loud frames): in front of band-pass
+    vertices.  The smoothers' state goes inf, then inf - inf = NaN on the next frame, and stays NaN: finite output before the
+    hit, NaN from there to the end -- although the input is finite again a few hundred frames later."""
+    p = W.ProjectScript(48000, bl)
+    p.set_length(seconds)
+    p.assets["n"] = W.Asset(W.noise_int16(3, 700))
+    p.assets["k"] = W.Asset(W.kick_int16(4, 3000))
+    p.load_sample("n", "n", "")
+    p.load_sample("k", "k", "")
+    p.event_files["h"] = np.array([(0.5, 60.0, 0.9)], np.float32).reshape(-1, 3)
+    p.load_midi_floww("h", "h")
+    p.add_sampleloop("a", 0.5, 0.0, "n")
+    p.add_sample_multi("hit", 3.0e38, 0.0, "k", "h", -1)
+    p.add_sum("boost", 1.0e6, 0.0)
+    p.connect("hit", "boost")
+    p.add_sum("mix", 1.0, 0.0)
+    p.connect("a", "mix")
+    p.connect("boost", "mix")
+    prev = "mix"
+    for i, pass_ in enumerate(shape):
+        p.add_bandpass("b%d" % i, 1.0, 0.0, 1.0, 300.0, 6000.0, pass_)
+        p.connect(prev, "b%d" % i)
+        prev = "b%d" % i
+    p.add_normalize("out", 1.0, 0.0)
+    p.connect(prev, "out")
+    p.set_output("out")
+    return p
+
+
+@pytest.mark.parametrize("shape", [(True,), (False,), (True, True, True), (True, False)])
+@pytest.mark.parametrize("bl,chunk", [(1024, 0), (256, 0), (1024, 40 * 1024)])
+def test_a_non_finite_state_stays_non_finite(gpu_api, oracle, shape, bl, chunk):
+    """The reference's smoother never recovers from a NaN (y + gamma (x - y) of a NaN is a NaN): every output frame after the
+    first poisoned one is NaN.  The scan's look-back forgets a tile after K tiles (2 here), so the launches end with a
+    gather over ALL earlier tiles (BandScanDesc::poison): chain kernel (`pass` vertices, alone or in a chain, with and
+    without the Normalize vertex in the launch) and k_band_scan (not `pass`), one chunk and several (the carried states)."""
+    p = _nan_burst_project(shape, bl)
+    built = _scan_build(p, gpu_api)
+    if chunk:
+        built[2].set_option("max_chunk_frames", chunk)
+    gp, gf = p.render(gpu_api, built=built)
+    op, of = p.render(oracle)
+    assert np.isnan(of).sum() > of.size // 2 and np.isfinite(of).sum() > of.size // 8   # (the case is what it claims to be)
+    assert np.abs(of[np.isfinite(of)]).max() > 0.1
+    assert np.array_equal(np.isnan(gf), np.isnan(of))
+    ok = np.isfinite(of)
+    assert _rms(gf[ok], of[ok]) <= 1e-6 and np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1

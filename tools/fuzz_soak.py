@@ -1,5 +1,7 @@
 """The random-project parity tests of tests/test_gpu_fuzz.py over any seed range:  python tools/fuzz_soak.py 1000 3000
-(bit-exact kinds), python tools/fuzz_soak.py 1000 3000 sinf (projects with debug_sine / synth: <= 1e-6 RMS)"""
+(bit-exact kinds), python tools/fuzz_soak.py 1000 3000 sinf (projects with debug_sine / synth: <= 1e-6 RMS),
+python tools/fuzz_soak.py 1000 3000 scan (the same random graphs with the tolerance-class band-pass, engine option band_mode 1:
+chains, the Sum vertex in front and the Normalize vertex behind a scan launch -- <= 1e-6 RMS of the output's scale)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,7 +12,8 @@ from oracle import binding as oracle
 import test_gpu_fuzz as F
 
 lo_seed, hi_seed = int(sys.argv[1]), int(sys.argv[2])
-sinf = len(sys.argv) > 3 and sys.argv[3] == "sinf"
+sinf = len(sys.argv) > 3 and sys.argv[3] in ("sinf", "scan")
+scan_mode = len(sys.argv) > 3 and sys.argv[3] == "scan"
 bad, rejected = [], 0
 for seed in range(lo_seed, hi_seed):
     p = F.random_project(seed, allow_sinf=sinf)
@@ -25,6 +28,8 @@ for seed in range(lo_seed, hi_seed):
             pass
         continue
     gb = p.build(api)
+    if scan_mode:
+        gb[2].set_option("band_mode", 1)
     for scan in (False, True, False):
         gp, gf = p.render(api, built=gb, scan=scan)
         op, of = p.render(oracle, built=ob, scan=scan)
