@@ -303,3 +303,32 @@ def test_a_non_finite_state_stays_non_finite(gpu_api, oracle, shape, bl, chunk):
     assert np.array_equal(np.isnan(gf), np.isnan(of))
     ok = np.isfinite(of)
     assert _rms(gf[ok], of[ok]) <= 1e-6 and np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1
+
+
+def test_a_long_chunk_of_a_vertex_that_is_not_pass_takes_the_exact_kernels(gpu_api, oracle):
+    """k_band_scan ends with a gather over ALL earlier tiles that waits without bound, and numbers its tiles by blockIdx: the
+    engine lets a vertex take it only where the grid is resident at once (band_scan_resident_capacity, a few hundred tiles of
+    4 096 frames).  Beyond that a vertex that is not `pass` keeps the exact kernels -- bit for bit the oracle -- while a `pass`
+    vertex (chain kernel, ticketed tiles) stays in scan mode at any length."""
+    for pass_, exact in ((False, True), (True, False)):
+        p = W.ProjectScript(48000, 1024)
+        p.set_length(140.0)
+        p.assets["n"] = W.Asset(W.noise_int16(9, 30011))
+        p.load_sample("n", "n", "")
+        p.add_sampleloop("a", 0.5, 10.0, "n")
+        p.add_bandpass("bp", 1.2, -20.0, 1.0, 200.0, 4000.0, pass_)
+        p.add_normalize("out", 1.0, 0.0)
+        p.connect("a", "bp")
+        p.connect("bp", "out")
+        p.set_output("out")
+        built = _scan_build(p, gpu_api)
+        built[2].set_profiling(1)
+        got = p.render(gpu_api, built=built)
+        fam = set(built[2].kernel_times())
+        built[2].set_profiling(0)
+        want = p.render(oracle)
+        assert ("k_band_spec" in fam) == exact and ("k_band_scan" in fam) == (not exact), fam
+        if exact:
+            assert_bit_exact(got, want)
+        else:
+            assert_close(got, want)
