@@ -3211,6 +3211,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             // (x - x == 0 only for finite x: the tile's response -- every lane's run feeds it -- and, in lane 63, the state entering it)
             if (poisoned_at == n_stages && __any((!(T0 - T0 == 0.0) || !(T2 - T2 == 0.0) || !(C0 - C0 == 0.0) || !(C2 - C2 == 0.0)) ? 1 : 0)) poisoned_at = s;
             if (lane == 63u) { carry_s[0] = C0; carry_s[1] = C2; }
+            // (the last stage: the tile's verdict is final -- out it goes now, a stage's output phase ahead of the gather at the end)
+            if (s + 1u == n_stages && lane == 0u) granule_store(d.poison + tile, poisoned_at);
             stamp(s, 5u);
         }
         __syncthreads();   // barrier 2: the state entering the tile
@@ -3321,7 +3323,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         __syncthreads();
     }
     if (tid == 0u) {
-        granule_store(d.poison + tile, poisoned_at);
         if (nd) {
             asm volatile("" ::"v"(norm_init));   // (the carried max has been READ before this tile counts as published)
             granule_store(nd->sync + tile, __float_as_uint(fmaxf(fmaxf(nwm[0], nwm[1]), fmaxf(nwm[2], nwm[3]))));
