@@ -3734,12 +3734,18 @@ void launch_band_fix(const BandSpecDesc* d, int n, uint32_t frames, uint32_t max
     for (int o = 0; o < n; o += kMaxGridY)
         hipLaunchKernelGGL(k_band_fix, dim3(G + H, std::min(n - o, kMaxGridY)), dim3(kFixThreads), 0, s, d + o, frames, G);
 }
+int band_scan_resident_capacity(int nf);
 template <int MODE>
 static void launch_band_scan_mode(const BandScanDesc* d, int n, uint32_t frames, uint32_t gx, int nf, hipStream_t s) {
-    static const auto k16 = &k_band_scan<MODE, 16>;   // (names without a comma for the launch macro)
+    static const auto k16 = &k_band_scan<MODE, 16>;
     static const auto k8 = &k_band_scan<MODE, 8>;
-    if (nf == 16) TD_BATCHED(k16, gx, kThreads, d, n, frames);
-    else TD_BATCHED(k8, gx, kThreads, d, n, frames);
+    // (the vertices of one launch must be resident TOGETHER: the gather at the kernel's end waits for every earlier tile of
+    // its vertex without bound -- a batch's vertices go out in slices that fit)
+    const int per = std::max(1, std::min(band_scan_resident_capacity(nf) / (int)std::max(gx, 1u), kMaxGridY));
+    for (int o = 0; o < n; o += per) {
+        if (nf == 16) hipLaunchKernelGGL(k16, dim3(gx, (uint32_t)std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+        else hipLaunchKernelGGL(k8, dim3(gx, (uint32_t)std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+    }
 }
 // Workgroups of k_band_scan the device holds at once (0: unknown) -- the all-earlier-tiles gather at its end waits without
 // bound, so the engine only lets a vertex take this kernel when its grid fits (the generic-terms instantiation is the largest)
