@@ -1578,7 +1578,7 @@ TD_DEV float2 adsr_frame(const AdsrVDesc& d, uint32_t m, float2 x) {
 //    and, if the same, applied as straight code.
 // Confs whose levels could reach the `res <= -1.0` escape (adsr.rs:62-69,75-86), negative or NaN times and runs that
 // straddle an interval start take adsr_vel frame by frame.  Same f32 operations in the same order either way: bit-exact.
-constexpr int kEnvRun = 16;
+constexpr int kEnvRun = 8;
 TD_DEV float fdiv_rcp(float n, float x, double rcp) {
     const float q = (float)((double)n * rcp);
     if (fabsf(q) < 1.0e-30f && q != 0.0f) return n / x;
