@@ -1617,14 +1617,21 @@ struct AdsrPiece { float a, dv, s1, s2, s3, x; double rcp; int k; };   // value 
 TD_DEV int adsr_piece_index(const AdsrRunConsts& u, float t) {   // the `t <= ...` chain of adsr.rs:46-60 (NaN: 3)
     return t <= u.A ? 0 : t <= u.AD ? 1 : t <= u.ADS ? 2 : 3;
 }
-TD_DEV AdsrPiece adsr_piece(const AdsrRunConsts& u, int k) {
+// The four pieces as a table in LDS, built once per workgroup (adsr_piece_table) and indexed per lane: written as a chain of
+// selects on the lane's piece index the compiler builds the same table itself -- in scratch memory, whose per-wave
+// allocation held the kernel at a quarter of its wave slots.
+struct __attribute__((aligned(16))) AdsrPieceRow { float a, dv, s1, s2, s3, x; double rcp; };
+TD_DEV void adsr_piece_table(const AdsrRunConsts& u, AdsrPieceRow* tab) {   // (one thread; straight-line stores)
+    tab[0] = AdsrPieceRow{u.std_v, u.dv0, 0.0f, 0.0f, 0.0f, u.A, u.rA};
+    tab[1] = AdsrPieceRow{u.att_v, u.dv1, u.A, 0.0f, 0.0f, u.D, u.rD};
+    tab[2] = AdsrPieceRow{u.dec_v, u.dv2, u.A, u.D, 0.0f, u.S, u.rS};
+    tab[3] = AdsrPieceRow{u.sus_v, u.dv3, u.A, u.D, u.S, u.R, u.rR};
+}
+TD_DEV AdsrPiece adsr_piece(const AdsrPieceRow* tab, int k) {
+    const AdsrPieceRow r = tab[k];
     AdsrPiece p;
     p.k = k;
-    p.s1 = 0.0f; p.s2 = 0.0f; p.s3 = 0.0f;
-    p.a = u.std_v; p.dv = u.dv0; p.x = u.A; p.rcp = u.rA;
-    if (k >= 1) { p.s1 = u.A; p.a = u.att_v; p.dv = u.dv1; p.x = u.D; p.rcp = u.rD; }
-    if (k >= 2) { p.s2 = u.D; p.a = u.dec_v; p.dv = u.dv2; p.x = u.S; p.rcp = u.rS; }
-    if (k >= 3) { p.s3 = u.S; p.a = u.sus_v; p.dv = u.dv3; p.x = u.R; p.rcp = u.rR; }
+    p.a = r.a; p.dv = r.dv; p.s1 = r.s1; p.s2 = r.s2; p.s3 = r.s3; p.x = r.x; p.rcp = r.rcp;
     return p;
 }
 // mode 0: apply_adsr (adsr.rs:75-86), 1: apply_ads (adsr.rs:62-69): beyond the sustain ramp the level is sustain_vel
@@ -1635,7 +1642,7 @@ TD_DEV float adsr_piece_value(const AdsrPiece& p, float t, int mode, float susta
     return p.a + q * p.dv;
 }
 struct AdsrVoiceRun { float t0, vel, rel; int mode; bool same; AdsrPiece pc; };   // mode 2: apply_r from `rel` (adsr.rs:71-73)
-TD_DEV AdsrVoiceRun adsr_voice_run(const AdsrRunConsts& u, bool use_off, float4 v, float off_first, float off_last, bool& ok) {
+TD_DEV AdsrVoiceRun adsr_voice_run(const AdsrRunConsts& u, const AdsrPieceRow* tab, bool use_off, float4 v, float off_first, float off_last, bool& ok) {
     AdsrVoiceRun r;
     r.t0 = v.x; r.vel = v.y; r.rel = v.z;
     r.mode = use_off ? (v.z == 0.0f ? 1 : 2) : 0;
@@ -1643,17 +1650,20 @@ TD_DEV AdsrVoiceRun adsr_voice_run(const AdsrRunConsts& u, bool use_off, float4 
     ok = ok && tf >= 0.0f && tl >= tf;   // (NaN fails both)
     const int kf = adsr_piece_index(u, tf), kl = adsr_piece_index(u, tl);
     r.same = kf == kl;
-    r.pc = adsr_piece(u, kf);
+    r.pc = adsr_piece(tab, kf);
     return r;
 }
-TD_DEV float adsr_voice_value(const AdsrRunConsts& u, const AdsrVoiceRun& r, float offset) {
+TD_DEV float adsr_voice_value(const AdsrRunConsts& u, const AdsrPieceRow* tab, const AdsrVoiceRun& r, float offset) {
     const float t = r.t0 + offset;
     if (r.mode == 2) return (r.rel + fminf(fdiv_rcp(t, u.R, u.rR), 1.0f) * (u.rel_v - r.rel)) * r.vel;
     if (r.same) return adsr_piece_value(r.pc, t, r.mode, u.sus_v) * r.vel;
-    return adsr_piece_value(adsr_piece(u, adsr_piece_index(u, t)), t, r.mode, u.sus_v) * r.vel;
+    return adsr_piece_value(adsr_piece(tab, adsr_piece_index(u, t)), t, r.mode, u.sus_v) * r.vel;
 }
 __global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restrict__ descs, uint32_t M) {
     const AdsrVDesc& d = descs[blockIdx.y];
+    __shared__ AdsrPieceRow ptab[4];
+    if (threadIdx.x == 0u) adsr_piece_table(adsr_run_consts(d), ptab);
+    __syncthreads();
     const uint32_t m0 = (blockIdx.x * kThreads + threadIdx.x) * (uint32_t)kEnvRun;
     if (m0 >= M) return;
     float* const out = d.env;
@@ -1669,8 +1679,8 @@ __global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restri
         const float4 p = d.tab.voices[2u * it], g = d.tab.voices[2u * it + 1u];   // (t_off, vel, release_val, skip)
         fast = p.w == 0.0f;
         const float of = fdiv_rcp((float)i0, u.srf, u.rsr), ol = fdiv_rcp((float)(i0 + (uint32_t)kEnvRun - 1u), u.srf, u.rsr);
-        pr = adsr_voice_run(u, d.use_off != 0u, p, of, ol, fast);
-        gr = adsr_voice_run(u, d.use_off != 0u, g, of, ol, fast);
+        pr = adsr_voice_run(u, ptab, d.use_off != 0u, p, of, ol, fast);
+        gr = adsr_voice_run(u, ptab, d.use_off != 0u, g, of, ol, fast);
     }
     if (fast) {
         const float maxmul = d.use_max ? 1.0f : 0.0f, minmul = 1.0f - maxmul;
@@ -1680,7 +1690,7 @@ __global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restri
 #pragma unroll
             for (uint32_t e = 0; e < 4u; ++e) {
                 const float offset = fdiv_rcp((float)(i0 + q + e), u.srf, u.rsr);   // (float)(i % bl) / (float)sr
-                const float pvel = adsr_voice_value(u, pr, offset), gvel = adsr_voice_value(u, gr, offset);
+                const float pvel = adsr_voice_value(u, ptab, pr, offset), gvel = adsr_voice_value(u, ptab, gr, offset);
                 const float av = fmaxf(pvel, gvel) * maxmul + fminf(pvel, gvel) * minmul;
                 v[e] = lerpf(1.0f, av, d.wet);
             }
