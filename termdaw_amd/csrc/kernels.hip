@@ -1432,7 +1432,9 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
     pa = make_float2(synth_frame(d, ma), two_a ? synth_frame(d, ma + 1u) : 0.0f);
     pb = make_float2(synth_frame(d, mb), two_b ? synth_frame(d, mb + 1u) : 0.0f);
 }
-__global__ __launch_bounds__(kThreads) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
+// (six workgroups per CU: 80 registers and a few spilled words instead of 100 -- 0.134 -> 0.126 ms on config 3; seven and eight
+// spill into the voice loop and lose)
+__global__ __launch_bounds__(kThreads, 6) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
     const SynthDesc& d = descs[blockIdx.y];
     // (tiles whose waves take the per-frame form go first: IntervalTab::tile_order)
     const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
