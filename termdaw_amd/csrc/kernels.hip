@@ -61,6 +61,28 @@ TD_DEV void store_pair(float2* p, uint32_t m, uint32_t M, float4 v) {
     if (m < M) gstore4(p + m, v);
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// A double moved across lanes by DPP (two 32-bit moves on the VALU; no trip through the LDS crossbar as __shfl takes).
+// Lanes whose source lies outside the row / wave, or that the row mask leaves out, receive 0.
+template <int CTRL, int ROW_MASK>
+TD_DEV double dpp_f64(double v) {
+    const long long u = __double_as_longlong(v);
+    constexpr bool kAll = ROW_MASK == 0xF;   // (every row written: "no source -> 0" is the instruction's own bound_ctrl, no 0 to pre-load)
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, ROW_MASK, 0xF, kAll);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xF, kAll);
+    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
+}
+constexpr int kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
+// the wave's sum of v, left in lane 63 (running sums inside the rows of 16, then row and half-wave totals passed on: a fixed order)
+TD_DEV double wave_sum_to_lane63(double v) {
+    v += dpp_f64<kDppRowShr + 1, 0xF>(v);
+    v += dpp_f64<kDppRowShr + 2, 0xF>(v);
+    v += dpp_f64<kDppRowShr + 4, 0xF>(v);
+    v += dpp_f64<kDppRowShr + 8, 0xF>(v);
+    v += dpp_f64<kDppRowBcast15, 0xA>(v);
+    v += dpp_f64<kDppRowBcast31, 0xC>(v);
+    return v;
+}
 TD_DEV float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
@@ -567,28 +589,31 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
                 if ((k1 >> j) & 1u) { if (want_l) pl *= rp.ql[j]; if (want_h) ph *= rp.qh[j]; }
             const double wl1 = rp.gl * pl, wl0 = wl1 * rp.ql[0], wh1 = rp.gh * ph, wh0 = wh1 * rp.qh[0];
             // the lane's two frames of each of its two blocks, four chains; then a fixed-order sum over each block's 128 lanes:
-            // partials to LDS (lane-major), 32 threads add 64 of them each, 16 threads add the two halves
-            __shared__ double rs[8][kThreads + 4];
+            // every wave adds up its 64 lanes on the VALU (a serial walk of 32 threads over LDS partials used to hold the
+            // whole workgroup for 64 dependent LDS round trips), 16 threads add the two halves of a block
+            double part[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
             if (want_l) {
-                rs[0][threadIdx.x] = wl0 * (double)a0.x + wl1 * (double)a0.z;
-                rs[1][threadIdx.x] = wl0 * (double)a0.y + wl1 * (double)a0.w;
-                rs[4][threadIdx.x] = wl0 * (double)a1.x + wl1 * (double)a1.z;
-                rs[5][threadIdx.x] = wl0 * (double)a1.y + wl1 * (double)a1.w;
+                part[0] = wl0 * (double)a0.x + wl1 * (double)a0.z;
+                part[1] = wl0 * (double)a0.y + wl1 * (double)a0.w;
+                part[4] = wl0 * (double)a1.x + wl1 * (double)a1.z;
+                part[5] = wl0 * (double)a1.y + wl1 * (double)a1.w;
             }
             if (want_h) {
-                rs[2][threadIdx.x] = wh0 * (double)a0.x + wh1 * (double)a0.z;
-                rs[3][threadIdx.x] = wh0 * (double)a0.y + wh1 * (double)a0.w;
-                rs[6][threadIdx.x] = wh0 * (double)a1.x + wh1 * (double)a1.z;
-                rs[7][threadIdx.x] = wh0 * (double)a1.y + wh1 * (double)a1.w;
+                part[2] = wh0 * (double)a0.x + wh1 * (double)a0.z;
+                part[3] = wh0 * (double)a0.y + wh1 * (double)a0.w;
+                part[6] = wh0 * (double)a1.x + wh1 * (double)a1.z;
+                part[7] = wh0 * (double)a1.y + wh1 * (double)a1.w;
             }
-            __syncthreads();
             __shared__ double rh[8][4];
-            if (threadIdx.x < 32u) {   // e = value index (0..7), q = quarter of the workgroup (64 lanes)
-                const uint32_t e = threadIdx.x >> 2, q = threadIdx.x & 3u;
-                double acc = 0.0;
-                if ((e & 2u) ? want_h : want_l)
-                    for (uint32_t i = 0; i < 64u; ++i) acc += rs[e][q * 64u + i];
-                rh[e][q] = acc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!((e & 2) ? want_h : want_l)) continue;   // (uniform)
+                const double t = wave_sum_to_lane63(part[e]);
+                if ((threadIdx.x & 63u) == 63u) rh[e][threadIdx.x >> 6] = t;
+            }
+            if ((threadIdx.x & 63u) == 63u) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (!((e & 2) ? want_h : want_l)) rh[e][threadIdx.x >> 6] = 0.0;
             }
             __syncthreads();
             if (threadIdx.x < 16u) {
@@ -2996,18 +3021,6 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
 // (Tried and dropped, both bit-identical: every WAVE handing over for itself -- no barriers, but 2 816 pollers with a
 // four times deeper look-back: 0.71 ms for BASELINE config 4's 84 stages against 0.60; a wave owning two wave-tiles half
 // a timeline apart so that one's hand-off passes under the other's arithmetic -- 256 registers, two waves per SIMD: 1.22 ms.)
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// A double moved across lanes by DPP (two 32-bit moves on the VALU; no trip through the LDS crossbar as __shfl takes).
-// Lanes whose source lies outside the row / wave, or that the row mask leaves out, receive 0.
-template <int CTRL, int ROW_MASK>
-TD_DEV double dpp_f64(double v) {
-    const long long u = __double_as_longlong(v);
-    constexpr bool kAll = ROW_MASK == 0xF;   // (every row written: "no source -> 0" is the instruction's own bound_ctrl, no 0 to pre-load)
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)u, CTRL, ROW_MASK, 0xF, kAll);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(u >> 32), CTRL, ROW_MASK, 0xF, kAll);
-    return __longlong_as_double((long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo));
-}
-constexpr int kDppRowShr = 0x110, kDppWaveShr1 = 0x138, kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;
 template <int TMODE>
 __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M, uint32_t chains_in_x) {
     constexpr int NF = 16, NP = NF / 2;
