@@ -286,7 +286,7 @@ struct BandDesc {
 //   (= the entry state the stored output was computed from) so that the check can simply be repeated.  The usual failures are
 //   constant or silent input stretches, where f32 trajectories park on different sticky points: there the
 //   true state is a fixed point, so k_band_fix skips the whole stretch in one step and leaves its output
-//   (state fixed, input known) to the parallel k_band_fill.
+//   (state fixed, input known) to the parallel fill at the end of the launch (band_fill_tiles).
 struct BandJob { uint32_t begin, end; float y[4]; uint32_t pad[2]; };   // frames [begin, end) with parked state y
 struct BandSpecDesc {
     const float2* x;        // summed input of the vertex, materialised (sum_inputs, no epilogue)
@@ -298,7 +298,7 @@ struct BandSpecDesc {
     const float* blk_peaks; // [ceil(frames / 256)] per 256-frame block: input peak, or -1 if bit-constant (k_sum mode 2)
     uint32_t* seg_flags;    // [nseg] bit0: input bit-identical over the whole segment, bit1: input all (+-)0
     float2* seg_x0;         // [nseg] first input frame of the segment
-    BandJob* jobs;          // [nseg] parked stretches found by k_band_fix, executed by k_band_fill
+    BandJob* jobs;          // [nseg] parked stretches found by k_band_fix's cascades, executed by its fill phase
     uint32_t* seg_job;      // [nseg] index of the job whose stretch covers (part of) the segment, or ~0
     uint32_t* stats;        // [8]: cascades repaired, segments recomputed, segments parked, jobs, ticket (zeroed by k_band_spec)
     uint32_t nseg, S, W;

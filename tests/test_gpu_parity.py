@@ -504,7 +504,7 @@ def _soak_case(seed):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_band_pass_random_soak(gpu_api, oracle, seed):
-    """Randomised soak of the speculative band-pass (k_band_spec / k_band_fix / k_band_fill) against the oracle, bit for
+    """Randomised soak of the speculative band-pass (k_band_spec / k_band_fix and its fill phase) against the oracle, bit for
     bit, fresh and scanned (tools/band_soak.py runs the same cases over any seed range)."""
     p, chunk = _soak_case(seed)
     gb, ob = p.build(gpu_api), p.build(oracle)
