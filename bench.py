@@ -232,8 +232,16 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    exchange.exchange()                      # the path's only exchange: one all-reduce(max) of the peak table, on the device
-    barrier()
+    # The closing barrier.  With more than one rank it IS the path's only exchange -- one all-reduce(max) of the peak table on
+    # device memory, which no rank leaves before every rank has contributed, i.e. has finished its K steps (each contributes
+    # only after synchronising its engine stream) -- followed by torch.cuda.synchronize(): a second collective (dist.barrier)
+    # behind it would time the same rendezvous twice.  A single rank has no collective and takes the plain barrier.
+    exchange.exchange()
+    if exchange.is_collective():
+        import torch
+        torch.cuda.synchronize()
+    else:
+        barrier()
     dt = time.perf_counter() - t0
     peaks = exchange.host()                  # (the report's copy of the table: outside the timed region, like the PCM it stays in HBM)
     ktimes = batch.kernel_times()

@@ -83,6 +83,10 @@ class PeakExchange:
                 self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
                 self._host = t.numpy()
 
+    def is_collective(self):
+        """True when exchange() runs an all-reduce over more than one rank (it then also is a barrier between them)."""
+        return self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1
+
     def host(self):
         return self._host if self._host is not None else self.table.cpu().numpy()
 
