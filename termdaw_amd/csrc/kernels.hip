@@ -3774,16 +3774,26 @@ static void launch_band_scan_mode(const BandScanDesc* d, int n, uint32_t frames,
     }
 }
 // Workgroups of k_band_scan the device holds at once (0: unknown) -- the all-earlier-tiles gather at its end waits without
-// bound, so the engine only lets a vertex take this kernel when its grid fits (the generic-terms instantiation is the largest)
+// bound, so the engine only lets a vertex take this kernel when its grid fits (the smallest occupancy over the instantiations)
+template <int NF>
+static int band_scan_min_blocks_per_cu() {   // over the term-mode instantiations launch_band_scan can pick
+    int per_cu = 1 << 30, v = 0;
+    const void* ks[] = {(const void*)k_band_scan<TERMS_EDGE_FEW, NF>, (const void*)k_band_scan<TERMS_ALL_EDGE, NF>, (const void*)k_band_scan<TERMS_ADSR1, NF>,
+                        (const void*)k_band_scan<TERMS_WITH_ADSR, NF>, (const void*)k_band_scan<TERMS_MIXED, NF>};
+    for (const void* k : ks) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k, kThreads, 0) != hipSuccess) return 0;
+        per_cu = std::min(per_cu, v);
+    }
+    return per_cu;
+}
 int band_scan_resident_capacity(int nf) {
     static int cap[2] = {-1, -1};
     const int i = nf == 16 ? 0 : 1;
     if (cap[i] < 0) {
-        int per_cu = 0, dev = 0;
+        int dev = 0;
         hipDeviceProp_t prop;
-        const hipError_t e = nf == 16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_band_scan<TERMS_MIXED, 16>, kThreads, 0)
-                                      : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_band_scan<TERMS_MIXED, 8>, kThreads, 0);
-        cap[i] = (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0;
+        const int per_cu = nf == 16 ? band_scan_min_blocks_per_cu<16>() : band_scan_min_blocks_per_cu<8>();
+        cap[i] = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0;
     }
     return cap[i];
 }
