@@ -634,6 +634,13 @@ def main():
                                                  "hbm_compulsory_bytes", "hbm_compulsory_frac", "frac_of_measured_copy", "note") if k in dom}
             roofline["avg_ms"] = dom["avg_ms"]
             roofline["rocprof_kernel"] = rocprof_kernel   # the engine times launch FAMILIES; this instantiation is the rocprofv3 name
+            if "hbm_compulsory_bytes" in dom:
+                # the same launch against the HBM roofline in its plain form: the bytes that must cross HBM once per launch
+                # (every sample table once + the output write) over the launch time, against 8 TB/s
+                hb = dom["hbm_compulsory_bytes"] / (dom["avg_ms"] * 1e-3) / 1e9
+                roofline["hbm_form"] = {"bound": "hbm", "achieved": round(hb, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                        "frac": round(hb / HBM_PEAK_GBS, 4), "bytes": dom["hbm_compulsory_bytes"],
+                                        "note": "compulsory HBM bytes only: the launch is bound by its cache-served gathers (`bound` above), not by HBM"}
             roofline["measured_copy_GBs"] = round(copy_gbs, 1)
             vp = ((profiled("valu") or {}).get("config2") or {}).get(dom["kernel"])
             if vp:
