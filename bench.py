@@ -66,6 +66,23 @@ def algorithmic_bytes_per_frame(k, fused, packed):
     }
 
 
+def k_sum_roofline_note(single_pass, sample_mb, frames, projects):
+    """The text beside the dominant kernel's roofline entry (both Normalize forms; tests/test_host_logic.py formats both)."""
+    return ("source inlining: k_sum's algorithmic bytes are its own gathers, %s -- k looping samples "
+            "read in place in their packed 16-bit form + %s.  The gathers re-read a %.0f MB "
+            "sample set ~37x per launch, so they are cache hits, not HBM traffic: `peak` is the rate at which "
+            "tools/ubench/ceilings.hip performs the SAME gathers and an 8 B/frame write with the arithmetic "
+            "removed (best of three issue depths, same lengths, same grid, this process, this device)%s; "
+            "`hbm_compulsory_frac` prices the bytes that must cross HBM once (packed samples + the output write) "
+            "against 8 TB/s") % (
+                "(4k+4) B/frame" if single_pass else "(4k+8) B/frame",
+                ("one int16 PCM write (the launch also finds the running peak through in-launch "
+                 "granules, scales and quantises: single_pass_normalize)") if single_pass else "one raw-sum write",
+                sample_mb,
+                (" -- frac = ceiling_ms / avg_ms; the ceiling kernel writes 4 B/frame more than this launch "
+                 "(%.1f us at 8 TB/s) and does none of its peak hand-off" % (4.0 * frames * projects / 8e12 * 1e6)) if single_pass else "")
+
+
 def ubench():
     """tools/ubench/libtd_ubench.so (built by __graft_entry__.build(); rebuilt here if missing)."""
     d = os.path.join(ROOT, "tools", "ubench")
@@ -598,19 +615,7 @@ def main():
                             "hbm_compulsory_bytes": compulsory,
                             "hbm_compulsory_frac": round(compulsory / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             "bytes_per_frame": abf[name],
-                            "note": ("source inlining: k_sum's algorithmic bytes are its own gathers, %s -- k looping samples "
-                                     "read in place in their packed 16-bit form + %s.  The gathers re-read a %.0f MB "
-                                     "sample set ~37x per launch, so they are cache hits, not HBM traffic: `peak` is the rate at which "
-                                     "tools/ubench/ceilings.hip performs the SAME gathers and an 8 B/frame write with the arithmetic "
-                                     "removed (best of three issue depths, same lengths, same grid, this process, this device)%s; "
-                                     "`hbm_compulsory_frac` prices the bytes that must cross HBM once (packed samples + the output write) "
-                                     "against 8 TB/s") % (
-                                        "(4k+4) B/frame" if single_pass else "(4k+8) B/frame",
-                                        ("one int16 PCM write (the launch also finds the running peak through in-launch "
-                                         "granules, scales and quantises: single_pass_normalize)") if single_pass else "one raw-sum write",
-                                        lens.sum() * 4 / 1e6,
-                                        " -- frac = ceiling_ms / avg_ms; the ceiling kernel writes 4 B/frame more than this launch "
-                                        "(%.1f us at 8 TB/s) and does none of its peak hand-off" % (4.0 * frames * P / 8e12 * 1e6) if single_pass else "")})
+                            "note": k_sum_roofline_note(single_pass, lens.sum() * 4 / 1e6, frames, P)})
             else:
                 row.update({"bound": "hbm", "peak": HBM_PEAK_GBS, "frac": round(gbs / HBM_PEAK_GBS, 4),
                             "frac_of_measured_copy": round(gbs / copy_gbs, 4), "bytes_per_frame": abf.get(name)})

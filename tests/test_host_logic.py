@@ -195,3 +195,17 @@ def test_c_abi_from_plain_c(api, tmp_path):
                            "-Wl,-rpath," + libdir])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "c abi ok" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_helpers_format_in_both_normalize_forms():
+    """bench.py's pure helpers (no GPU needed to import the module): the roofline note formats for both Normalize forms, the
+    byte model follows the engine mode."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("td_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for single in (False, True):
+        note = mod.k_sum_roofline_note(single, 20.3, 2880512, 1)
+        assert ("(4k+4)" in note) == single and "20 MB" in note
+    assert mod.algorithmic_bytes_per_frame(64, True, True)["k_sum"] == 4.0 * 64 + 8.0
+    assert mod.algorithmic_bytes_per_frame(64, False, False)["k_sum"] == 8.0 * 64 + 8.0
