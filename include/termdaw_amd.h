@@ -178,11 +178,14 @@ size_t td_graph_device_bytes(const td_graph* g);
  * of its input terms: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
  * "band_mode" 0|1 (default 0 = exact: band_pass_gen, extensions.rs:654-689, bit-identical to the reference's serial
- * recurrence -- the parity mode.  1 = scan: the same filter as a blocked affine scan, TOLERANCE class: <= 1e-6 RMS on
- * the f32 output and +-1 LSB on the PCM against the exact mode (measured 6.4e-8 RMS through 84 band-pass vertices in a
- * row); one launch per band-pass vertex, and ONE launch for a whole chain of `pass` band-pass vertices linked by
- * single-input Sum / Adsr vertices.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel
- * smoothers never reach an output (extensions.rs:685) and are not run in this mode);
+ * recurrence -- the parity mode.  1 = scan: the same filter as a blocked affine scan, TOLERANCE class: another
+ * realisation of the reference's own f32 rounding noise -- measured 6.3e-8 RMS through 84 band-pass vertices in a row,
+ * +-1 LSB on the PCM; above 1e-6 of the output peak only where a band-pass vertex removes >= 30 dB of its input and a
+ * Normalize vertex brings the rest back up (8 of 18 000 random graphs, at most 3.3e-6).  A state that goes
+ * NaN / infinite stays NaN, as in the reference.  One launch per band-pass vertex, and ONE launch for a whole chain of
+ * `pass` band-pass vertices linked by single-input Sum / Adsr vertices, with the Sum vertex in front and the Normalize
+ * vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers never reach
+ * an output (extensions.rs:685) and are not run in this mode);
  * "band_chain" 0|1 (default 1; 0: scan mode launches every band-pass vertex on its own) / "fuse_normalize" 0|1 (default 1:
  * in scan mode a Normalize vertex whose one input is a scan launch's last vertex is evaluated by that launch) / "band_scan_nf" 8|16 (frames
  * per lane of a single vertex' launch) / "band_scan_depth" n (default 64: the look-back reaches back until what a tile
