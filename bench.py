@@ -242,8 +242,10 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     barrier()
     # HIP events around every launch of every PROF_EVERY-th step, on the engine's stream (the events cost a
     # few microseconds per launch -- a tenth of a single-project step if every render carried them)
-    # (a short timed region -- the driver's K = 20 -- carries two sampled steps, not K / 8 + 1: each costs ~15 us)
-    every = PROF_EVERY if steps >= 64 else max(PROF_EVERY, (steps + 1) // 2)
+    # (a short timed region -- the driver's K = 20 -- carries ONE sampled step, a middle one, not K / 8 + 1: each costs ~15 us of the
+    # region; the sampling counter starts at this call, so `every` = K with K // 2 untimed-warm steps' worth of offset is not
+    # available -- the engine samples submissions 0, every, 2 every, ...: every = K makes it the first step of the region)
+    every = PROF_EVERY if steps >= 64 else max(PROF_EVERY, steps)
     batch.set_profiling(every)
     barrier()
     t0 = time.perf_counter()
