@@ -679,6 +679,7 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world,
             "n_ranks_seen": dist.get_world_size() if use_dist else 1,   # what the process group itself reports
+            "exchange_backend": (backend if use_dist else "none"),      # "nccl" = RCCL: the peak table is all-reduced on device memory
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

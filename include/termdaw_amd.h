@@ -157,6 +157,12 @@ float td_graph_output_peak(const td_graph* g);
  * synchronisation (td_graph_sync waits).  Same work as td_graph_render_all. */
 size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits);
 int td_graph_sync(td_graph* g);
+/* How often a single-pass Normalize launch of this graph (or of the batch it belongs to) had to be redone by the check
+ * kernel after the fact: a tile of the launch gave up its bounded wait for an earlier tile's running peak -- another
+ * process or stream kept part of the grid off the device -- and td_graph_sync / td_batch_sync / the read functions then
+ * ran k_norm_fix before returning.  The results are the same either way; nothing in the library traps or waits without
+ * bound on work that may not be running.  0 in normal operation. */
+size_t td_graph_norm_fix_runs(const td_graph* g);
 /* HIP-event timing of the launches of the last render, per kernel family (ms).  names/ms are parallel
  * arrays of capacity cap; returns the number of entries. Enabled by td_graph_set_profiling(g, n): n = 1
  * times every render, n > 1 every n-th render only (the events themselves cost a few us per launch), 0 off. */
@@ -203,7 +209,8 @@ size_t td_graph_device_bytes(const td_graph* g);
  * "single_pass_normalize" 0|1 (default 1: a FRESH render of a Normalize vertex whose inputs are all looping samples on a
  * timeline of >= 1 800 blocks finds the running peak inside the summing launch -- every tile publishes its maximum and
  * reads the earlier tiles' -- and scales, pans, gains and quantises out of registers; the same check kernel stands behind
- * it; 0: the two launches sum + peaks / scale -- same values);
+ * it; 0: the two launches sum + peaks / scale -- same values) / "norm_debug" n (tests: bit 0 makes every tile of such a launch
+ * give up its wait for the earlier tiles at once, so the check kernel redoes the vertex: same values);
  * "output_f32" 0|1 (default 1; 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames --
  * td_graph_read_f32 then fails, the PCM is unchanged);
  * "table_cache" 0|1 (default 1: the compiled event tables of an event-driven vertex stay on the device and are
@@ -245,6 +252,20 @@ size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits);
 size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits);
 int td_batch_sync(td_batch* b);
 int td_batch_normalize_scan(td_batch* b, size_t chunks);    /* State::scan_exact (state.rs:473-475) per project */
+/* State::render (state.rs:477-577) for every project END TO END -- render, PCM to the host, WAV file (hound::WavWriter,
+ * state.rs:508-575: the same header and words td_state_render writes) -- as a pipeline: the projects render in groups of
+ * `group` (<= 0: 4), one submission each, queued back to back; a copy stream moves each project's PCM into page-locked host
+ * memory as soon as its group has rendered, while later groups render; `writers` host threads write paths[i] as soon as
+ * project i's copy has landed.  paths NULL (or writers 0): no files, the PCM stays readable through td_batch_host_pcm.
+ * Returns 1 when everything is written.  times (may be NULL): 8 doubles -- [0] wall ms of the call, [1] of which buffer /
+ * event setup (first call), [2] GPU ms first render start -> last render end, [3] copy-stream ms first copy start -> last
+ * copy end, [4] sum of the copies' own ms, [5] bytes copied, [6] host ms first file opened -> last file closed, [7] host ms
+ * spent enqueueing. */
+int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t render_sr, const char* const* paths, int group,
+                             int writers, double* times);
+/* Project i's PCM of the last td_batch_render_to_files in the library's page-locked buffer (valid until the next such call
+ * or td_batch_free). */
+const void* td_batch_host_pcm(const td_batch* b, size_t i, size_t* bytes);
 /* Per-project peak after the last render: the output Normalize vertex' running peak (`max`, extensions.rs:323,
  * i.e. the project's pre-normalisation peak) or, for other output kinds, the absolute peak of the output.
  * td_batch_peaks: host copy, one float per project in td_batch_add order.  td_batch_peak_table_device: fills a

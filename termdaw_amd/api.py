@@ -85,6 +85,7 @@ SIGNATURES = {
     "td_graph_output_peak": (_f32, [_vp]),
     "td_graph_render_all_async": (_sz, [_vp, _vp, _vp, _sz, _i32]),
     "td_graph_sync": (_i32, [_vp]),
+    "td_graph_norm_fix_runs": (_sz, [_vp]),
     "td_graph_set_profiling": (None, [_vp, _i32]),
     "td_graph_host_times": (_sz, [_vp, C.POINTER(C.c_double), _i32]),
     "td_graph_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
@@ -100,6 +101,8 @@ SIGNATURES = {
     "td_batch_render_all_async": (_sz, [_vp, _sz, _i32]),
     "td_batch_sync": (_i32, [_vp]),
     "td_batch_normalize_scan": (_i32, [_vp, _sz]),
+    "td_batch_render_to_files": (_i32, [_vp, _sz, _i32, _sz, C.POINTER(_cp), _i32, _i32, C.POINTER(C.c_double)]),
+    "td_batch_host_pcm": (_vp, [_vp, _sz, C.POINTER(_sz)]),
     "td_batch_peaks": (_i32, [_vp, _fp]),
     "td_batch_peak_table_device": (_i32, [_vp, _vp, _sz, _sz, _sz]),
     "td_batch_set_profiling": (None, [_vp, _i32]),
@@ -408,6 +411,10 @@ class Graph:
     def sync(self):
         _check(lib().td_graph_sync(self.h))
 
+    def norm_fix_runs(self):
+        """How often a single-pass Normalize launch was redone by the check kernel after the fact (0 in normal operation)."""
+        return lib().td_graph_norm_fix_runs(self.h)
+
     def host_times(self, reset=True):
         """Host ms per phase since the last reset: compile, descriptors, upload, launches; and chunk count."""
         out = (C.c_double * 4)()
@@ -480,6 +487,27 @@ class Batch:
 
     def sync(self):
         _check(lib().td_batch_sync(self.h))
+
+    E2E_KEYS = ("wall_ms", "setup_ms", "gpu_render_span_ms", "copy_span_ms", "copy_busy_ms", "bytes", "write_span_ms", "enqueue_ms")
+
+    def render_to_files(self, cs, bd=16, render_sr=48000, paths=None, group=4, writers=8):
+        """State::render end to end for every project: render -> page-locked host PCM -> WAV files, pipelined.  paths None:
+        no files (render + D2H).  Returns the timing report (E2E_KEYS)."""
+        arr = None
+        if paths is not None:
+            arr = (_cp * len(paths))(*[p.encode() for p in paths])
+        times = (C.c_double * 8)()
+        _check(lib().td_batch_render_to_files(self.h, cs, bd, render_sr, arr, group, writers if paths is not None else 0, times))
+        return dict(zip(self.E2E_KEYS, [float(x) for x in times]))
+
+    def host_pcm(self, i, bd=16):
+        """Project i's PCM of the last render_to_files, copied out of the library's page-locked buffer."""
+        n = _sz(0)
+        p = lib().td_batch_host_pcm(self.h, i, C.byref(n))
+        if not p:
+            raise TermdawError("no host PCM")
+        raw = C.string_at(p, n.value)
+        return np.frombuffer(raw, dtype=np.int32 if bd > 16 else np.int16).reshape(-1, 2).copy()
 
     def normalize_scan(self, chunks):
         _check(lib().td_batch_normalize_scan(self.h, chunks))

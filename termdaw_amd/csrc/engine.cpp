@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <limits>
 
 #include "wav.h"
@@ -922,10 +923,10 @@ static int ensure_state_slots(td_graph* g) {
     return 1;
 }
 
+static int drain(td_graph* g);   // stream drained + deferred k_norm_fix settled (defined with the render loop)
 static int pull_state(td_graph* g) {
     if (g->state_dev_dirty && g->dstate && !g->hstate.empty()) {
-        if (!ensure_device(g->device)) return 0;
-        TD_HIP(hipStreamSynchronize(g->stream));
+        if (!drain(g)) return 0;
         TD_HIP(hipMemcpy(g->hstate.data(), g->dstate, g->hstate.size() * sizeof(StateSlot), hipMemcpyDeviceToHost));
         g->state_dev_dirty = false;
     }
@@ -935,7 +936,7 @@ static int pull_state(td_graph* g) {
 static int ensure_buffers(td_graph* g, size_t frames) {
     frames += frames & 1;
     if (frames > g->cap_frames) {
-        TD_HIP(hipStreamSynchronize(g->stream));
+        if (!drain(g)) return 0;
         for (float2* p : g->pool) {
             (void)hipFree(p);
             g->device_bytes -= g->cap_frames * sizeof(float2);
@@ -959,10 +960,31 @@ static float2* take_buffer(td_graph* g) {
     return p;
 }
 
+// Waits for `stream`, then looks at the arena's host-visible word: a single-pass Normalize tile of the last submission gave
+// up its bounded wait for an earlier tile (SumDesc modes 4 / 5) and the check launch was not enqueued behind it -> k_norm_fix
+// redoes the vertex now, from the block peaks the launch left behind.  The normal case costs one load of page-locked memory.
+static int settle_arena(Arena& ar, hipStream_t stream) {
+    if (!stream) return 1;
+    TD_HIP(hipStreamSynchronize(stream));
+    if (!ar.h_flag || !*(volatile uint32_t*)ar.h_flag) return 1;
+    for (const auto& f : ar.pending_fix) launch_norm_fix((const SumDesc*)(ar.d + f.off), f.n, f.M, f.bl, stream);
+    TD_HIP(hipGetLastError());
+    TD_HIP(hipStreamSynchronize(stream));
+    *(volatile uint32_t*)ar.h_flag = 0u;
+    ar.fix_runs += 1;
+    return 1;
+}
+
 static int ensure_arena(Arena& ar, size_t bytes, hipStream_t stream) {
+    if (!ar.h_flag) {
+        TD_HIP(hipHostMalloc((void**)&ar.h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *ar.h_flag = 0u;
+        TD_HIP(hipHostGetDevicePointer((void**)&ar.d_flag, ar.h_flag, 0));
+    }
     if (bytes <= ar.cap) return 1;
     const size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
-    if (stream) TD_HIP(hipStreamSynchronize(stream));
+    if (stream && !settle_arena(ar, stream)) return 0;   // (a pending fix reads descriptors in the buffer about to go)
+    ar.pending_fix.clear();
     if (ar.h) (void)hipHostFree(ar.h);
     if (ar.d) (void)hipFree(ar.d);
     ar.h = nullptr;
@@ -984,6 +1006,7 @@ static void free_arena(Arena& ar) {
     if (ar.d) (void)hipFree(ar.d);
     if (ar.copied) (void)hipEventDestroy(ar.copied);
     if (ar.graph_exec) (void)hipGraphExecDestroy(ar.graph_exec);
+    if (ar.h_flag) (void)hipHostFree(ar.h_flag);
     ar = Arena{};
 }
 
@@ -1442,15 +1465,6 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 if (!inlined[bw]) last_use[bw] = std::max(last_use[bw], g->level[last]);
             }
         }
-    // ---- a vertex left on k_band_scan (not `pass`, 8 frames per lane, chains switched off) ends with a gather over ALL
-    // earlier tiles that waits without bound (BandScanDesc::poison): only where its grid is resident at once -- a longer
-    // chunk of such a vertex takes the exact kernels
-    for (auto it = scan_plan.begin(); it != scan_plan.end();) {
-        const size_t vi = it->first;
-        const bool chained = inlined[vi] == 5 || chain_of.count(vi) != 0;
-        if (!chained && (int)it->second.n_tiles > band_scan_resident_capacity(it->second.nf)) it = scan_plan.erase(it);
-        else ++it;
-    }
     // ---- gain buffers of the Adsr vertices that are read through (k_adsr_env), before everything else: they depend on
     // the event tables only, and a chain launch needs those of its links however deep they sit in the graph
     {
@@ -1690,7 +1704,9 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 }
             }
             norm_mode[vi] = mode;
-            if (mode != 5u) fam_v[mode == 1u ? F_SCALE : F_NORMFIX].push_back(vi);
+            // (modes 3 / 4 / 5 all have k_norm_fix behind them; for 4 / 5 on the output vertex of a one-chunk render it is not
+            // enqueued but kept for settle(): nothing in the submission reads the vertex' frames or its carried max)
+            fam_v[mode == 1u ? F_SCALE : F_NORMFIX].push_back(vi);
         }
         std::map<size_t, std::pair<size_t, size_t>> norm_scratch;   // vi -> (peaks, init snapshot)
         std::map<size_t, SumDesc> sum_desc_of;                      // Normalize vertices: their k_sum descriptor (k_norm_fix reuses it)
@@ -1850,6 +1866,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             if (!g->output_f32) x.out = nullptr;
                         }
                         x.term_mode = term_mode[vi];
+                        x.debug = (uint32_t)g->norm_debug;
                         x.pg = presum ? PanGain{1.0f, 1.0f, 1.0f, 0u} : make_pg(v.gain, v.angle);
                         if (presum && band_plan[vi].Wq) {   // block responses for the warm-up guess
                             BandPlan& bp = band_plan[vi];
@@ -1881,6 +1898,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             if (d[i].mode >= 4u) {   // one granule per workgroup (at most one per block)
                                 cb.sync_fix.push_back({o + offsetof(SumDesc, sync), cb.sync_bytes});
                                 cb.sync_bytes += (nb * 8 + 63) & ~(size_t)63;
+                                cb.flag_fix.push_back(o + offsetof(SumDesc, host_flag));
                             }
                             scratch_field(o, offsetof(SumDesc, peaks), pk);
                             scratch_field(o, offsetof(SumDesc, init_copy), ic);
@@ -1916,16 +1934,24 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                     }
                 } break;
                 case F_NORMFIX: {   // the same descriptors the speculative k_sum launch got
+                    // deferred (kept for settle(), not launched): a mode 4 / 5 output vertex of a one-chunk render -- last in `vs`
+                    auto deferred = [&](size_t vi) { return g->defer_fix && norm_mode[vi] >= 4u && (long)vi == g->output_vertex; };
+                    std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return deferred(a) < deferred(b); });
                     std::vector<SumDesc> d;
                     for (size_t vi : vs) d.push_back(sum_desc_of[vi]);
                     off = st.put(d);
+                    size_t n_now = 0;
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SumDesc);
                         ptr_field(o, offsetof(SumDesc, ins), ins_off[vs[i]]);
                         scratch_field(o, offsetof(SumDesc, peaks), norm_scratch[vs[i]].first);
                         scratch_field(o, offsetof(SumDesc, init_copy), norm_scratch[vs[i]].second);
+                        if (!deferred(vs[i])) ++n_now;
                     }
-                } break;
+                    if (n_now) add_launch(fam, off, (int)n_now, 0u, lv);
+                    if (n_now < vs.size()) add_launch(fam, off + n_now * sizeof(SumDesc), (int)(vs.size() - n_now), 1u, lv);
+                    continue;
+                }
                 case F_ADSR: {
                     // (k_adsr is instantiated per term mode like k_sum; its pair mapping has no packed-loop form)
                     for (size_t vi : vs)
@@ -2312,6 +2338,10 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         uint64_t p = (uint64_t)(uintptr_t)(ar.d + sync_at + f.off);
         memcpy(&st.b[f.at], &p, 8);
     }
+    for (size_t at : cb.flag_fix) {
+        uint64_t p = (uint64_t)(uintptr_t)ar.d_flag;
+        memcpy(&st.b[at], &p, 8);
+    }
     for (auto& f : cb.table_fix) {
         uint64_t p = (uint64_t)(uintptr_t)(ar.d + f.off);
         memcpy(&st.b[f.at], &p, 8);
@@ -2381,6 +2411,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
 
     // ---- 4. launch, level by level
     const auto tp3 = std::chrono::steady_clock::now();
+    ar.pending_fix.clear();   // (what an un-settled earlier submission left: prepare_render has settled it where its result is still needed)
     size_t li = 0;
     while (li < launches.size()) {
         size_t lj = li;
@@ -2398,6 +2429,10 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         }
         for (size_t q = li; q < lj; ++q) {
             const Launch& L = launches[q];
+            if (L.fam == F_NORMFIX && (L.aux & 1u)) {   // deferred: launched by settle_arena() only if a tile raised the host-visible word
+                ar.pending_fix.push_back({L.off, L.n, L.M, L.bl});
+                continue;
+            }
             const void* d = ar.d + L.off;
             const int a = aux_stream_of(L.fam);
             hipStream_t s = (fork && a >= 0) ? fork_g->aux[a] : stream;
@@ -2487,7 +2522,7 @@ static int prepare_render(td_graph* g, size_t n_blocks, int bits, bool want_pcm,
         rp->word = rp->qmode == 1 ? 2 : 4;
         const size_t need = rp->total * 2 * rp->word + 64;
         if (need > g->pcm_cap) {
-            TD_HIP(hipStreamSynchronize(g->stream));
+            if (!drain(g)) return 0;
             if (g->d_pcm) { (void)hipFree(g->d_pcm); g->device_bytes -= g->pcm_cap; }
             g->d_pcm = nullptr;
             g->pcm_cap = 0;
@@ -2500,7 +2535,7 @@ static int prepare_render(td_graph* g, size_t n_blocks, int bits, bool want_pcm,
     if (rp->multi) {
         const size_t need = (rp->total + 2) * sizeof(float2);
         if (need > g->out_f32_cap) {
-            TD_HIP(hipStreamSynchronize(g->stream));
+            if (!drain(g)) return 0;
             if (g->d_out_f32) { (void)hipFree(g->d_out_f32); g->device_bytes -= g->out_f32_cap; }
             g->d_out_f32 = nullptr;
             g->out_f32_cap = 0;
@@ -2547,12 +2582,33 @@ static void finish_render(td_graph* g, const RenderPlan& rp) {
     g->last_bits = rp.bits;
 }
 
+// Everything queued for the graph has completed AND a deferred k_norm_fix has run if one was called for (settle_arena): the
+// point from which results -- PCM, f32 frames, carried Normalize state -- may be read.
+static int drain(td_graph* g) {
+    if (!g->stream) return 1;
+    if (!ensure_device(g->device)) return 0;
+    if (!settle_arena(g->arena, g->stream)) return 0;
+    if (g->batch && g->batch->stream && !settle_arena(g->batch->arena, g->batch->stream)) return 0;
+    return 1;
+}
+// A render whose output Normalize vertex continues from its carried max needs the previous render's deferred fix settled
+// first (a render that starts from reset_normalization does not read it: back-to-back fresh renders never wait here).
+static int settle_before_render(td_graph* g) {
+    const bool pending = !g->arena.pending_fix.empty() || (g->batch && !g->batch->arena.pending_fix.empty());
+    if (!pending || g->output_vertex < 0) return 1;
+    const Vertex& ov = g->vertices[(size_t)g->output_vertex];
+    if (ov.kind == K_NORMALIZE && ov.has_init_override) return 1;
+    return drain(g);
+}
+
 // Renders n_blocks blocks in chunks.  advance_graph_time: Graph::render semantics (t += bl per block);
 // otherwise the scan's explicit j*bl clock starting at scan_t0 (graph.rs:229-233).
 int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
                         int bits, bool advance_graph_time, size_t scan_t0, bool want_pcm) {
     RenderPlan rp;
+    if (!settle_before_render(g)) return 0;
     if (!prepare_render(g, n_blocks, bits, want_pcm, &rp)) return 0;
+    g->defer_fix = !rp.multi;   // (a later chunk reads the carried max; the f32 copy of a multi-chunk render reads the frames)
     ChunkBuild& cb = g->build;
     cb.st = &g->staging;
     // (a graph that belongs to a batch may still render alone: it then uses its own arena on the shared stream)
@@ -2608,13 +2664,20 @@ static int graph_set_time_impl(td_graph* g, size_t time) {   // graph.rs:123-128
 // chunk into the batch's ChunkBuild, ONE submission uploads the tables and launches the merged grids.  Graphs
 // may differ in everything (structure, block length, chunk cap); launches merge only where level, family and
 // launch parameters agree.
-static int batch_render_chunks(td_batch* b, size_t n_blocks, bool is_scan, int bits, bool advance_graph_time, bool want_pcm) {
-    const size_t P = b->graphs.size();
-    if (P == 0) return 1;
+// Projects [lo, hi) of the batch.  allow_defer: nothing is submitted through the batch's arena before the caller settles it
+// (a deferred k_norm_fix lives in the arena's LAST submission only).
+static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks, bool is_scan, int bits, bool advance_graph_time,
+                              bool want_pcm, bool allow_defer) {
+    if (hi <= lo) return 1;
     if (!ensure_device(b->device)) return 0;
+    const size_t P = hi - lo;
     std::vector<RenderPlan> rp(P);
-    for (size_t i = 0; i < P; ++i)
-        if (!prepare_render(b->graphs[i], n_blocks, bits, want_pcm, &rp[i])) return 0;
+    for (size_t i = 0; i < P; ++i) {
+        td_graph* g = b->graphs[lo + i];
+        if (!settle_before_render(g)) return 0;
+        if (!prepare_render(g, n_blocks, bits, want_pcm, &rp[i])) return 0;
+        g->defer_fix = allow_defer && !rp[i].multi;
+    }
     ChunkBuild& cb = b->build;
     cb.st = &b->staging;
     std::vector<size_t> done(P, 0), nb(P, 0);
@@ -2628,12 +2691,13 @@ static int batch_render_chunks(td_batch* b, size_t n_blocks, bool is_scan, int b
             nb[i] = std::min(rp[i].chunk_blocks, n_blocks - done[i]);
             if (!nb[i]) continue;
             any = true;
-            fb_before[i] = {b->fbs[i]->frame, b->fbs[i]->start_indices};
-            if (!compile_next_chunk(b->graphs[i], b->sbs[i], b->fbs[i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
+            td_flowwbank* fb = b->fbs[lo + i];
+            fb_before[i] = {fb->frame, fb->start_indices};
+            if (!compile_next_chunk(b->graphs[lo + i], b->sbs[lo + i], fb, rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
                 for (size_t q = 0; q <= i; ++q)
                     if (nb[q]) {
-                        b->fbs[q]->frame = fb_before[q].first;
-                        b->fbs[q]->start_indices = fb_before[q].second;
+                        b->fbs[lo + q]->frame = fb_before[q].first;
+                        b->fbs[lo + q]->start_indices = fb_before[q].second;
                     }
                 return 0;
             }
@@ -2644,13 +2708,16 @@ static int batch_render_chunks(td_batch* b, size_t n_blocks, bool is_scan, int b
         if (!submit_chunk(b->arena, cb, b->stream, b->prof, nullptr, &scratch_base, &b->host_ms[2])) return 0;
         for (size_t i = 0; i < P; ++i) {
             if (!nb[i]) continue;
-            if (!finish_chunk(b->graphs[i], rp[i], done[i], nb[i], advance_graph_time, scratch_base)) return 0;
+            if (!finish_chunk(b->graphs[lo + i], rp[i], done[i], nb[i], advance_graph_time, scratch_base)) return 0;
             done[i] += nb[i];
         }
         b->host_steps += 1;
     }
-    for (size_t i = 0; i < P; ++i) finish_render(b->graphs[i], rp[i]);
+    for (size_t i = 0; i < P; ++i) finish_render(b->graphs[lo + i], rp[i]);
     return 1;
+}
+static int batch_render_chunks(td_batch* b, size_t n_blocks, bool is_scan, int bits, bool advance_graph_time, bool want_pcm) {
+    return batch_render_range(b, 0, b->graphs.size(), n_blocks, is_scan, bits, advance_graph_time, want_pcm, true);
 }
 
 }  // namespace tde
@@ -3093,6 +3160,7 @@ int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb
     fb->start_indices = starts;
     if (!ok) return -1;
     std::vector<float2> tmp(g->bl);
+    if (!drain(g)) return -1;
     if (hipMemcpyAsync(tmp.data(), g->last_out_f32, g->bl * sizeof(float2), hipMemcpyDeviceToHost, g->stream) != hipSuccess ||
         hipStreamSynchronize(g->stream) != hipSuccess) {
         fail("HIP error: block read-back failed");
@@ -3134,8 +3202,7 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
     if (!scan_begin(g, fb)) return 0;
     if (!graph_render_chunks(g, sb, fb, chunks, true, 16, false, 0, false)) return 0;
     if (!scan_end(g, fb)) return 0;
-    TD_HIP(hipStreamSynchronize(g->stream));
-    return 1;
+    return drain(g);
 }
 
 size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits) {
@@ -3143,12 +3210,8 @@ size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwb
     if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
     return n_blocks * g->bl;
 }
-int td_graph_sync(td_graph* g) {
-    if (!g->stream) return 1;
-    if (!ensure_device(g->device)) return 0;
-    TD_HIP(hipStreamSynchronize(g->stream));
-    return 1;
-}
+int td_graph_sync(td_graph* g) { return drain(g); }
+size_t td_graph_norm_fix_runs(const td_graph* g) { return g->arena.fix_runs + (g->batch ? g->batch->arena.fix_runs : 0); }
 size_t td_graph_render_all(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits) {
     const size_t n = td_graph_render_all_async(g, sb, fb, n_blocks, bits);
     if (!n) return 0;
@@ -3165,6 +3228,7 @@ size_t td_graph_render_all_resampled(td_graph* g, const td_samplebank* sb, td_fl
     }
     if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, false)) return 0;
     if (!graph_set_time_impl(g, 0)) return 0;
+    if (!drain(g)) return 0;   // (the resampler reads the output vertex' frames)
     const size_t total = n_blocks * g->bl;
     float2* rs = nullptr;
     size_t nout = 0;
@@ -3197,22 +3261,20 @@ const void* td_graph_output_pcm_device(const td_graph* g) { return g->d_pcm; }
 const float* td_graph_output_f32_device(const td_graph* g) { return (const float*)g->last_out_f32; }
 int td_graph_read_pcm(const td_graph* g, void* out, size_t bytes) {
     if (!g->d_pcm || bytes > g->pcm_bytes) return fail("read_pcm: nothing rendered / size too large");
-    if (!ensure_device(g->device)) return 0;
-    TD_HIP(hipStreamSynchronize(g->stream));
+    if (!drain(const_cast<td_graph*>(g))) return 0;
     TD_HIP(hipMemcpy(out, g->d_pcm, bytes, hipMemcpyDeviceToHost));
     return 1;
 }
 int td_graph_read_f32(const td_graph* g, float* out, size_t n_floats) {
     if (!g->last_out_f32 || n_floats > g->last_frames * 2) return fail("read_f32: nothing rendered / size too large");
-    if (!ensure_device(g->device)) return 0;
-    TD_HIP(hipStreamSynchronize(g->stream));
+    if (!drain(const_cast<td_graph*>(g))) return 0;
     TD_HIP(hipMemcpy(out, g->last_out_f32, n_floats * sizeof(float), hipMemcpyDeviceToHost));
     return 1;
 }
 float td_graph_output_peak(const td_graph* gc) {
     td_graph* g = const_cast<td_graph*>(gc);
     if (!g->last_out_f32 || !g->last_frames) return 0.0f;
-    if (!ensure_device(g->device)) return 0.0f;
+    if (!drain(g)) return 0.0f;
     launch_absmax((const float*)g->last_out_f32, (uint32_t)std::min<size_t>(g->last_frames * 2, 0xFFFFFFFFu), g->d_scalar,
                   g->stream);
     float v = 0.0f;
@@ -3313,6 +3375,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }
     if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
     if (k == "single_pass_normalize") { g->single_pass_normalize = value != 0; return 1; }
+    if (k == "norm_debug") { g->norm_debug = (int)value; return 1; }
     if (k == "fuse_normalize") { g->fuse_normalize = value != 0; return 1; }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "table_cache") { g->table_cache = value != 0; return 1; }
@@ -3336,7 +3399,7 @@ td_batch* td_batch_new(void) {
 void td_batch_free(td_batch* b) {
     if (!b) return;
     const bool dev_ok = hipSetDevice(b->device) == hipSuccess;
-    if (b->stream && dev_ok) (void)hipStreamSynchronize(b->stream);
+    if (b->stream && dev_ok) (void)settle_arena(b->arena, b->stream);   // (the projects' results stay readable through their own handles)
     for (td_graph* g : b->graphs) {   // the projects outlive the batch: give each its own stream back (made on next use)
         g->batch = nullptr;
         g->stream = nullptr;
@@ -3349,6 +3412,9 @@ void td_batch_free(td_batch* b) {
         free_arena(b->arena);
         free_prof(b->prof);
         if (b->d_peaks) (void)hipFree(b->d_peaks);
+        if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
+        for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
+        if (b->host_pcm) (void)hipHostFree(b->host_pcm);
         if (b->stream) (void)hipStreamDestroy(b->stream);
     }
     delete b;
@@ -3392,14 +3458,147 @@ size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits) {
 int td_batch_sync(td_batch* b) {
     if (!b->stream) return 1;
     if (!ensure_device(b->device)) return 0;
-    TD_HIP(hipStreamSynchronize(b->stream));
-    return 1;
+    return settle_arena(b->arena, b->stream);
 }
 size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits) {
     const size_t n = td_batch_render_all_async(b, n_blocks, bits);
     if (!n) return 0;
     if (!td_batch_sync(b)) return 0;
     return n;
+}
+
+// State::render (state.rs:477-577) for every project of the batch, END TO END: render, PCM to the host, the WAV file.
+// The projects render in groups of `group` (one submission each, queued back to back on the batch's stream); a copy
+// stream takes each project's PCM to page-locked host memory as soon as its group has rendered, while the next groups
+// render; `writers` host threads write project i's file -- hound's header (wav.cpp) + the PCM words -- as soon as its copy
+// has landed.  Returns when every file is written.
+int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t render_sr, const char* const* paths, int group,
+                             int writers, double* times) {
+    const size_t P = b->graphs.size();
+    if (times) for (int i = 0; i < 8; ++i) times[i] = 0.0;
+    if (!P) return 1;
+    if (!ensure_device(b->device)) return 0;
+    if (!(bits == 8 || bits == 16 || bits == 24 || bits == 32)) return fail("Bitdepth not supported: choose bitdepth in {8, 16, 24, 32}.");
+    const size_t G = group > 0 ? (size_t)group : 4;
+    const size_t n_groups = (P + G - 1) / G;
+    const auto w0 = std::chrono::steady_clock::now();
+    if (!b->copy_stream) TD_HIP(hipStreamCreateWithFlags(&b->copy_stream, hipStreamNonBlocking));
+    // events: [g] render of group g done; then per project a timed pair around its copy; two timed ones around the renders
+    const size_t n_ev = n_groups + 2 * P + 2;
+    while (b->ev_pool.size() < n_ev) {
+        hipEvent_t e = nullptr;
+        TD_HIP(hipEventCreate(&e));
+        b->ev_pool.push_back(e);
+    }
+    hipEvent_t* ev_group = b->ev_pool.data();
+    hipEvent_t* ev_c0 = ev_group + n_groups;
+    hipEvent_t* ev_c1 = ev_c0 + P;
+    hipEvent_t ev_r0 = ev_c1[P], ev_r1 = ev_c1[P + 1];
+    // page-locked PCM for the whole batch (kept from call to call)
+    const size_t word = bits > 16 ? 4 : 2;
+    b->host_pcm_off.assign(P, 0);
+    b->host_pcm_bytes.assign(P, 0);
+    size_t need = 0;
+    for (size_t i = 0; i < P; ++i) {
+        b->host_pcm_off[i] = need;
+        b->host_pcm_bytes[i] = n_blocks * b->graphs[i]->bl * 2 * word;
+        need += (b->host_pcm_bytes[i] + 4095) & ~(size_t)4095;
+    }
+    if (need > b->host_pcm_cap) {
+        if (b->host_pcm) (void)hipHostFree(b->host_pcm);
+        b->host_pcm = nullptr;
+        b->host_pcm_cap = 0;
+        TD_HIP(hipHostMalloc((void**)&b->host_pcm, need, hipHostMallocDefault));
+        b->host_pcm_cap = need;
+    }
+    const auto w1 = std::chrono::steady_clock::now();
+    // writer threads: project i is theirs once its copy event has completed
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::vector<std::string> errs((size_t)std::max(writers, 0));
+    std::vector<double> first_write((size_t)std::max(writers, 0), -1.0), last_write((size_t)std::max(writers, 0), 0.0);
+    std::atomic<size_t> queued{0};   // projects whose copy has been enqueued (events below that index are recorded)
+    const int dev = b->device;
+    auto writer = [&](int w) {
+        (void)hipSetDevice(dev);
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= P) return;
+            while (queued.load(std::memory_order_acquire) <= i) {
+                if (failed.load()) return;
+                std::this_thread::yield();
+            }
+            if (hipEventSynchronize(ev_c1[i]) != hipSuccess) { failed = 1; errs[w] = "copy event failed"; return; }
+            const double t_a = ms_between(w0, std::chrono::steady_clock::now());
+            if (first_write[w] < 0) first_write[w] = t_a;
+            std::string err;
+            if (!tdw::write_wav_int(paths[i], b->host_pcm + b->host_pcm_off[i], n_blocks * b->graphs[i]->bl, 2, render_sr, bits, &err)) {
+                failed = 1;
+                errs[w] = err;
+                return;
+            }
+            last_write[w] = ms_between(w0, std::chrono::steady_clock::now());
+        }
+    };
+    std::vector<std::thread> pool;
+    if (paths)
+        for (int w = 0; w < writers; ++w) pool.emplace_back(writer, w);
+    int ok = 1;
+    TD_HIP(hipEventRecord(ev_r0, b->stream));
+    for (size_t gi = 0; gi < n_groups && ok; ++gi) {
+        const size_t lo = gi * G, hi = std::min(P, lo + G);
+        ok = batch_render_range(b, lo, hi, n_blocks, false, bits, true, true, false);
+        for (size_t i = lo; i < hi && ok; ++i) ok = graph_set_time_impl(b->graphs[i], 0);   // state.rs:575
+        if (!ok) break;
+        if (hipEventRecord(ev_group[gi], b->stream) != hipSuccess || hipStreamWaitEvent(b->copy_stream, ev_group[gi], 0) != hipSuccess) { ok = fail("HIP error: event"); break; }
+        for (size_t i = lo; i < hi; ++i) {
+            const td_graph* g = b->graphs[i];
+            if (hipEventRecord(ev_c0[i], b->copy_stream) != hipSuccess ||
+                hipMemcpyAsync(b->host_pcm + b->host_pcm_off[i], g->d_pcm, b->host_pcm_bytes[i], hipMemcpyDeviceToHost, b->copy_stream) != hipSuccess ||
+                hipEventRecord(ev_c1[i], b->copy_stream) != hipSuccess) { ok = fail("HIP error: PCM copy to the host"); break; }
+            queued.store(i + 1, std::memory_order_release);
+        }
+    }
+    if (ok && hipEventRecord(ev_r1, b->stream) != hipSuccess) ok = fail("HIP error: event");
+    if (!ok) failed = 1;
+    const auto w2 = std::chrono::steady_clock::now();
+    for (auto& t : pool) t.join();
+    if (hipStreamSynchronize(b->copy_stream) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) ok = ok && fail("HIP error: stream");
+    const auto w3 = std::chrono::steady_clock::now();
+    if (ok && failed.load()) {
+        std::string e = "td_batch_render_to_files: ";
+        for (auto& x : errs) if (!x.empty()) { e += x; break; }
+        return fail(e);
+    }
+    if (!ok) return 0;
+    if (times) {
+        float ms = 0.f;
+        times[0] = ms_between(w0, w3);                         // wall: whole call
+        times[1] = ms_between(w0, w1);                         // of which: page-locked buffer (first call only) + events
+        if (hipEventElapsedTime(&ms, ev_r0, ev_r1) == hipSuccess) times[2] = ms;           // GPU: first render start -> last render end
+        if (hipEventElapsedTime(&ms, ev_c0[0], ev_c1[P - 1]) == hipSuccess) times[3] = ms; // copy stream: first copy start -> last copy end
+        double busy = 0.0, bytes = 0.0;
+        for (size_t i = 0; i < P; ++i) {
+            if (hipEventElapsedTime(&ms, ev_c0[i], ev_c1[i]) == hipSuccess) busy += ms;
+            bytes += (double)b->host_pcm_bytes[i];
+        }
+        times[4] = busy;                                       // sum of the copies' own durations
+        times[5] = bytes;
+        double fw = -1.0, lw = 0.0;
+        for (size_t w = 0; w < first_write.size(); ++w) {
+            if (first_write[w] >= 0 && (fw < 0 || first_write[w] < fw)) fw = first_write[w];
+            lw = std::max(lw, last_write[w]);
+        }
+        times[6] = fw < 0 ? 0.0 : lw - fw;                     // host: first file opened -> last file closed
+        times[7] = ms_between(w1, w2);                         // host: time to enqueue everything
+    }
+    return 1;
+}
+const void* td_batch_host_pcm(const td_batch* b, size_t i, size_t* bytes) {
+    if (bytes) *bytes = 0;
+    if (!b->host_pcm || i >= b->host_pcm_off.size()) return nullptr;
+    if (bytes) *bytes = b->host_pcm_bytes[i];
+    return b->host_pcm + b->host_pcm_off[i];
 }
 int td_batch_normalize_scan(td_batch* b, size_t chunks) {   // State::scan_exact (state.rs:473-475) for every project
     for (size_t i = 0; i < b->graphs.size(); ++i) {
@@ -3421,6 +3620,8 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
     if (n_total > 0xFFFFFFFFull) return fail("td_batch_peak_table_device: table too large");
     if (!ensure_device(b->device)) return 0;
     if (!b->stream) TD_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    // (the carried max of a single-pass Normalize is final once a deferred k_norm_fix has had its chance)
+    if (!b->arena.pending_fix.empty() && !settle_arena(b->arena, b->stream)) return 0;
     if (P > b->peaks_cap) {
         TD_HIP(hipStreamSynchronize(b->stream));
         if (b->d_peaks) (void)hipFree(b->d_peaks);

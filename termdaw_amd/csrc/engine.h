@@ -199,6 +199,14 @@ struct Arena {
     // uploaded bytes (descriptors: every pointer and parameter) and the launch list are unchanged
     hipGraphExec_t graph_exec = nullptr;
     std::vector<uint64_t> graph_key;
+    // Single-pass Normalize launches (SumDesc modes 4 / 5) whose k_norm_fix was NOT enqueued behind them (the vertex is the
+    // last thing its submission computes): a tile whose bounded wait gives up sets *h_flag (page-locked host memory, d_flag =
+    // its device address); settle_arena() looks at the word once the stream has drained and launches these then.
+    uint32_t* h_flag = nullptr;
+    uint32_t* d_flag = nullptr;
+    struct PendingFix { size_t off; int n; uint32_t M, bl; };
+    std::vector<PendingFix> pending_fix;
+    size_t fix_runs = 0;       // how often that happened (td_graph_norm_fix_runs)
 };
 
 // HIP-event timing of launch families (bench hook)
@@ -216,7 +224,8 @@ struct Launch {
     int fam;
     size_t off;
     int n;
-    uint32_t aux;      // F_SUM / F_ADSR: term mode | 0x100 (wide ok); band families: max segment count
+    uint32_t aux;      // F_SUM / F_ADSR: term mode | 0x100 (wide ok); band families: max segment count; F_NORMFIX: 1 = deferred
+                       // (not launched: kept as the arena's pending fix)
     int level;
     uint32_t M, bl;    // frames of the chunk, reference block length
     int is_scan;
@@ -237,6 +246,7 @@ struct ChunkBuild {
     // memset per submission
     size_t sync_bytes = 0;
     std::vector<Fix> sync_fix;
+    std::vector<size_t> flag_fix;   // pointer fields -> the arena's host-visible word (SumDesc::host_flag)
     std::vector<Launch> launches;
     size_t n_graphs = 0;
     void clear() {
@@ -247,6 +257,7 @@ struct ChunkBuild {
         zero.clear();
         sync_bytes = 0;
         sync_fix.clear();
+        flag_fix.clear();
         launches.clear();
         n_graphs = 0;
     }
@@ -309,6 +320,8 @@ struct td_graph {
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
     bool fuse_normalize = true;                // band_mode 1: a Normalize vertex right behind a scan launch is evaluated by that launch (BandScanDesc::norm)
     bool single_pass_normalize = true;         // fresh renders of wide all-loop sums find the running peak inside the sum launch (SumDesc mode 4)
+    int norm_debug = 0;                        // (tests) bit 0: every single-pass Normalize tile gives up its wait at once -> k_norm_fix
+    bool defer_fix = true;                     // (set per render) this render is one chunk: the output vertex' k_norm_fix may wait for settle()
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
     unsigned band_guess_min = 4096;            // the guess is used where the short warm-up is at least this long (frames)
     unsigned band_scan_depth = 64;             // band_mode 1: look-back until (1 - gamma)^(tile K) <= e^-band_scan_depth
@@ -352,6 +365,13 @@ struct td_batch {
     std::vector<const float*> peak_src;  // the source-pointer table as the device holds it (td_batch_peak_table_device)
     double host_ms[4] = {0, 0, 0, 0};
     size_t host_steps = 0;
+    // td_batch_render_to_files: the PCM of every project in page-locked host memory, filled by a copy stream while later
+    // projects render; events: a group's render done / a project's copy done (+ timed pairs for the report)
+    hipStream_t copy_stream = nullptr;
+    uint8_t* host_pcm = nullptr;
+    size_t host_pcm_cap = 0;
+    std::vector<size_t> host_pcm_off, host_pcm_bytes;
+    std::vector<hipEvent_t> ev_pool;
 };
 
 namespace tde {

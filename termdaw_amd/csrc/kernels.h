@@ -97,9 +97,11 @@ struct SumDesc {
                                //    straight out of registers; block peaks still go to `peaks`, a peak above max sets
                                //    state->violated and k_norm_fix (same descriptors) redoes the vertex the two-pass way
                                // 4: Normalize in ONE pass with the running peak (fresh renders), see `sync` below
-                               // 5: the same for a grid that is resident at once (checked on the host): no k_norm_fix behind it
+                               // 5: the same, for a grid the host expects to be resident at once (k_sum16w, k_norm1, the epilogue
+                               //    of k_band_chain).  Same kernel code as mode 4: the wait for earlier tiles is BOUNDED, a tile
+                               //    that gives up raises state->violated (and *host_flag) and k_norm_fix redoes the vertex
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
-    uint32_t pad;
+    uint32_t debug;            // (tests) bit 0: every wait for an earlier tile's granule gives up at once -> violated -> k_norm_fix
     PanGain pg;
     // mode 2: a second copy of the raw sum, planar within every aligned 4-frame block --
     // {l0 l1 l2 l3}{r0 r1 r2 r3} instead of {l0 r0 l1 r1}{l2 r2 l3 r3} -- the form k_band_spec's warm-up
@@ -113,6 +115,10 @@ struct SumDesc {
     // mode 4 (k_sum16w only): Normalize in ONE pass with the RUNNING peak -- every tile publishes its maximum as a granule
     // in `sync` ([tiles] words, zeroed before the launch) and reads the earlier tiles'; k_norm_fix behind it as in mode 3
     unsigned long long* sync;
+    // modes 4 / 5: a word in page-locked HOST memory (device address), set to 1 by a tile whose bounded wait gave up.  Where
+    // the vertex is the last thing its submission computes, the engine does not enqueue k_norm_fix behind the launch: it
+    // looks at this word once the stream has drained and launches the fix only then (engine.cpp settle()).  nullptr: none.
+    uint32_t* host_flag;
 };
 
 // Normalize pass B: running max over the block peaks (`*max = buf_max.max(*max)`), buf.scale(len, 1.0 / max)
@@ -331,9 +337,10 @@ struct BandSpecDesc {
 //   dropped is below the f32 denormal floor), read back with agent-scope atomic loads; then every lane starts from its
 //   exact-arithmetic entry state rounded to f32 and runs the REFERENCE's expression over its NF frames, so what
 //   differs from the exact kernels is only the entry state's last bits (the f32 trajectory's own accumulated rounding).
-//   One vertex (n_stages 1): tiles are numbered by blockIdx.x and waiting is bounded -- a predecessor that has not
-//   published in time is recomputed by the waiting workgroup itself, same arithmetic, same values -- so nothing depends on
-//   dispatch order; only tile 0, which depends on nobody, is waited for without bound.
+//   Tiles are numbered by a ticket drawn at start: a workgroup only ever waits for LOWER tickets, whose holders are
+//   running -- nothing depends on the order workgroups are dispatched in or on how many are resident at once.
+//   One vertex (n_stages 1): the look-back's wait is bounded all the same -- a predecessor that has not published in
+//   time is recomputed by the waiting workgroup itself, same arithmetic, same values.
 //   A chain (n_stages > 1: `pass` band-pass vertices linked by single-input, single-consumer gain / pan stages and Adsr
 //   vertices -- the shape of BASELINE config 4's 252 effect stages; k_band_chain): the frames stay in registers from
 //   stage to stage, the links (`0.0 + x`, envelope gain, pan / gain: BandPost) are applied in between, and every stage
@@ -370,7 +377,7 @@ struct BandScanDesc {
     const InTerm* ins;          // the (first) vertex' input terms, in connect() order
     float2* out;                // the (last) vertex' output
     const BandStageDesc* stages;
-    uint32_t* ticket;           // n_stages > 1: tile counter, zeroed before the launch
+    uint32_t* ticket;           // {tile counter, "tile 0 has read the carried states"}, zeroed before the launch
     uint32_t n_stages;
     uint32_t k, term_mode, n_tiles;
     uint32_t flags;             // bit 0: (tests) every poll times out at once -> all predecessors recomputed (n_stages 1)

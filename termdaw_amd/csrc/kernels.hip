@@ -138,7 +138,14 @@ TD_DEV void granule_store(unsigned long long* p, uint32_t value) {
 TD_DEV unsigned long long granule_load(const unsigned long long* p) {
     return __hip_atomic_load((gu64)(TD_GLOBAL char*)const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-constexpr uint32_t kScanSpinLimitSum = 20000;   // polls (~1 us each) of one earlier tile's granule before k_sum16w mode 4 gives up
+constexpr uint32_t kScanSpinLimitSum = 20000;   // polls (~1 us each) of one earlier tile's granule before a single-pass Normalize tile gives up
+// A single-pass Normalize tile (SumDesc modes 4 / 5) whose bounded wait gave up: the device-side flag k_norm_fix looks at,
+// and the word in page-locked host memory the engine looks at once the stream has drained (system scope: it must be
+// visible to the host when the launch has completed).
+TD_DEV void raise_violated(NormState* st, uint32_t* host_flag) {
+    st->violated = 1u;
+    if (host_flag) __hip_atomic_store((gu32)(TD_GLOBAL char*)host_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // The granules of ALL tiles below `n`, a workgroup's threads striding over them: f(index, value) for each; false when one
 // did not show within `limit` polls.  Four loads per thread are in flight before the first is looked at -- a thread's
 // granules, one dependent round trip after the other, were 2 - 3 us of every launch that ends in such a gather.
@@ -720,12 +727,11 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         // every earlier tile's granule read back (704 tiles: three 8-byte loads per lane, spinning until tagged) -- their
         // maximum with the carried max is the running peak entering this tile.  Then the frames are scaled, panned, gained
         // and quantised straight out of the registers: the raw sums never reach memory and pass B (k_scale) is not launched.
-        // A workgroup only waits for LOWER tiles, which the dispatcher starts first in practice but need not.  Mode 5: the host
-        // has checked that the whole grid is resident at once (occupancy x CUs, sum16w_resident_capacity), so every tile
-        // runs whatever the dispatch order and the wait needs no way out (a bound of seconds, then a trap: fail loudly).
-        // Mode 4 (a grid larger than that): the wait is bounded, a tile that gives up raises `violated`, and k_norm_fix --
-        // launched behind such a kernel, one load per workgroup when nothing is wrong -- redoes the vertex the two-pass way
-        // from the block peaks stored here.
+        // A workgroup only waits for LOWER tiles, which the dispatcher starts first in practice but need not: the wait is
+        // BOUNDED (modes 4 and 5 alike), a tile that gives up raises `violated` -- and the host-visible word `host_flag` -- and
+        // k_norm_fix redoes the vertex the two-pass way from the block peaks stored here.  The engine enqueues that launch
+        // right behind this one where anything in the submission reads the vertex' output, and otherwise only when the
+        // host-visible word says so (settle(), engine.cpp): nothing in here can trap or hang.
         const float init = spec_init_early;
         __shared__ float wm4[kThreads / 64], pm4[kThreads / 64];
         __shared__ uint32_t bad4;
@@ -753,9 +759,9 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
             granule_store(sync + blockIdx.x, __float_as_uint(T));
         }
         float pm = 0.0f;
-        const bool ok = for_lower_granules(sync, blockIdx.x, d.mode == 5 ? 0x400000u : kScanSpinLimitSum,
-                                           [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); });
-        if (d.mode == 5 && !ok) __builtin_trap();   // (seconds without a resident tile publishing: not a state to compute on)
+        const bool forced = (d.debug & 1u) != 0u && blockIdx.x != 0u;   // (tests: every wait gives up at once)
+        const bool ok = !forced && for_lower_granules(sync, blockIdx.x, kScanSpinLimitSum,
+                                                      [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); });
         pm = wave_max(pm);
         if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
         if (!ok) bad4 = 1u;
@@ -770,7 +776,7 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         }
         if (threadIdx.x == 0) {
             NormState* st = const_cast<NormState*>(d.state);
-            if (bad4) st->violated = 1u;
+            if (bad4) raise_violated(st, d.host_flag);
             else if (blockIdx.x == gridDim.x - 1u) st->max = run;   // (every earlier tile has read the old value: see above)
         }
         spec_init = -1.0f;   // (no speculation to check below)
@@ -855,6 +861,8 @@ __global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ 
     float4 a[2 * TPW];
     uint32_t mm[2 * TPW];
     __shared__ float wm[TPW][kThreads / 64], pm4[kThreads / 64];
+    __shared__ uint32_t bad1;
+    if (threadIdx.x == 0) bad1 = 0u;   // (read after two barriers)
 #pragma unroll
     for (int u = 0; u < TPW; ++u) {
         const uint32_t tile = blockIdx.x * (uint32_t)TPW + (uint32_t)u;
@@ -898,10 +906,12 @@ __global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ 
         }
     }
     float pm = 0.0f;
-    if (!for_lower_granules(d.sync, blockIdx.x, 0x400000u, [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); }))
-        __builtin_trap();   // (seconds without a resident workgroup publishing: not a state to compute on)
+    // (bounded, as in k_sum16w: a workgroup that gives up raises `violated` and k_norm_fix redoes the vertex)
+    const bool forced = (d.debug & 1u) != 0u && blockIdx.x != 0u;   // (tests: every wait gives up at once)
+    const bool ok = !forced && for_lower_granules(d.sync, blockIdx.x, kScanSpinLimitSum, [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); });
     pm = wave_max(pm);
     if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
+    if (!ok) bad1 = 1u;
     __syncthreads();
     float run = fmaxf(fmaxf(fmaxf(pm4[0], pm4[1]), fmaxf(pm4[2], pm4[3])), init);   // max_{b-1} entering the first tile
 #pragma unroll
@@ -919,7 +929,11 @@ __global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ 
             }
         }
     }
-    if (threadIdx.x == 0 && blockIdx.x == gridDim.x - 1u) const_cast<NormState*>(d.state)->max = run;   // (every earlier workgroup has read the old value)
+    if (threadIdx.x == 0) {
+        NormState* st = const_cast<NormState*>(d.state);
+        if (bad1) raise_violated(st, d.host_flag);
+        else if (blockIdx.x == gridDim.x - 1u) st->max = run;   // (every earlier workgroup has read the old value)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -996,7 +1010,7 @@ __global__ __launch_bounds__(kThreads) void k_scale(const ScaleDesc* __restrict_
 __global__ __launch_bounds__(kThreads) void k_norm_fix(const SumDesc* __restrict__ descs, uint32_t M, uint32_t bl, uint32_t nb) {
     const SumDesc& d = descs[blockIdx.y];
     NormState* st = const_cast<NormState*>(d.state);
-    if ((d.mode != 3u && d.mode != 4u) || st->violated == 0u) return;   // the normal case: the whole launch is a few hundred one-load workgroups
+    if ((d.mode != 3u && d.mode != 4u && d.mode != 5u) || st->violated == 0u) return;   // the normal case: the whole launch is a few hundred one-load workgroups
     const float init = d.init_copy[0];
     __shared__ float wmax[kThreads / 64];
     const uint32_t n_tiles = (M + kTileFrames - 1) / kTileFrames;
@@ -2597,15 +2611,11 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     const uint32_t n_stages = d.n_stages;
     const bool chain = n_stages > 1u;
     const BandStageDesc TD_CONST* const stages = (const BandStageDesc TD_CONST*)(const TD_CONST char*)d.stages;   // (uniform: scalar loads)
-    // Tile number.  A chain's workgroups draw tickets: a workgroup only ever waits for LOWER tiles, and whoever drew a
-    // lower ticket is running -- no assumption about the order workgroups are dispatched in.  (A single vertex uses
-    // blockIdx.x and bounded waits instead: the ticket counter would serialise the start of a ~15 us kernel.)
-    uint32_t tile = blockIdx.x;
-    if (chain) {
-        if (tid == 0u) tile_s = atomicAdd(d.ticket, 1u);
-        __syncthreads();
-        tile = tile_s;
-    }
+    // Tile number: a ticket.  A workgroup only ever waits for LOWER tiles, and whoever drew a lower ticket is running -- no
+    // assumption about the order workgroups are dispatched in, nor about how many of them the device holds at once.
+    if (tid == 0u) tile_s = atomicAdd(d.ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = tile_s;
     if (tile == 0u) {
         // The carried states, before any workgroup can have replaced them: the last tile stores a stage's new state only
         // after it has seen the word set below.
@@ -2972,12 +2982,12 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     }
     if (d.poison) {
         // ---- once NaN, always NaN (the reference's smoother state never recovers; the look-back forgets a tile after K tiles):
-        // every tile says at which stage it went non-finite and learns the same of ALL earlier tiles.  The host sets `poison`
-        // only where the whole grid is resident at once, so every tile does get here (trap otherwise, as in k_norm1).
+        // every tile says at which stage it went non-finite and learns the same of ALL earlier tiles (lower tickets: their
+        // holders are running and get here without waiting for anybody above them, so the wait needs no bound).
         __shared__ uint32_t pz[kThreads / 64];
         if (tid == 0u) granule_store(d.poison + tile, poisoned_at);
         uint32_t pmin = n_stages;
-        if (!for_lower_granules(d.poison, tile, 0x400000u, [&pmin](uint32_t, uint32_t v) { pmin = min(pmin, v); })) __builtin_trap();
+        (void)for_lower_granules(d.poison, tile, 0xFFFFFFFFu, [&pmin](uint32_t, uint32_t v) { pmin = min(pmin, v); });
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off, 64));
         if (lane == 0u) pz[wave] = pmin;
@@ -3361,14 +3371,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     uint32_t pmin = n_stages, ptile = 0xFFFFFFFFu;   // the earliest stage an earlier tile went non-finite at; the first such tile
     float pm = 0.0f;                                 // the largest block peak of the earlier tiles
     {
+        // (lower TICKETS: their holders are running and reach this point without waiting for anybody above them -- the
+        // wait needs no bound, like the look-back's)
         const uint32_t ns = n_stages;
-        bool ok;
-        if (nd) ok = for_lower_granules2(d.poison, nd->sync, tile, 0x400000u, [&](uint32_t idx, uint32_t p, uint32_t v) {
+        if (nd) (void)for_lower_granules2(d.poison, nd->sync, tile, 0xFFFFFFFFu, [&](uint32_t idx, uint32_t p, uint32_t v) {
                 pmin = min(pmin, p);
                 if (p < ns) ptile = min(ptile, idx);
                 pm = fmaxf(pm, __uint_as_float(v)); });
-        else ok = for_lower_granules(d.poison, tile, 0x400000u, [&](uint32_t idx, uint32_t p) { pmin = min(pmin, p); if (p < ns) ptile = min(ptile, idx); });
-        if (!ok) __builtin_trap();   // (seconds without a lower ticket getting here: not a state to compute on)
+        else (void)for_lower_granules(d.poison, tile, 0xFFFFFFFFu, [&](uint32_t idx, uint32_t p) { pmin = min(pmin, p); if (p < ns) ptile = min(ptile, idx); });
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -3399,7 +3409,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             if (lane == 0u) nwm[wave] = 0.0f;
             float pm2 = 0.0f;
             const uint32_t upto = min(ptile + 1u, tile);
-            (void)for_lower_granules(nd->sync, upto, 0x400000u, [&pm2](uint32_t, uint32_t v) { pm2 = fmaxf(pm2, __uint_as_float(v)); });
+            (void)for_lower_granules(nd->sync, upto, 0xFFFFFFFFu, [&pm2](uint32_t, uint32_t v) { pm2 = fmaxf(pm2, __uint_as_float(v)); });
             pm2 = wave_max(pm2);
             if (lane == 0u) npm[wave] = pm2;
             __syncthreads();

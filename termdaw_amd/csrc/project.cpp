@@ -566,8 +566,14 @@ static int state_render_device(td_state* s) {
     if (s->psr > s->render_sr) {   // state.rs:533-561 (build-defined resampler, parity unpinned)
         frames = td_graph_render_all_resampled(s->g, s->sb, s->fb, s->cs, (int)s->bd, s->psr, s->render_sr);
         if (!frames) return 0;
-    } else if (!td_graph_render_all(s->g, s->sb, s->fb, s->cs, (int)s->bd)) {
-        return 0;
+    } else {
+        // the sink only ever reads the integer PCM (state.rs:515-575): a Normalize output vertex keeps no f32 copy of
+        // its frames for this render (engine option "output_f32" 0 -- the form bench.py times), whatever the handle's setting
+        const bool keep = s->g->output_f32;
+        s->g->output_f32 = false;
+        const size_t n = td_graph_render_all(s->g, s->sb, s->fb, s->cs, (int)s->bd);
+        s->g->output_f32 = keep;
+        if (!n) return 0;
     }
     s->out_frames = frames;
     if (!s->host_pcm.resize(frames * 2 * word)) return fail("termdaw_amd: out of page-locked host memory for the PCM read-back");

@@ -1,0 +1,173 @@
+"""What bench.py times, and the Normalize forms no other test reaches, against the oracle (normalize_gen,
+extensions.rs:321-329; sum_inputs, extensions.rs:310-319; the sink's quantiser, state.rs:515-532).
+
+* BASELINE config 2 at its full size with EXACTLY the options bench.py's build_batch sets (fuse_sources 1,
+  packed_samples 1, output_f32 0): the render is ONE launch of the k_sum family (no k_scale, no k_norm_fix), the PCM is
+  the oracle's byte for byte; the same for the 64-project batch (config 5's per-GPU share) through td_batch_*.
+* a 120 s config-2 project: the wide summing grid is larger than what the device holds at once (SumDesc mode 4), fresh
+  and twice in a row (the second render continues the running peak), and with engine option norm_debug 1 -- every tile
+  gives up its wait for the earlier tiles at once, `violated` is raised and k_norm_fix redoes the vertex.
+* the same forced give-up through the resident-grid form (mode 5, k_sum16w and k_norm1), where the check launch is not
+  enqueued but run by td_graph_sync / the read functions when the host-visible word says so: td_graph_norm_fix_runs
+  counts it.
+* bench.py as ONE rank over RCCL (TD_BENCH_FORCE_DIST=1, backend nccl): process-group init with device_id and the
+  on-device all-reduce(max) of PeakExchange execute on the MI355X.
+"""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from termdaw_amd import batch as tb
+from termdaw_amd import workloads as W
+from test_gpu_parity import assert_bit_exact, _bits
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH_OPTS = {"fuse_sources": 1, "packed_samples": 1, "output_f32": 0}   # bench.py build_batch()
+
+
+def _digest(pcm):
+    return hashlib.sha256(np.ascontiguousarray(pcm, dtype="<i2").tobytes()).hexdigest()
+
+
+def _families(g, render):
+    g.set_profiling(1)
+    out = render()
+    fam = g.kernel_times()
+    g.set_profiling(0)
+    return out, fam
+
+
+def test_config2_full_size_exactly_as_the_bench_times_it(gpu_api, oracle):
+    p = W.config2()
+    assert p.cs == 2813
+    sb, fb, g = p.build(gpu_api)
+    for k, v in BENCH_OPTS.items():
+        g.set_option(k, v)
+    osb, ofb, og = p.build(oracle)
+    ref_pcm, _ = og.render_all(osb, ofb, p.cs, 16, want_f32=False)
+    for rep in range(2):
+        g.reset_normalize_vertices()          # the bench's step(): batch.rewind() + render
+        fb.set_time(0)
+        (pcm, f32), fam = _families(g, lambda: g.render_all(sb, fb, p.cs, 16, want_f32=False))
+        assert set(fam) == {"k_sum"} and fam["k_sum"][1] == 1, fam      # ONE launch: no k_scale, no k_norm_fix
+        assert f32 is None
+        assert np.array_equal(pcm, ref_pcm)
+        assert g.get_normalization_value("sum") == og.get_normalization_value("sum")
+        two = np.zeros(2, np.float32)
+        with pytest.raises(gpu_api.TermdawError):                       # (no f32 copy of the output was kept)
+            gpu_api._check(gpu_api.lib().td_graph_read_f32(g.h, two.ctypes.data_as(gpu_api.C.POINTER(gpu_api.C.c_float)), 2))
+    assert g.norm_fix_runs() == 0
+
+
+def test_config5_share_exactly_as_the_bench_times_it(gpu_api, oracle):
+    """64 full-size projects through td_batch_* with the bench's options: per-project PCM digest and the peak table."""
+    n = 64
+    batch, first = tb.build_shard(gpu_api, lambda pid: W.config2(seed_offset=64 * pid), list(range(n)), BENCH_OPTS)
+    cs = first.cs
+    want_digest, want_peak = [], []
+    for pid in range(n):
+        p = W.config2(seed_offset=64 * pid)
+        osb, ofb, og = p.build(oracle)
+        pcm, _ = og.render_all(osb, ofb, p.cs, 16, want_f32=False)
+        want_digest.append(_digest(pcm))
+        want_peak.append(np.float32(og.get_normalization_value("sum")))
+        del p, osb, ofb, og, pcm
+    batch.set_profiling(1)
+    batch.rewind()
+    assert batch.render_all(cs, 16) == cs * 1024
+    fam = batch.kernel_times()
+    batch.set_profiling(0)
+    assert set(fam) == {"k_sum"}, fam
+    assert [_digest(batch.read_pcm(i, cs)) for i in range(n)] == want_digest
+    assert np.array_equal(_bits(batch.peaks()), _bits(np.array(want_peak, np.float32)))
+
+
+@pytest.mark.parametrize("debug", [0, 1])
+def test_config2_120s_grid_beyond_the_resident_capacity(gpu_api, oracle, debug):
+    """5 626 blocks: 1 407 workgroups of k_sum16w<4> -- more than the device holds at once, so the engine picks mode 4
+    (bounded wait).  Fresh, then again without a reset (the running peak carries over), both byte for byte; debug 1 makes
+    every tile give up at once: k_norm_fix redoes the whole vertex from the stored block peaks."""
+    p = W.config2(seconds=120.0)
+    assert p.cs == 5626
+    sb, fb, g = p.build(gpu_api)
+    for k, v in BENCH_OPTS.items():
+        g.set_option(k, v)
+    g.set_option("norm_debug", debug)
+    osb, ofb, og = p.build(oracle)
+    for rep in range(2):
+        fb.set_time(0)
+        ofb.set_time(0)
+        (pcm, _), fam = _families(g, lambda: g.render_all(sb, fb, p.cs, 16, want_f32=False))
+        ref, _ = og.render_all(osb, ofb, p.cs, 16, want_f32=False)
+        assert "k_scale" not in fam and "k_sum" in fam, fam
+        assert np.array_equal(pcm, ref), "render %d" % rep
+        assert g.get_normalization_value("sum") == og.get_normalization_value("sum")
+    if debug:
+        assert g.norm_fix_runs() >= 1
+
+
+@pytest.mark.parametrize("shape", ["wide", "narrow", "one_block"])
+def test_forced_give_up_in_the_resident_grid_forms(gpu_api, oracle, shape):
+    """Mode 5 (the grid fits the device): k_sum16w on config 2 at 60 s, k_norm1 on a short mixed project and on single
+    block pulls.  norm_debug 1: every tile but the first gives up, the host-visible word is raised, and the fix runs when
+    the results are asked for -- same bytes as the oracle, f32 copy included."""
+    if shape == "wide":
+        p = W.config2()
+    elif shape == "narrow":
+        p = W.config1(seconds=3.0)
+    else:
+        p = W.config1(seconds=0.2)
+    sb, fb, g = p.build(gpu_api)
+    g.set_option("norm_debug", 1)
+    osb, ofb, og = p.build(oracle)
+    if shape == "one_block":
+        for _ in range(p.cs):
+            got = g.render(sb, fb)
+            ref = og.render(osb, ofb)
+            fb.set_time_to_next_block()
+            ofb.set_time_to_next_block()
+            assert np.array_equal(_bits(got[0]), _bits(ref[0])) and np.array_equal(_bits(got[1]), _bits(ref[1]))
+        return
+    for rep in range(2):
+        fb.set_time(0)
+        ofb.set_time(0)
+        assert_bit_exact(g.render_all(sb, fb, p.cs, 16), og.render_all(osb, ofb, p.cs, 16))
+        assert g.get_normalization_value("sum") == og.get_normalization_value("sum")
+    assert g.norm_fix_runs() >= 2
+    # pipelined: two fresh renders queued back to back, results read afterwards -- the second's fix is the one that counts
+    g.set_option("norm_debug", 1)
+    for _ in range(2):
+        g.reset_normalize_vertices()
+        fb.set_time(0)
+        g.render_all_async(sb, fb, p.cs, 16)
+    g.sync()
+    og.reset_normalize_vertices()
+    ofb.set_time(0)
+    ref = og.render_all(osb, ofb, p.cs, 16)
+    pcm = np.zeros_like(ref[0])
+    gpu_api._check(gpu_api.lib().td_graph_read_pcm(g.h, pcm.ctypes.data_as(gpu_api.C.c_void_p), pcm.nbytes))
+    assert np.array_equal(pcm, ref[0])
+
+
+def test_bench_one_rank_over_rccl():
+    """`bench.py --gpus 1` with TD_BENCH_FORCE_DIST=1: init_process_group("nccl", device_id=...) and PeakExchange's
+    device-side all_reduce(max) run on the GPU under the driver's own command line; the line keeps its contract."""
+    env = dict(os.environ, TD_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline", "--projects-per-gpu", "3", "--seconds", "6"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and out["value"] > 0
+    assert out["exchange_backend"] == "nccl"
+    assert out["peak_table_entries"] == 3 and all(v > 0 for v in out["peak_table"])

@@ -1,0 +1,73 @@
+"""State::render end to end for a batch of projects (state.rs:477-577: render, quantise, hound WAV file): the pipelined
+form td_batch_render_to_files -- groups of projects rendering while a copy stream moves finished PCM into page-locked
+host memory and host threads write the files -- must produce, per project, the very file td_state_render writes for that
+project alone (same header, same words), and the same PCM the oracle renders."""
+import os
+
+import numpy as np
+import pytest
+
+from termdaw_amd import workloads as W
+
+pytestmark = pytest.mark.gpu
+
+
+def _projects():
+    return [W.config2(seconds=1.7, seed_offset=64 * 0), W.drum_project(seconds=1.7), W.config2(seconds=1.7, seed_offset=64 * 2),
+            W.config1(seconds=1.7), W.config2(seconds=1.7, n_src=9, seed_offset=64 * 4), W.drum_project(seconds=1.7),
+            W.config2(seconds=1.7, seed_offset=64 * 6)]
+
+
+@pytest.mark.parametrize("bits,group,writers", [(16, 2, 3), (16, 4, 1), (24, 3, 2), (16, 16, 8)])
+def test_batch_files_equal_the_single_project_files(gpu_api, oracle, tmp_path, bits, group, writers):
+    projects = _projects()
+    cs = projects[0].cs
+    batch = gpu_api.Batch()
+    for p in projects:
+        p.set_render_bitdepth(bits)
+        batch.add(*p.build(gpu_api))
+    paths = [str(tmp_path / ("b%d.wav" % i)) for i in range(len(projects))]
+    for rep in range(2):        # (the second call reuses the page-locked buffer, the streams and the events)
+        batch.rewind()
+        rep_t = batch.render_to_files(cs, bits, 48000, paths, group=group, writers=writers)
+        assert rep_t["bytes"] == sum(cs * p.bl * 2 * (4 if bits > 16 else 2) for p in projects)
+        assert rep_t["wall_ms"] > 0 and rep_t["copy_busy_ms"] > 0 and rep_t["gpu_render_span_ms"] > 0
+        for i, p in enumerate(projects):
+            # the file td_state_render writes for this project alone, from its Lua text
+            s = gpu_api.State("", 48000, p.bl)
+            assert s.refresh(p.to_lua(str(tmp_path / ("assets%d" % i)))), gpu_api.last_error()
+            one = str(tmp_path / ("s%d.wav" % i))
+            s.render(one)
+            assert open(paths[i], "rb").read() == open(one, "rb").read(), "project %d, call %d" % (i, rep)
+            # ... and the oracle's PCM words
+            ref_pcm, _ = p.render(oracle, want_f32=False)
+            assert np.array_equal(batch.host_pcm(i, bits), ref_pcm)
+            del s
+
+
+def test_render_to_host_without_files(gpu_api, oracle):
+    projects = _projects()[:3]
+    cs = projects[0].cs
+    batch = gpu_api.Batch()
+    for p in projects:
+        batch.add(*p.build(gpu_api))
+    batch.rewind()
+    t = batch.render_to_files(cs, 16, 48000, None, group=2)
+    assert t["write_span_ms"] == 0.0
+    for i, p in enumerate(projects):
+        assert np.array_equal(batch.host_pcm(i), p.render(oracle, want_f32=False)[0])
+    # the ordinary batch calls still work afterwards, on the same handles
+    batch.rewind()
+    batch.render_all(cs, 16)
+    assert np.array_equal(batch.read_pcm(0, cs), batch.host_pcm(0))
+
+
+def test_unwritable_path_is_an_error_not_a_crash(gpu_api, tmp_path):
+    p = W.config1(seconds=0.5)
+    batch = gpu_api.Batch()
+    batch.add(*p.build(gpu_api))
+    with pytest.raises(gpu_api.TermdawError):
+        batch.render_to_files(p.cs, 16, 48000, [str(tmp_path / "no_such_dir" / "x.wav")], group=1, writers=1)
+    batch.rewind()
+    batch.render_to_files(p.cs, 16, 48000, [str(tmp_path / "x.wav")], group=1, writers=1)
+    assert os.path.getsize(str(tmp_path / "x.wav")) == 44 + p.cs * 1024 * 4
