@@ -101,25 +101,54 @@ def ubench():
     return L
 
 
+def cpu_model():
+    """The host CPU's model string (/proc/cpuinfo), or "unknown"."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(project, frames, runs=5):
-    """Oracle ("port" of the reference algorithm) on one host core: whole config-2 project per run."""
+    """Oracle ("port" of the reference algorithm) on ONE host core, the process pinned to it for the measurement
+    (`taskset -c <core>`): whole config-2 project per run, median."""
     from oracle import binding as oracle
+    pinned = None
+    before = None
+    try:
+        before = os.sched_getaffinity(0)
+        pinned = min(before)
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        before = None
     times = []
-    for r in range(runs + 1):
-        built = project.build(oracle)
-        t0 = time.perf_counter()
-        project.render(oracle, built=built, want_f32=False)
-        dt = time.perf_counter() - t0
-        if r:
-            times.append(dt)
+    try:
+        for r in range(runs + 1):
+            built = project.build(oracle)
+            t0 = time.perf_counter()
+            project.render(oracle, built=built, want_f32=False)
+            dt = time.perf_counter() - t0
+            if r:
+                times.append(dt)
+    finally:
+        if before is not None:
+            try:
+                os.sched_setaffinity(0, before)
+            except OSError:
+                pass
     med = float(np.median(times))
     return {
         "value": round(frames / med / 1e6, 4),
         "unit": "Msamples/s",
         "cores": 1,
         "kind": "port",
-        "sample": "full workload (64 sampleloop -> normalize, %d frames) x %d runs, median; 1 thread of %d host cores; "
-                  "C++ restatement of the reference algorithm (oracle/), not the Rust binary" % (frames, runs, os.cpu_count()),
+        "sample": "full workload (%d frames) x %d runs, median" % (frames, runs),
+        "pinned_to_core": pinned,
+        "cpu": cpu_model(),
+        "host_cores": os.cpu_count(),
         "seconds_per_render": round(med, 4),
     }
 
@@ -431,6 +460,154 @@ def edge_buffer_mode(api, workloads, seconds, frames, copy_gbs, reps=5):
                     "says); HIP-event time per launch, %d renders; north_star asks >= 40 %% of the measured copy rate here" % reps}
 
 
+def pinned_d2h_gbs(nbytes, reps=3):
+    """The box's device -> page-locked host copy rate for one transfer of nbytes (torch, one stream), GB/s."""
+    import torch
+    n = max(1, nbytes // 4)
+    dev = torch.empty(n, dtype=torch.int32, device="cuda").zero_()
+    host = torch.empty(n, dtype=torch.int32, pin_memory=True)
+    host.copy_(dev, non_blocking=True)
+    torch.cuda.synchronize()
+    best = 0.0
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        host.copy_(dev, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize()
+        best = max(best, n * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del dev, host
+    return best
+
+
+def end_to_end(b64, cs, frames, render_only_ms_per_project):
+    """SURVEY 8(d) "report separately with D2H + file write": the config-5 share (64 projects) through
+    td_batch_render_to_files -- render in groups, a copy stream taking finished PCM to page-locked host memory under the
+    later renders, host threads writing the WAV files (tmpfs) -- outside the timed region, never `value`."""
+    import shutil
+    import tempfile
+    P = len(b64)
+    nbytes = frames * 4 * P
+    out = {"projects": P, "bytes": nbytes, "render_only_ms_per_project": round(render_only_ms_per_project, 5)}
+    try:
+        out["pinned_d2h_GBs_measured"] = round(pinned_d2h_gbs(nbytes // 8), 2)
+    except Exception as e:   # noqa: BLE001
+        out["pinned_d2h_GBs_measured"] = None
+        out["pinned_error"] = str(e)[:80]
+    group, writers = 8, max(1, min(16, (os.cpu_count() or 2) // 2))
+
+    def run(paths, reps):
+        best = None
+        for _ in range(reps):
+            b64.rewind()
+            t = b64.render_to_files(cs, 16, 48000, paths, group=group, writers=writers)
+            if best is None or t["wall_ms"] < best["wall_ms"]:
+                best = t
+        return best
+    run(None, 1)   # (allocates the page-locked buffer)
+    t = run(None, 3)
+    gbs = t["bytes"] / (t["copy_span_ms"] * 1e-3) / 1e9
+    out["render_d2h"] = {"ms_per_project": round(t["wall_ms"] / P, 5), "Msamples_per_s": round(frames * P / t["wall_ms"] / 1e3, 1),
+                         "d2h_GBs": round(gbs, 2), "d2h_busy_GBs": round(t["bytes"] / (t["copy_busy_ms"] * 1e-3) / 1e9, 2),
+                         "gpu_render_span_ms": round(t["gpu_render_span_ms"], 3), "copy_span_ms": round(t["copy_span_ms"], 3),
+                         "wall_ms": round(t["wall_ms"], 3)}
+    if out.get("pinned_d2h_GBs_measured"):
+        out["render_d2h"]["d2h_frac_of_pinned_rate"] = round(gbs / out["pinned_d2h_GBs_measured"], 4)
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    d = tempfile.mkdtemp(prefix="td_e2e_", dir=base)
+    try:
+        paths = [os.path.join(d, "p%02d.wav" % i) for i in range(P)]
+        run(paths, 1)
+        t = run(paths, 2)
+        out["render_d2h_wav"] = {"ms_per_project": round(t["wall_ms"] / P, 5), "Msamples_per_s": round(frames * P / t["wall_ms"] / 1e3, 1),
+                                 "write_span_ms": round(t["write_span_ms"], 3), "write_GBs": round(t["bytes"] / (max(t["write_span_ms"], 1e-6) * 1e-3) / 1e9, 2),
+                                 "wall_ms": round(t["wall_ms"], 3), "writers": writers, "group": group, "dir": "tmpfs" if base else "tmp"}
+        out["file_bytes_each"] = os.path.getsize(paths[0])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
+NOTES = "profiles/NOTES.md"   # the prose that used to ride in the line, by note id
+
+
+def compact(o):
+    """The ONE line the driver stores: every headline number, no prose (notes live in profiles/NOTES.md under the ids
+    given here); `--full` prints the long form instead."""
+    c = {k: o[k] for k in ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "exchange_backend", "steps", "warmup", "ms_per_step",
+                           "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in o}
+    cfg = o["config"]
+    c["config"] = {"workload": cfg["workload"], "frames_per_project": cfg["frames_per_project"], "projects_per_gpu": cfg["projects_per_gpu"],
+                   "vertices_per_project": cfg["vertices_per_project"], "normalize": cfg["normalize_id"], "output": "int16 PCM in HBM",
+                   "parallelism": cfg["parallelism_id"]}
+    r = o.get("roofline")
+    if r:
+        rr = {"bound": "hbm", "ceiling": r.get("bound"), "kernel": r.get("rocprof_kernel"), "avg_ms": r.get("avg_ms"), "achieved": r.get("achieved"),
+              "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic")}
+        tp = r.get("traffic_profiled") or {}
+        if tp:
+            rr["traffic_profiled"] = {"bytes": tp.get("bytes_per_launch"), "l2_hit": tp.get("l2_hit_rate"), "file": tp.get("profile")}
+        for k in ("bytes_per_frame", "ceiling_ms", "hbm_compulsory_bytes", "hbm_compulsory_frac", "frac_of_l2_peak", "frac_of_measured_copy", "measured_copy_GBs"):
+            if k in r:
+                rr[k] = r[k]
+        if "l2_mall_split" in r:
+            rr["l2_mall_split"] = {"floor_ms": r["l2_mall_split"]["floor_ms"], "frac": r["l2_mall_split"]["frac"]}
+        if "valu_profiled" in r:
+            rr["SQ_INSTS_VALU_profiled"] = round(r["valu_profiled"].get("SQ_INSTS_VALU", 0))
+        rr["note"] = NOTES + "#roofline"
+        c["roofline"] = rr
+    if "cpu_baseline" in o:
+        c["cpu_baseline"] = o["cpu_baseline"]
+        c["gpu_over_cpu_1thread"] = o.get("gpu_over_cpu_1thread")
+    e = o.get("edge_buffer_mode")
+    if e:
+        c["edge_buffer_mode"] = e if "error" in e else {k: e[k] for k in ("k_sum_ms", "k_scale_ms", "bytes_per_frame", "GB/s", "frac_hbm_peak", "frac_measured_copy",
+                                                                           "measured_copy_GBs", "ms_per_render") if k in e}
+        c["edge_buffer_mode"]["note"] = NOTES + "#edge_buffer_mode"
+    c5 = o.get("config5")
+    if c5:
+        c["config5"] = {k: c5[k] for k in ("value", "unit", "projects_per_gpu", "projects", "steps", "ms_per_step", "ms_per_project") if k in c5}
+    sc = o.get("scanned")
+    if sc:
+        c["scanned"] = {k: sc[k] for k in ("ms_per_render", "Msamples_per_s", "scan_ms", "ms_per_render_with_f32_copy") if k in sc}
+    if "with_f32_copy" in o:
+        c["with_f32_copy_ms"] = o["with_f32_copy"]["ms_per_render"]
+    if "pcie_inclusive" in o:
+        c["pcie_inclusive"] = {k: o["pcie_inclusive"][k] for k in ("ms_per_render", "Msamples_per_s")}
+    if "e2e" in o:
+        c["e2e"] = o["e2e"]
+    if "cpu_baseline_all_cores" in o:
+        a = o["cpu_baseline_all_cores"]
+        c["cpu_all_cores"] = {"value": a["value"], "cores": a["cores"], "gpu_over": o.get("gpu_over_cpu_all_cores")}
+    cf = o.get("configs")
+    if isinstance(cf, list):
+        rows = []
+        for x in cf:
+            row = {"config": x["config"], "ms": x["ms_per_render"], "Msps": x["Msamples_per_s"], "launches": x["launches_per_render"]}
+            if "band_mode" in x:
+                row["band_mode"] = x["band_mode"]
+            ks = x.get("kernels") or []
+            row["kernels"] = {k["kernel"]: k["ms_per_render"] for k in ks[:3]}
+            b = x.get("bound") or {}
+            if b:
+                row["bound"] = {"kind": b.get("kind"), "floor_ms": b.get("floor_ms"), "frac": b.get("frac")}
+                if b.get("SQ_INSTS_VALU_profiled"):
+                    row["bound"]["insts"] = round(b["SQ_INSTS_VALU_profiled"])
+            if x.get("batch"):
+                row["batch_ms_per_project"] = {str(e2["projects"]): e2.get("ms_per_project", e2.get("error")) for e2 in x["batch"]}
+            rows.append(row)
+        c["configs"] = rows
+        c["configs_note"] = NOTES + "#configs"
+    elif cf:
+        c["configs"] = cf
+    c["rooflines"] = [{k: r2.get(k) for k in ("kernel", "avg_ms", "launches", "achieved", "peak", "frac", "bytes_per_frame") if k in r2} for r2 in o.get("rooflines", [])]
+    for k in ("kernel_timing_every", "host_ms_per_step", "peak_table_entries", "device_bytes", "vertex_frames_per_s"):
+        if k in o:
+            c[k] = o[k]
+    c["peak_table"] = o.get("peak_table", [])[:4]
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cpu-worker", type=int, default=None, help=argparse.SUPPRESS)
@@ -443,6 +620,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="headline only: no config5 / scanned / configs / ceilings of other kernels")
     ap.add_argument("--no-fuse", action="store_true", help="edge-buffer model: one HBM buffer per source vertex (no source inlining)")
     ap.add_argument("--no-pack", action="store_true", help="inlined sources gather the f32 sample form (8 B/frame) instead of the packed 16-bit one")
+    ap.add_argument("--full", action="store_true", help="print the long form of the line (every note string and per-kernel breakdown) instead of the compact one")
     args = ap.parse_args()
     if args.cpu_worker is not None:
         cpu_worker(args.cpu_worker, args.seconds)
@@ -535,6 +713,12 @@ def main():
               "note": "BASELINE config 5's per-GPU share: 64 independent config-2 projects (seed offset 64 x project id) resident per GPU, "
                       "one batch submission per step (launches of the 64 projects merged into one grid per kernel family), ONE "
                       "all-reduce(max) of the %d-entry peak table in the timed region" % (64 * world)}
+        e2e = None
+        if rank == 0 and world == 1:
+            try:
+                e2e = end_to_end(b64, cs, frames, dt5 / c5_steps / 64 * 1e3)
+            except Exception as e:   # noqa: BLE001
+                e2e = {"error": str(e)[:200]}
         del b64
 
     result_line = None
@@ -692,6 +876,8 @@ def main():
                                    "per GPU per step (project p of the job on rank p mod N, seed offset 64*p)" % (args.seconds, P),
                        "frames_per_project": frames, "projects_per_gpu": P, "vertices_per_project": N_SRC + 1,
                        "source_inlining": not args.no_fuse, "packed_samples": (not args.no_fuse) and (not args.no_pack),
+                       "normalize_id": (("one launch" if "k_norm_fix" not in ktimes else "one launch + check launch") if single_pass else "two passes"),
+                       "parallelism_id": "project p on rank p mod N; one RCCL all-reduce(max) of the %d-entry peak table" % (P * world),
                        "normalize": ("single pass, ONE launch: sum, running peak through in-launch granules, scale and quantise (k_sum16w mode 5)"
                                      if "k_norm_fix" not in ktimes else
                                      "single pass: running peak through in-launch granules (k_sum16w mode 4) + k_norm_fix check") if single_pass
@@ -701,6 +887,7 @@ def main():
             "roofline": roofline,
             "rooflines": kernels,
             "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % prof_every,
+            "kernel_timing_every": prof_every,
             "prewarm": "%.2f s of untimed steps before the W warm-up steps (steady device clocks)" % PREWARM_S,
             "host_ms_per_step": {k: round(v / max(host["steps"], 1), 5) for k, v in host.items() if k != "steps"},
             "peak_table": [round(float(x), 6) for x in peaks[:16]],
@@ -711,6 +898,8 @@ def main():
         }
         if c5:
             out["config5"] = c5
+            if e2e:
+                out["e2e"] = e2e
         if world == 1 and not args.no_extras:
             sb0, fb0, g0 = batch.projects[0]
             # the reference's recommended workflow: `normalize` (scan_exact, state.rs:473) then `render`; the scan is paid
@@ -790,7 +979,7 @@ def main():
                 if allc:
                     out["cpu_baseline_all_cores"] = allc
                     out["gpu_over_cpu_all_cores"] = round(out["value"] / allc["value"], 1)
-        result_line = json.dumps(out)
+        result_line = json.dumps(out if args.full else compact(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -305,12 +305,13 @@ def test_a_non_finite_state_stays_non_finite(gpu_api, oracle, shape, bl, chunk):
     assert _rms(gf[ok], of[ok]) <= 1e-6 and np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1
 
 
-def test_a_long_chunk_of_a_vertex_that_is_not_pass_takes_the_exact_kernels(gpu_api, oracle):
-    """k_band_scan ends with a gather over ALL earlier tiles that waits without bound, and numbers its tiles by blockIdx: the
-    engine lets a vertex take it only where the grid is resident at once (band_scan_resident_capacity, a few hundred tiles of
-    4 096 frames).  Beyond that a vertex that is not `pass` keeps the exact kernels -- bit for bit the oracle -- while a `pass`
-    vertex (chain kernel, ticketed tiles) stays in scan mode at any length."""
-    for pass_, exact in ((False, True), (True, False)):
+def test_a_grid_longer_than_the_device_holds_stays_in_scan_mode(gpu_api, oracle):
+    """k_band_scan and k_band_chain both number their tiles by a ticket drawn at start: a workgroup only waits for lower
+    tickets, whose holders are running, so neither kernel depends on its grid being resident at once -- a 140 s chunk (1 641
+    tiles of 4 096 frames, several times what the device holds) of a vertex that is not `pass` (k_band_scan: look-back with
+    bounded waits, the all-earlier-tiles gather at the end) and of a `pass` vertex (chain kernel) both stay in scan mode,
+    inside the tolerance class."""
+    for pass_ in (False, True):
         p = W.ProjectScript(48000, 1024)
         p.set_length(140.0)
         p.assets["n"] = W.Asset(W.noise_int16(9, 30011))
@@ -327,8 +328,5 @@ def test_a_long_chunk_of_a_vertex_that_is_not_pass_takes_the_exact_kernels(gpu_a
         fam = set(built[2].kernel_times())
         built[2].set_profiling(0)
         want = p.render(oracle)
-        assert ("k_band_spec" in fam) == exact and ("k_band_scan" in fam) == (not exact), fam
-        if exact:
-            assert_bit_exact(got, want)
-        else:
-            assert_close(got, want)
+        assert "k_band_spec" not in fam and "k_band_scan" in fam, fam
+        assert_close(got, want)

@@ -90,11 +90,11 @@ def test_config5_share_exactly_as_the_bench_times_it(gpu_api, oracle):
 
 @pytest.mark.parametrize("debug", [0, 1])
 def test_config2_120s_grid_beyond_the_resident_capacity(gpu_api, oracle, debug):
-    """5 626 blocks: 1 407 workgroups of k_sum16w<4> -- more than the device holds at once, so the engine picks mode 4
+    """5 625 blocks: 1 407 workgroups of k_sum16w<4> -- more than the device holds at once, so the engine picks mode 4
     (bounded wait).  Fresh, then again without a reset (the running peak carries over), both byte for byte; debug 1 makes
     every tile give up at once: k_norm_fix redoes the whole vertex from the stored block peaks."""
     p = W.config2(seconds=120.0)
-    assert p.cs == 5626
+    assert p.cs == 5625
     sb, fb, g = p.build(gpu_api)
     for k, v in BENCH_OPTS.items():
         g.set_option(k, v)

@@ -27,22 +27,30 @@ def test_batch_files_equal_the_single_project_files(gpu_api, oracle, tmp_path, b
         p.set_render_bitdepth(bits)
         batch.add(*p.build(gpu_api))
     paths = [str(tmp_path / ("b%d.wav" % i)) for i in range(len(projects))]
-    for rep in range(2):        # (the second call reuses the page-locked buffer, the streams and the events)
+    obuilt = [p.build(oracle) for p in projects]
+    for rep in range(2):        # (the second call reuses the page-locked buffer, the streams and the events; vertex state carries over)
         batch.rewind()
         rep_t = batch.render_to_files(cs, bits, 48000, paths, group=group, writers=writers)
         assert rep_t["bytes"] == sum(cs * p.bl * 2 * (4 if bits > 16 else 2) for p in projects)
         assert rep_t["wall_ms"] > 0 and rep_t["copy_busy_ms"] > 0 and rep_t["gpu_render_span_ms"] > 0
         for i, p in enumerate(projects):
-            # the file td_state_render writes for this project alone, from its Lua text
-            s = gpu_api.State("", 48000, p.bl)
-            assert s.refresh(p.to_lua(str(tmp_path / ("assets%d" % i)))), gpu_api.last_error()
-            one = str(tmp_path / ("s%d.wav" % i))
-            s.render(one)
-            assert open(paths[i], "rb").read() == open(one, "rb").read(), "project %d, call %d" % (i, rep)
-            # ... and the oracle's PCM words
-            ref_pcm, _ = p.render(oracle, want_f32=False)
-            assert np.array_equal(batch.host_pcm(i, bits), ref_pcm)
-            del s
+            data = open(paths[i], "rb").read()
+            if rep == 0:
+                # the file td_state_render writes for this project alone, from its Lua text
+                s = gpu_api.State("", 48000, p.bl)
+                assert s.refresh(p.to_lua(str(tmp_path / ("assets%d" % i)))), gpu_api.last_error()
+                one = str(tmp_path / ("s%d.wav" % i))
+                s.render(one)
+                assert data == open(one, "rb").read(), "project %d" % i
+                del s
+            # ... and the oracle's PCM words, rendered the same number of times from the same rewinds
+            osb, ofb, og = obuilt[i]
+            og.reset_normalize_vertices()
+            ofb.set_time(0)
+            ref_pcm, _ = og.render_all(osb, ofb, cs, bits, want_f32=False)
+            assert np.array_equal(batch.host_pcm(i, bits), ref_pcm), "project %d, call %d" % (i, rep)
+            if bits == 16:
+                assert data[44:] == ref_pcm.tobytes()
 
 
 def test_render_to_host_without_files(gpu_api, oracle):

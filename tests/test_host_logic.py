@@ -209,3 +209,25 @@ def test_bench_helpers_format_in_both_normalize_forms():
         assert ("(4k+4)" in note) == single and "20 MB" in note
     assert mod.algorithmic_bytes_per_frame(64, True, True)["k_sum"] == 4.0 * 64 + 8.0
     assert mod.algorithmic_bytes_per_frame(64, False, False)["k_sum"] == 8.0 * 64 + 8.0
+
+
+def test_bench_line_compact_form_fits_the_drivers_tail():
+    """bench.py prints the compact form of its line: every headline number, no prose -- the long form of a committed run
+    compacts to well under the 6 KB the driver's stored tail holds, with the derived-mode entries ahead of `configs`."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    full["config"]["normalize_id"] = "one launch"
+    full["config"]["parallelism_id"] = "project p on rank p mod N; one RCCL all-reduce(max) of the 1-entry peak table"
+    c = bench.compact(full)
+    line = json.dumps(c)
+    assert len(line) <= 6000, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in c, k
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(c["roofline"]) and c["roofline"]["bound"] in ("hbm", "mfma")
+    assert "model" not in c["config"] and "workload" in c["config"]
+    keys = list(c)
+    assert keys.index("edge_buffer_mode") < keys.index("configs") and keys.index("config5") < keys.index("configs")
+    assert keys.index("scanned") < keys.index("configs")
+    assert os.path.exists(os.path.join(ROOT, "profiles", "NOTES.md"))
