@@ -367,7 +367,7 @@ struct td_batch {
     size_t host_steps = 0;
     // td_batch_render_to_files: the PCM of every project in page-locked host memory, filled by a copy stream while later
     // projects render; events: a group's render done / a project's copy done (+ timed pairs for the report)
-    hipStream_t copy_stream = nullptr;
+    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;
     uint8_t* host_pcm = nullptr;
     size_t host_pcm_cap = 0;
     std::vector<size_t> host_pcm_off, host_pcm_bytes;

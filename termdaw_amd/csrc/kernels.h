@@ -224,6 +224,11 @@ struct SynthDesc {
     // one is enabled), so its envelope value -- a pure function of the conf and the voice's clocks -- is reused
     uint32_t tf_env_src, tr_env_src;
     PanGain pg;
+    // 1: the interval table is cut at every envelope breakpoint and a voice is FOUR float4 -- (hz, env_t, 0, 0) and, per
+    // oscillator (square, top-flat, triangle), (s1, s2, A, B): envelope x velocity x volume x osc_amp_multiplier x shape scale
+    // = A + B ((t - s1) - s2), t = env_t + in-block offset (engine.cpp synth_refine_affine); 0: one float4 (hz, vel, env_t,
+    // rel_t) per voice, envelopes evaluated per frame (confs that can reach the `res <= -1.0` escape, zero-length pieces)
+    uint32_t affine, pad2;
 };
 
 // sampsyn_gen (extensions.rs:532-578) with this engine's own wavetable oscillator (the sampsyn crate is
@@ -457,7 +462,7 @@ void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStrea
 void launch_sample_multi(const MultiDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_lerp(const LerpDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_debug_sine(const SineDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
-void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, bool affine, hipStream_t s);   // every descriptor: SynthDesc::affine == affine
 void launch_sampsyn(const SampsynDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);

@@ -1471,6 +1471,116 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
     pa = make_float2(synth_frame(d, ma), two_a ? synth_frame(d, ma + 1u) : 0.0f);
     pb = make_float2(synth_frame(d, mb), two_b ? synth_frame(d, mb + 1u) : 0.0f);
 }
+// ---- the affine form (SynthDesc::affine): every oscillator's envelope x velocity x volume x amplitude scale is
+// A + B ((t - s1) - s2) inside an interval, (s1, s2, A, B) from the voice record (scalar loads) -- no piece selection, no
+// held level, no per-voice products on the device.  One voice, one frame pair:
+//   th = time hz;  sn = sin(th 2 pi);  t = env_t + off;
+//   square    clamp(sn, -z, z)            x  fma(u, B, A)      (1 / z folded into A, B)
+//   top-flat  (min(sn, z) + (1 - z) / 2)  x  fma(u, B, A)      (2 / (1 + z) folded)
+//   triangle  (4 |th - floor(th + 0.5)| - 1) x fma(u, B, A)
+// SHARE_TR: the triangle's conf is the top-flat's (BASELINE config 3's shape): same (s1, s2), one u for both.
+typedef float f4c __attribute__((ext_vector_type(4)));
+template <bool SQ, bool TF, bool TR, bool SHARE_TR>
+TD_DEV f2 synth_pair_affine(const f4c q0, const f4c q1, const f4c q2, const f4c q3, float zsq, float ztf, float tf_bias, f2 time, f2 off, f2 acc) {
+    const f2 th = time * q0.x;
+    const f2 t = q0.y + off;
+    f2 sn = (f2)(0.0f);
+    if (SQ || TF) sn = sin_any2(th * (2.0f * kPi));
+    if (SQ) {
+        const f2 ek = fma2((t - q1.x) - q1.y, (f2)(q1.w), (f2)(q1.z));
+        f2 c;   // clamp(sn, -z, z) as ONE v_med3_f32 (sn is finite: a polynomial of a finite argument)
+        c.x = __builtin_amdgcn_fmed3f(sn.x, -zsq, zsq);
+        c.y = __builtin_amdgcn_fmed3f(sn.y, -zsq, zsq);
+        acc = fma2(c, ek, acc);
+    }
+    f2 utf = (f2)(0.0f);
+    if (TF) {
+        utf = (t - q2.x) - q2.y;
+        const f2 ek = fma2(utf, (f2)(q2.w), (f2)(q2.z));
+        f2 m;   // min(sn, z) as the median of (sn, z, -inf): no canonicalising v_max in front of it
+        m.x = __builtin_amdgcn_fmed3f(sn.x, ztf, -__builtin_inff());
+        m.y = __builtin_amdgcn_fmed3f(sn.y, ztf, -__builtin_inff());
+        acc = fma2(m + tf_bias, ek, acc);
+    }
+    if (TR) {
+        const f2 u = SHARE_TR ? utf : (t - q3.x) - q3.y;
+        const f2 ek = fma2(u, (f2)(q3.w), (f2)(q3.z));
+        f2 fl = th + 0.5f;
+        fl.x = floorf(fl.x);
+        fl.y = floorf(fl.y);
+        const f2 dd = th - fl;
+        f2 w;   // 4 |d| - 1: the absolute value rides as a source modifier of a plain v_fma_f32
+        w.x = __builtin_fmaf(4.0f, __builtin_fabsf(dd.x), -1.0f);
+        w.y = __builtin_fmaf(4.0f, __builtin_fabsf(dd.y), -1.0f);
+        acc = fma2(w, ek, acc);
+    }
+    return acc;
+}
+// all voices of interval `it` for the lane's two frame pairs (uniform: the records come in through scalar loads)
+template <bool SQ, bool TF, bool TR, bool SHARE_TR>
+TD_DEV void synth_interval_affine(const SynthDesc& d, uint32_t it, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
+    const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
+    const uint32_t v0 = off_c[it], v1 = off_c[it + 1u];
+    const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
+    const float zsq = d.square.param, ztf = d.topflat.param, tf_bias = (1.0f - ztf) / 2.0f;
+    f4c q0 = vc[4u * v0], q1 = vc[4u * v0 + 1u], q2 = vc[4u * v0 + 2u], q3 = vc[4u * v0 + 3u];   // (v0 == v1: the table ends with spare records)
+    for (uint32_t v = v0; v < v1; ++v) {
+        // the next record's scalar loads fly under this voice's arithmetic
+        const f4c n0 = vc[4u * v + 4u], n1 = vc[4u * v + 5u], n2 = vc[4u * v + 6u], n3 = vc[4u * v + 7u];
+        a = synth_pair_affine<SQ, TF, TR, SHARE_TR>(q0, q1, q2, q3, zsq, ztf, tf_bias, ta, oa, a);
+        b = synth_pair_affine<SQ, TF, TR, SHARE_TR>(q0, q1, q2, q3, zsq, ztf, tf_bias, tb, ob, b);
+        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+    }
+}
+TD_DEV void synth_interval_affine_any(const SynthDesc& d, uint32_t it, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
+    const bool sq = d.square.volume > 0.0f, tf = d.topflat.volume > 0.0f, tr = d.triangle.volume > 0.0f;   // (uniform)
+    if (sq && tf && tr) {
+        if (d.tf_env_src == 0u && d.tr_env_src == 2u) synth_interval_affine<true, true, true, true>(d, it, ta, tb, oa, ob, a, b);
+        else synth_interval_affine<true, true, true, false>(d, it, ta, tb, oa, ob, a, b);
+    } else if (sq && tf) synth_interval_affine<true, true, false, false>(d, it, ta, tb, oa, ob, a, b);
+    else if (sq && tr) synth_interval_affine<true, false, true, false>(d, it, ta, tb, oa, ob, a, b);
+    else if (tf && tr) synth_interval_affine<false, true, true, false>(d, it, ta, tb, oa, ob, a, b);
+    else if (sq) synth_interval_affine<true, false, false, false>(d, it, ta, tb, oa, ob, a, b);
+    else if (tf) synth_interval_affine<false, true, false, false>(d, it, ta, tb, oa, ob, a, b);
+    else if (tr) synth_interval_affine<false, false, true, false>(d, it, ta, tb, oa, ob, a, b);
+}
+TD_DEV uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    return v;
+}
+TD_DEV void synth_quad_affine(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M, float2& pa, float2& pb) {
+    const bool two_a = ma + 1u < M, two_b = mb + 1u < M;
+    const uint32_t i0 = find_interval(d.tab, ma), i1 = two_a ? find_interval(d.tab, ma + 1u) : i0;
+    const uint32_t i2 = find_interval(d.tab, mb), i3 = two_b ? find_interval(d.tab, mb + 1u) : i2;
+    f2 ta = synth_time2(d, ma), tb = synth_time2(d, mb), oa = synth_off2(d, ma), ob = synth_off2(d, mb);
+    if (!two_a) { ta.y = ta.x; oa.y = oa.x; }
+    if (!two_b) { tb.y = tb.x; ob.y = ob.x; }
+    const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
+    f2 a = (f2)(0.0f), b = (f2)(0.0f);
+    if (__all((i0 == it0 && i1 == it0 && i2 == it0 && i3 == it0) ? 1 : 0)) {
+        synth_interval_affine_any(d, it0, ta, tb, oa, ob, a, b);
+    } else {
+        // The wave's frames lie in several intervals (an event or an envelope breakpoint inside its two 128-frame runs):
+        // one pass of the same voice loop per interval that holds any of them, every frame keeping the pass of its own.
+        uint32_t it = wave_min_u32(min(min(i0, i1), min(i2, i3)));
+        for (;;) {
+            f2 ca = (f2)(0.0f), cb = (f2)(0.0f);
+            synth_interval_affine_any(d, it, ta, tb, oa, ob, ca, cb);
+            if (i0 == it) a.x = ca.x;
+            if (i1 == it) a.y = ca.y;
+            if (i2 == it) b.x = cb.x;
+            if (i3 == it) b.y = cb.y;
+            // the next interval any frame of the wave lies in
+            const uint32_t big = 0xFFFFFFFFu;
+            const uint32_t nx = wave_min_u32(min(min(i0 > it ? i0 : big, i1 > it ? i1 : big), min(i2 > it ? i2 : big, i3 > it ? i3 : big)));
+            if (nx == big) break;
+            it = nx;
+        }
+    }
+    pa = make_float2(a.x, two_a ? a.y : 0.0f);
+    pb = make_float2(b.x, two_b ? b.y : 0.0f);
+}
 // (six workgroups per CU: 80 registers and a few spilled words instead of 100 -- 0.134 -> 0.126 ms on config 3; seven and eight
 // spill into the voice loop and lose)
 __global__ __launch_bounds__(kThreads, 6) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
@@ -1483,6 +1593,18 @@ __global__ __launch_bounds__(kThreads, 6) void k_synth(const SynthDesc* __restri
     const uint32_t mc0 = min(m0, M - 1u), mc1 = min(m1, M - 1u);
     float2 p0, p1;
     synth_quad(d, mc0, mc1, M, p0, p1);
+    if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(p0.x, p0.x, p0.y, p0.y), d.pg));
+    if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(p1.x, p1.x, p1.y, p1.y), d.pg));
+}
+// the affine form (every descriptor of the launch has SynthDesc::affine set: the engine groups them)
+__global__ __launch_bounds__(kThreads, 6) void k_synth_affine(const SynthDesc* __restrict__ descs, uint32_t M) {
+    const SynthDesc& d = descs[blockIdx.y];
+    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
+    const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
+    const uint32_t m1 = m0 + kTileFrames / 2;
+    const uint32_t mc0 = min(m0, M - 1u), mc1 = min(m1, M - 1u);
+    float2 p0, p1;
+    synth_quad_affine(d, mc0, mc1, M, p0, p1);
     if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(p0.x, p0.x, p0.y, p0.y), d.pg));
     if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(p1.x, p1.x, p1.y, p1.y), d.pg));
 }
@@ -3128,6 +3250,16 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         }
     };
 
+    {   // (experiment) phase groups: contiguous thirds / halves of the timeline start the stage loop a fraction of a stage apart
+        const uint32_t ng = (d.flags >> 4) & 0xFu, du = (d.flags >> 8) & 0xFFu;
+        if (ng > 1u && du) {
+            const uint32_t per = (d.n_tiles + ng - 1u) / ng, grp = tile / per;
+            if (grp) {
+                const unsigned long long t_end = wall_clock64() + (unsigned long long)grp * du * 10ull;   // du: 100-ns units (100 MHz clock)
+                while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(4);
+            }
+        }
+    }
     for (uint32_t s = 0; s < n_stages; ++s) {
         const BandStageDesc TD_CONST* const sp = stages + s;
         stamp(s, 0u);
@@ -3721,9 +3853,10 @@ void launch_debug_sine(const SineDesc* d, int n, uint32_t frames, uint32_t bl, h
     (void)bl;
     TD_BATCHED(k_debug_sine, tiles(frames), kThreads, d, n, frames);
 }
-void launch_synth(const SynthDesc* d, int n, uint32_t frames, hipStream_t s) {
+void launch_synth(const SynthDesc* d, int n, uint32_t frames, bool affine, hipStream_t s) {
     if (!n || !frames) return;
-    TD_BATCHED(k_synth, tiles(frames), kThreads, d, n, frames);
+    if (affine) TD_BATCHED(k_synth_affine, tiles(frames), kThreads, d, n, frames);
+    else TD_BATCHED(k_synth, tiles(frames), kThreads, d, n, frames);
 }
 void launch_sampsyn(const SampsynDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
