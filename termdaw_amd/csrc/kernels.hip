@@ -3260,24 +3260,34 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             }
         }
     }
+    // What a stage needs before its first instruction -- the two gammas, the table pointers, the first envelope link -- is
+    // read ONE STAGE AHEAD, in one batch of scalar loads: read where it is used, behind `&&` and `if`, it was five dependent
+    // scalar-cache round trips in front of every stage's recurrence.
+    struct StageHead { float lgam, hgam; const double* pw; const double* pk; uint32_t n_post; const float* env0; const float* env1; };
+    auto head_of = [&](uint32_t s) {
+        const BandStageDesc TD_CONST* const q = stages + s;
+        return StageHead{q->lgamma, q->hgamma, q->pw, q->pk, q->n_post, q->post[0].env, q->post[1].env};
+    };
+    StageHead head = head_of(0u);
     for (uint32_t s = 0; s < n_stages; ++s) {
         const BandStageDesc TD_CONST* const sp = stages + s;
         stamp(s, 0u);
-        const float lgam = sp->lgamma, hgam = sp->hgamma;
-        if (sp->pw != pw_cur) {   // (uniform; the stages of a chain of identical filters share their tables: loaded once)
-            pw_cur = sp->pw;
+        const StageHead next_head = head_of(min(s + 1u, n_stages - 1u));
+        const float lgam = head.lgam, hgam = head.hgam;
+        if (head.pw != pw_cur) {   // (uniform; the stages of a chain of identical filters share their tables: loaded once)
+            pw_cur = head.pw;
             pwl = pw_cur[lane];
             pwh = pw_cur[64u + lane];
             w16l = pw_cur[(lane & 15u) + 1u]; w16h = pw_cur[64u + (lane & 15u) + 1u];
             w32l = pw_cur[(lane & 31u) + 1u]; w32h = pw_cur[64u + (lane & 31u) + 1u];
         }
-        if (sp->pk != pk_cur) {
-            pk_cur = sp->pk;
+        if (head.pk != pk_cur) {
+            pk_cur = head.pk;
             pkl = pk_cur[lane]; pkh = pk_cur[kScanMaxK + lane];
             pkl2 = pk_cur[64u + lane]; pkh2 = pk_cur[kScanMaxK + 64u + lane];
         }
         // the next link's envelope gains for the lane's frames: issued now, used after the output
-        const float* env_pre = ((s + 1u < n_stages || nd) && sp->n_post) ? (sp->post[0].env ? sp->post[0].env : (sp->n_post > 1u ? sp->post[1].env : nullptr)) : nullptr;
+        const float* env_pre = ((s + 1u < n_stages || nd) && head.n_post) ? (head.env0 ? head.env0 : (head.n_post > 1u ? head.env1 : nullptr)) : nullptr;
         float4 envv[NP / 2];
 #pragma unroll
         for (int q = 0; q < NP / 2; ++q)
@@ -3466,6 +3476,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
             }
         }
+        head = next_head;
     }
     if (prof) return;
     // ---- the chain's end.  Once NaN, always NaN: the reference's smoother state never recovers, the look-back above forgets a
