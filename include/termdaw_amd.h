@@ -246,8 +246,10 @@ size_t td_batch_size(const td_batch* b);
 void td_batch_rewind(td_batch* b);
 /* td_graph_render_all[_async] for every project (each project's PCM / f32 stays readable through its own
  * td_graph_read_pcm / td_graph_output_pcm_device).  Returns n_blocks x the FIRST project's block length (projects of a
- * batch may differ in block length: project i rendered n_blocks x its own), 0 on failure.  On failure the FlowwBank
- * cursors of the projects compiled in the failing step are back where that step found them. */
+ * batch may differ in block length: project i rendered n_blocks x its own), 0 on failure.  A step that fails while its
+ * projects are being compiled (an out-of-range sample index, an impossible release note ...) leaves the HOST side of every
+ * project where the step found it -- FlowwBank cursor, playhead, loop cursors, carried voices, a pending reset_normalization --
+ * so the call can be repeated; what the device has already run cannot be taken back. */
 size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits);
 size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits);
 int td_batch_sync(td_batch* b);
@@ -284,6 +286,17 @@ td_state* td_state_new(const char* wdir, size_t project_samplerate, size_t buffe
 /* Reads <wdir>/project.toml ([settings] main, buffer_length=1024, project_samplerate=44100; config.rs:19-76). */
 td_state* td_state_open(const char* wdir);
 void td_state_free(td_state* s);
+/* Engine options of the State's graph (the keys of td_graph_set_option; they survive td_state_refresh).  ONE default
+ * differs from a bare td_graph: a State renders band-pass vertices in SCAN mode ("band_mode" 1) -- band_pass_gen
+ * (extensions.rs:654-689) as a blocked affine scan, tolerance class: <= 1e-6 RMS on the f32 output and +-1 LSB on the PCM
+ * against the reference's serial recurrence (measured 6.3e-8 RMS through 84 band-pass vertices in a row; above 1e-6 of the
+ * output peak only where a band-pass vertex removes >= 30 dB of its input and a Normalize vertex brings the rest back up: 8 of
+ * 18 000 random graphs, at most 3.3e-6).  That is the bound BASELINE's north_star sets for float filter paths, and it is what
+ * makes a deep effect chain fast: BASELINE config 4 (84 band-pass vertices) renders in 0.43 ms in scan mode and 12.0 ms with the
+ * exact kernels.  td_state_set_option(s, "band_mode", 0) selects the exact kernels -- bit-identical to the reference's
+ * recurrence, the mode every bit-exact parity test runs in; a project without band-pass vertices renders the same bytes in
+ * both. */
+int td_state_set_option(td_state* s, const char* key, long value);
 /* State::refresh state.rs:50-471 on the given Lua source / on <wdir>/<main>. 1 = loaded. */
 int td_state_refresh_source(td_state* s, const char* lua_source);
 int td_state_refresh(td_state* s);

@@ -27,11 +27,16 @@ def main(argv=None):
     ap.add_argument("--scan", action="store_true", help="run the exact normalisation scan before rendering")
     ap.add_argument("-o", "--output", default=None, help="override set_output_file()")
     ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--exact-bandpass", action="store_true",
+                    help="band-pass vertices through the exact kernels (bit-identical to the reference's recurrence; default: scan mode, "
+                         "<= 1e-6 RMS / +-1 LSB, 28x faster on a deep effect chain)")
     ap.add_argument("--stream", action="store_true", help="stream workflow: events from stdin, block pulls at the playhead")
     ap.add_argument("--realtime", action="store_true", help="with --stream: pace the pulls against the wall clock")
     args = ap.parse_args(argv)
     api.set_device(args.device)
     s = api.State(open_dir=args.project_dir)
+    if args.exact_bandpass:
+        s.set_option("band_mode", 0)
     if args.stream:
         return stream(s, args)
     t0 = time.perf_counter()

@@ -111,6 +111,7 @@ SIGNATURES = {
     "td_state_new": (_vp, [_cp, _sz, _sz]),
     "td_state_open": (_vp, [_cp]),
     "td_state_free": (None, [_vp]),
+    "td_state_set_option": (_i32, [_vp, _cp, _lng]),
     "td_state_refresh_source": (_i32, [_vp, _cp]),
     "td_state_refresh": (_i32, [_vp]),
     "td_state_scan_exact": (_i32, [_vp]),
@@ -564,6 +565,10 @@ class State:
     def refresh(self, source=None):
         ok = lib().td_state_refresh(self.h) if source is None else lib().td_state_refresh_source(self.h, source.encode())
         return bool(ok)
+
+    def set_option(self, key, value):
+        """Engine option of the State's graph; a State defaults to band_mode 1 (scan), set_option("band_mode", 0) = exact."""
+        _check(lib().td_state_set_option(self.h, key.encode(), int(value)))
 
     def scan_exact(self):
         _check(lib().td_state_scan_exact(self.h))

@@ -168,6 +168,7 @@ void td_samplebank::release(void* p) {
                 if (s.live == 0) {               // nothing left in it: reuse from the start, or give it back
                     // (kernels queued by td_graph_render_all_async / td_batch_render_all_async on the engines' non-blocking
                     // streams may still gather from this memory: the per-sample hipFree of the old path synchronised implicitly)
+                    (void)hipSetDevice(device);   // (the BANK's device, whatever the calling thread last selected)
                     (void)hipDeviceSynchronize();
                     if (i + 1 == v.size()) s.used = 0;
                     else { (void)hipFree(s.base); v.erase(v.begin() + (long)i); }
@@ -2764,6 +2765,38 @@ static int settle_before_render(td_graph* g) {
     return drain(g);
 }
 
+// What compiling a chunk changes on the host side of a project -- loop cursors, the carried state of event-driven vertices,
+// a pending reset_normalization, the playhead, the FlowwBank cursor -- so that a step that fails while compiling a LATER project
+// of the batch (or a later chunk) can put every project back where the step found it: a retry then renders the same thing.
+void HostSnapshot::take(const td_graph* g, const td_flowwbank* fb) {
+    t = g->t;
+    fb_frame = fb->frame;
+    fb_start = fb->start_indices;
+    v.resize(g->vertices.size());
+    for (size_t i = 0; i < v.size(); ++i) {
+        const Vertex& x = g->vertices[i];
+        v[i].loop_t = x.loop_t;
+        v[i].has_init_override = x.has_init_override;
+        v[i].peak_known = x.peak_known;
+        v[i].init_override = x.init_override;
+        v[i].state.clear();
+        save_state(x, v[i].state);
+    }
+}
+void HostSnapshot::put(td_graph* g, td_flowwbank* fb) const {
+    g->t = t;
+    fb->frame = fb_frame;
+    fb->start_indices = fb_start;
+    for (size_t i = 0; i < v.size() && i < g->vertices.size(); ++i) {
+        Vertex& x = g->vertices[i];
+        x.loop_t = v[i].loop_t;
+        x.has_init_override = v[i].has_init_override;
+        x.peak_known = v[i].peak_known;
+        x.init_override = v[i].init_override;
+        load_state(x, v[i].state);
+    }
+}
+
 // Renders n_blocks blocks in chunks.  advance_graph_time: Graph::render semantics (t += bl per block);
 // otherwise the scan's explicit j*bl clock starting at scan_t0 (graph.rs:229-233).
 int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan,
@@ -2779,9 +2812,16 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
     while (done < n_blocks) {
         const size_t nb = std::min(rp.chunk_blocks, n_blocks - done);
         cb.clear();
-        if (!compile_next_chunk(g, sb, fb, rp, done, nb, is_scan, advance_graph_time, scan_t0, cb)) return 0;
+        g->snapshot.take(g, fb);   // (a chunk that fails to compile or to submit leaves the host state where it found it)
+        if (!compile_next_chunk(g, sb, fb, rp, done, nb, is_scan, advance_graph_time, scan_t0, cb)) {
+            g->snapshot.put(g, fb);
+            return 0;
+        }
         const uint8_t* scratch_base = nullptr;
-        if (!submit_chunk(g->arena, cb, g->stream, g->prof, g, &scratch_base, &g->host_ms[2])) return 0;
+        if (!submit_chunk(g->arena, cb, g->stream, g->prof, g, &scratch_base, &g->host_ms[2])) {
+            g->snapshot.put(g, fb);
+            return 0;
+        }
         g->host_chunks += 1;
         if (!finish_chunk(g, rp, done, nb, advance_graph_time, scratch_base)) return 0;
         done += nb;
@@ -2848,27 +2888,30 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
         const auto t0 = std::chrono::steady_clock::now();
         cb.clear();
         bool any = false;
-        // (a failing project must not leave the cursors of the projects compiled before it in this step half-advanced)
-        std::vector<std::pair<size_t, std::vector<size_t>>> fb_before(P);
+        // (a failing step must not leave the projects compiled before the failure half-advanced: cursors, loop positions,
+        // carried voices, a consumed reset_normalization all go back to where this step found them)
+        auto roll_back = [&]() {
+            for (size_t q = 0; q < P; ++q)
+                if (nb[q]) b->graphs[lo + q]->snapshot.put(b->graphs[lo + q], b->fbs[lo + q]);
+        };
+        for (size_t i = 0; i < P; ++i) nb[i] = std::min(rp[i].chunk_blocks, n_blocks - done[i]);
+        for (size_t i = 0; i < P; ++i)
+            if (nb[i]) b->graphs[lo + i]->snapshot.take(b->graphs[lo + i], b->fbs[lo + i]);
         for (size_t i = 0; i < P; ++i) {
-            nb[i] = std::min(rp[i].chunk_blocks, n_blocks - done[i]);
             if (!nb[i]) continue;
             any = true;
-            td_flowwbank* fb = b->fbs[lo + i];
-            fb_before[i] = {fb->frame, fb->start_indices};
-            if (!compile_next_chunk(b->graphs[lo + i], b->sbs[lo + i], fb, rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
-                for (size_t q = 0; q <= i; ++q)
-                    if (nb[q]) {
-                        b->fbs[lo + q]->frame = fb_before[q].first;
-                        b->fbs[lo + q]->start_indices = fb_before[q].second;
-                    }
+            if (!compile_next_chunk(b->graphs[lo + i], b->sbs[lo + i], b->fbs[lo + i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
+                roll_back();
                 return 0;
             }
         }
         if (!any) break;
         const uint8_t* scratch_base = nullptr;
         b->host_ms[0] += ms_between(t0, std::chrono::steady_clock::now());
-        if (!submit_chunk(b->arena, cb, b->stream, b->prof, nullptr, &scratch_base, &b->host_ms[2])) return 0;
+        if (!submit_chunk(b->arena, cb, b->stream, b->prof, nullptr, &scratch_base, &b->host_ms[2])) {
+            roll_back();   // (host side only: what the device has already run of this step cannot be taken back)
+            return 0;
+        }
         for (size_t i = 0; i < P; ++i) {
             if (!nb[i]) continue;
             if (!finish_chunk(b->graphs[lo + i], rp[i], done[i], nb[i], advance_graph_time, scratch_base)) return 0;
@@ -3075,7 +3118,7 @@ void td_graph_free(td_graph* g) {
 }
 void td_graph_reset(td_graph* g) {
     if ((g->stream || !g->wavetables.empty()) && hipSetDevice(g->device) == hipSuccess) {
-        if (g->stream) (void)hipStreamSynchronize(g->stream);
+        if (g->stream) (void)drain(g);   // (a deferred k_norm_fix belongs to the vertices about to go)
         for (float* p : g->wavetables) (void)hipFree(p);
         free_tables(g);
     }

@@ -265,6 +265,19 @@ struct ChunkBuild {
 }  // namespace tde
 
 struct td_batch;
+struct td_graph;
+
+namespace tde {
+// What compiling a chunk changes on the host side of a project (engine.cpp): taken before a step, put back if it fails.
+struct HostSnapshot {
+    size_t t = 0, fb_frame = 0;
+    std::vector<size_t> fb_start;
+    struct V { uint64_t loop_t; bool has_init_override, peak_known; float init_override; std::string state; };
+    std::vector<V> v;
+    void take(const td_graph* g, const td_flowwbank* fb);
+    void put(td_graph* g, td_flowwbank* fb) const;
+};
+}  // namespace tde
 
 struct td_graph {
     // graph.rs:12-22
@@ -345,6 +358,7 @@ struct td_graph {
     std::vector<size_t> cursor_starts;
     double host_ms[4] = {0, 0, 0, 0};   // host time per run_chunk phase: compile, descriptors, upload, launches
     size_t host_chunks = 0;
+    tde::HostSnapshot snapshot;         // host state at the start of the chunk being compiled (restored if it fails)
 };
 
 // Many independent projects rendered together (BASELINE config 5: the body of State::render's loop,

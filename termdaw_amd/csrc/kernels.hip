@@ -2867,7 +2867,10 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         return (q & 1u) ? (uint32_t)(u >> 32) : (uint32_t)u;
     };
     bool state_may_be_written = tile == 0u;   // (this workgroup has seen "tile 0 has read the carried states")
-    uint32_t poisoned_at = n_stages;          // the first stage at which this tile's response or entry state was not finite (uniform)
+    // the first stage at which this tile's response or entry state was not finite (uniform), per channel: the left smoothers
+    // (chains 0, 2) and the right ones (chains 1, 3) -- the reference's cutl depends on the left pair only, cutr on the right
+    // (extensions.rs:674-687), so a right-channel NaN must not reach the left output or the left states
+    uint32_t poisoned_l = n_stages, poisoned_r = n_stages;
 
     const double* pw_cur = nullptr;
     double pwl = 1.0, pwh = 1.0;   // (1 - gamma)^(NF lane), low / high
@@ -3001,10 +3004,12 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         __syncthreads();
         // (x - x == 0 only for finite x: the tile's own response and the state entering it -- once either is not finite the
         // reference's state stays NaN for the rest of the chunk, see the end of the kernel)
-        if (poisoned_at == n_stages &&
-            (!(B[0] - B[0] == 0.0) || !(B[1] - B[1] == 0.0) || !(B[2] - B[2] == 0.0) || !(B[3] - B[3] == 0.0) || !(carry_s[0] - carry_s[0] == 0.0) ||
-             !(carry_s[1] - carry_s[1] == 0.0) || !(carry_s[2] - carry_s[2] == 0.0) || !(carry_s[3] - carry_s[3] == 0.0)))
-            poisoned_at = s;
+        if (poisoned_l == n_stages &&
+            (!(B[0] - B[0] == 0.0) || !(B[2] - B[2] == 0.0) || !(carry_s[0] - carry_s[0] == 0.0) || !(carry_s[2] - carry_s[2] == 0.0)))
+            poisoned_l = s;
+        if (poisoned_r == n_stages &&
+            (!(B[1] - B[1] == 0.0) || !(B[3] - B[3] == 0.0) || !(carry_s[1] - carry_s[1] == 0.0) || !(carry_s[3] - carry_s[3] == 0.0)))
+            poisoned_r = s;
         // entry state of the lane's run, exact arithmetic rounded once: excl + a^(NF lane) (xw + a_wave^wave C)
         double awpl = 1.0, awph = 1.0;
         for (uint32_t w = 0; w < wave; ++w) { awpl *= awl; awph *= awh; }
@@ -3106,25 +3111,44 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         // ---- once NaN, always NaN (the reference's smoother state never recovers; the look-back forgets a tile after K tiles):
         // every tile says at which stage it went non-finite and learns the same of ALL earlier tiles (lower tickets: their
         // holders are running and get here without waiting for anybody above them, so the wait needs no bound).
-        __shared__ uint32_t pz[kThreads / 64];
-        if (tid == 0u) granule_store(d.poison + tile, poisoned_at);
-        uint32_t pmin = n_stages;
-        (void)for_lower_granules(d.poison, tile, 0xFFFFFFFFu, [&pmin](uint32_t, uint32_t v) { pmin = min(pmin, v); });
+        __shared__ uint32_t pz[kThreads / 64][2];
+        if (tid == 0u) granule_store(d.poison + tile, poisoned_l | (poisoned_r << 16));   // (n_stages <= 128)
+        uint32_t pl = n_stages, pr = n_stages;
+        (void)for_lower_granules(d.poison, tile, 0xFFFFFFFFu, [&pl, &pr](uint32_t, uint32_t v) { pl = min(pl, v & 0xFFFFu); pr = min(pr, v >> 16); });
+        pl = min(pl, poisoned_l);   // (the tile's own verdict: its arithmetic has carried the NaN into its own frames already,
+        pr = min(pr, poisoned_r);   //  the states it may have to write below have not)
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) pmin = min(pmin, (uint32_t)__shfl_xor((int)pmin, off, 64));
-        if (lane == 0u) pz[wave] = pmin;
+        for (int off = 32; off > 0; off >>= 1) {
+            pl = min(pl, (uint32_t)__shfl_xor((int)pl, off, 64));
+            pr = min(pr, (uint32_t)__shfl_xor((int)pr, off, 64));
+        }
+        if (lane == 0u) { pz[wave][0] = pl; pz[wave][1] = pr; }
         __syncthreads();
-        pmin = min(min(pz[0], pz[1]), min(pz[2], pz[3]));
-        if (pmin < n_stages) {   // (rare)
+        pl = min(min(pz[0][0], pz[1][0]), min(pz[2][0], pz[3][0]));
+        pr = min(min(pz[0][1], pz[1][1]), min(pz[2][1], pz[3][1]));
+        if (pl < n_stages || pr < n_stages) {   // (rare)
             const float qnan = __uint_as_float(0x7FC00000u);
+            // a `pass` vertex' right output is r - cutl (quirk Q7): NaN with the LEFT smoothers; otherwise with the right ones
+            bool right_bad = pr < n_stages;
+            for (uint32_t s = pl; s < n_stages && !right_bad; ++s) right_bad = stages[s].pass != 0u;
+            const bool left_bad = pl < n_stages;
 #pragma unroll
-            for (int j = 0; j < NP; ++j) x[j] = make_float4(qnan, qnan, qnan, qnan);
+            for (int j = 0; j < NP; ++j) {
+                if (left_bad) { x[j].x = qnan; x[j].z = qnan; }
+                if (right_bad) { x[j].y = qnan; x[j].w = qnan; }
+            }
             if (mlast - tile0 < TILE && wave == 0u) {   // (the tile with the chunk's last frame: the states carried out of the chunk)
-                for (uint32_t s = pmin + lane; s < n_stages; s += 64u) {
+                for (uint32_t s = min(pl, pr) + lane; s < n_stages; s += 64u) {
                     float* sf = reinterpret_cast<float*>(stages[s].state);
                     const bool rr = stages[s].pass == 0u;
-                    if (stages[s].lgamma != 0.0f) { sf[0] = qnan; if (rr) sf[1] = qnan; }
-                    if (stages[s].hgamma != 0.0f) { sf[2] = qnan; if (rr) sf[3] = qnan; }
+                    if (s >= pl) {
+                        if (stages[s].lgamma != 0.0f) sf[0] = qnan;
+                        if (stages[s].hgamma != 0.0f) sf[2] = qnan;
+                    }
+                    if (s >= pr && rr) {
+                        if (stages[s].lgamma != 0.0f) sf[1] = qnan;
+                        if (stages[s].hgamma != 0.0f) sf[3] = qnan;
+                    }
                 }
             }
         }
@@ -3704,33 +3728,38 @@ constexpr int kMaxGridY = 65535;
         hipLaunchKernelGGL(KERNEL, dim3((GRID_X), std::min((N) - o_, kMaxGridY)), dim3(BLOCK), 0, s, (D) + o_, __VA_ARGS__)
 
 static const auto k_sum32w_2 = &k_sum16w<2, false>;   // (names without a comma for the launch macro)
-// Workgroups of a k_sum16w form that the device holds at once (0: unknown).  A single-pass Normalize whose grid fits
-// needs no check launch behind it (SumDesc mode 5).
+// Workgroups of a k_sum16w form that the device holds at once (0: unknown): a speed figure -- launch slices are sized so that
+// a slice's workgroups start together -- never a correctness assumption (the single-pass Normalize's waits are bounded).
+constexpr int kMaxDev = 16;   // the occupancy x CU caches below are kept per device (a process may drive several)
+static inline int cur_dev() { int d = 0; return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < kMaxDev) ? d : 0; }
 int sum16w_resident_capacity(int nq, bool packed) {
-    static int cap[3] = {-1, -1, -1};   // <4, true>, <2, true>, <2, false>
+    static int cap_all[kMaxDev][3];   // <4, true>, <2, true>, <2, false>; 0 = not asked yet (stored + 1)
+    int* const cap = cap_all[cur_dev()];
     const int i = packed ? (nq == 4 ? 0 : 1) : 2;
-    if (cap[i] < 0) {
+    if (cap[i] > 0) return cap[i] - 1;
+    {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
         hipError_t e = i == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sum16w<4, true>, kThreads, 0)
                      : i == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sum16w<2, true>, kThreads, 0)
                               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sum16w<2, false>, kThreads, 0);
-        cap[i] = (e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-                     ? per_cu * prop.multiProcessorCount : 0;
+        cap[i] = 1 + ((e == hipSuccess && hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+                          ? per_cu * prop.multiProcessorCount : 0);
     }
-    return cap[i];
+    return cap[i] - 1;
 }
 // k_norm1: the instantiation for (term mode, tiles per workgroup), its resident capacity, its launch
 template <int TMODE, int TPW>
 static int norm1_capacity_of() {
-    static int cap = -1;
-    if (cap < 0) {
+    static int cap_all[kMaxDev];   // per device; 0 = not asked yet (stored + 1)
+    int& cap = cap_all[cur_dev()];
+    if (cap == 0) {
         int per_cu = 0, dev = 0;
         hipDeviceProp_t prop;
-        cap = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_norm1<TMODE, TPW>, kThreads, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
-               hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0;
+        cap = 1 + ((hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_norm1<TMODE, TPW>, kThreads, 0) == hipSuccess && hipGetDevice(&dev) == hipSuccess &&
+                    hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0);
     }
-    return cap;
+    return cap - 1;
 }
 template <int TMODE>
 static int norm1_capacity_mode(int tpw) {
@@ -3941,15 +3970,16 @@ static int band_scan_min_blocks_per_cu() {   // over the term-mode instantiation
     return per_cu;
 }
 int band_scan_resident_capacity(int nf) {
-    static int cap[2] = {-1, -1};
+    static int cap_all[kMaxDev][2];   // per device; 0 = not asked yet (stored + 1)
+    int* const cap = cap_all[cur_dev()];
     const int i = nf == 16 ? 0 : 1;
-    if (cap[i] < 0) {
+    if (cap[i] == 0) {
         int dev = 0;
         hipDeviceProp_t prop;
         const int per_cu = nf == 16 ? band_scan_min_blocks_per_cu<16>() : band_scan_min_blocks_per_cu<8>();
-        cap[i] = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0;
+        cap[i] = 1 + ((hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? per_cu * prop.multiProcessorCount : 0);
     }
-    return cap[i];
+    return cap[i] - 1;
 }
 void launch_band_scan(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s) {
     if (!n || !frames) return;

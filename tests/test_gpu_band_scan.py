@@ -305,6 +305,32 @@ def test_a_non_finite_state_stays_non_finite(gpu_api, oracle, shape, bl, chunk):
     assert _rms(gf[ok], of[ok]) <= 1e-6 and np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1
 
 
+@pytest.mark.parametrize("silent", [0, 1])
+@pytest.mark.parametrize("shape", [(False,), (True,), (False, False), (True, False)])
+def test_a_non_finite_state_of_one_channel_stays_in_that_channel(gpu_api, oracle, silent, shape):
+    """The burst that overflows the smoothers lives in ONE channel (the other channel of the asset is silent): a vertex that
+    is not `pass` keeps its channels apart -- cutl comes from the left smoothers, cutr from the right ones
+    (extensions.rs:674-687) -- so only that channel turns NaN, now and in the carried states; a `pass` vertex' right output
+    is r - cutl (quirk Q7): NaN with the left channel, untouched by the right one.  NaN masks equal the oracle's per channel."""
+    p = _nan_burst_project(shape, 1024)
+    k = p.assets["k"].pcm.copy()
+    k[:, silent] = 0
+    p.assets["k"] = W.Asset(k)
+    built = _scan_build(p, gpu_api)
+    obuilt = p.build(oracle)
+    for rep in range(2):   # (the second render starts from the carried -- partly NaN -- filter states)
+        gp, gf = p.render(gpu_api, built=built)
+        op, of = p.render(oracle, built=obuilt)
+        assert np.array_equal(np.isnan(gf), np.isnan(of)), "render %d" % rep
+        if rep == 0:
+            nan_l, nan_r = np.isnan(of[:, 0]).any(), np.isnan(of[:, 1]).any()
+            assert nan_l or nan_r
+            if shape[-1] is False and len(shape) == 1:
+                assert nan_l != nan_r            # (the case is what it claims to be: one channel only)
+        ok = np.isfinite(of)
+        assert _rms(gf[ok], of[ok]) <= 1e-6 and np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1
+
+
 def test_a_grid_longer_than_the_device_holds_stays_in_scan_mode(gpu_api, oracle):
     """k_band_scan and k_band_chain both number their tiles by a ticket drawn at start: a workgroup only waits for lower
     tickets, whose holders are running, so neither kernel depends on its grid being resident at once -- a 140 s chunk (1 641

@@ -180,3 +180,35 @@ def test_config3_batch_of_8_scan(gpu_api, oracle):
     batch.render_all(cs, 16)
     for i, p in enumerate(projects):
         assert_close((batch.read_pcm(i, cs), _f32_of(gpu_api, batch, i, cs)), p.render(oracle))
+
+
+def test_a_failing_step_leaves_the_other_projects_where_it_found_them(gpu_api, oracle):
+    """A batch step in which a LATER project fails to compile (a sampleloop whose sample index lies outside its bank)
+    restores the host side of the projects compiled before it: the reset_normalization consumed from project 0, its loop
+    cursors, its FlowwBank cursor, the drum project's carried voices.  Rendered on their own afterwards they give exactly
+    what a fresh render gives -- the failed step has left no trace."""
+    p0, p1 = W.config2(seconds=1.0, n_src=5), W.drum_project(seconds=1.0)
+    cs = p0.cs
+    b0, b1 = p0.build(gpu_api), p1.build(gpu_api)
+    bad_sb, bad_fb, bad_g = gpu_api.SampleBank(48000), gpu_api.FlowwBank(48000, 1024), gpu_api.Graph(1024, 48000)
+    bad_g.add_sampleloop("x", 1.0, 0.0, 7)     # no such sample: the render fails while this project is compiled
+    bad_g.add_normalize("n", 1.0, 0.0)
+    bad_g.connect("x", "n")
+    bad_g.set_output("n")
+    batch = gpu_api.Batch()
+    batch.add(*b0)
+    batch.add(*b1)
+    # one good render first: carried state everywhere (running peak, voices)
+    batch.render_all(cs, 16)
+    ob0, ob1 = p0.build(oracle), p1.build(oracle)
+    ob0[2].render_all(ob0[0], ob0[1], cs, 16)
+    ob1[2].render_all(ob1[0], ob1[1], cs, 16)
+    batch.add(bad_sb, bad_fb, bad_g)
+    batch.rewind()
+    for (osb, ofb, og) in (ob0, ob1):
+        og.reset_normalize_vertices()
+        ofb.set_time(0)
+    with pytest.raises(gpu_api.TermdawError):
+        batch.render_all(cs, 16)
+    for (sb, fb, g), (osb, ofb, og) in ((b0, ob0), (b1, ob1)):
+        assert_bit_exact(g.render_all(sb, fb, cs, 16), og.render_all(osb, ofb, cs, 16))

@@ -38,6 +38,7 @@ def test_batch_files_equal_the_single_project_files(gpu_api, oracle, tmp_path, b
             if rep == 0:
                 # the file td_state_render writes for this project alone, from its Lua text
                 s = gpu_api.State("", 48000, p.bl)
+                s.set_option("band_mode", 0)   # (the batch's graphs were built with the graph-level default: exact)
                 assert s.refresh(p.to_lua(str(tmp_path / ("assets%d" % i)))), gpu_api.last_error()
                 one = str(tmp_path / ("s%d.wav" % i))
                 s.render(one)
@@ -79,3 +80,28 @@ def test_unwritable_path_is_an_error_not_a_crash(gpu_api, tmp_path):
     batch.rewind()
     batch.render_to_files(p.cs, 16, 48000, [str(tmp_path / "x.wav")], group=1, writers=1)
     assert os.path.getsize(str(tmp_path / "x.wav")) == 44 + p.cs * 1024 * 4
+
+
+def test_front_end_default_is_scan_mode(gpu_api, oracle, tmp_path):
+    """A State renders band-pass vertices in scan mode by default (td_state_set_option in termdaw_amd.h): the same bytes as a
+    graph with band_mode 1, within the tolerance class of the oracle; band_mode 0 gives the oracle's bytes; the setting
+    survives a refresh; a project without band-pass vertices is bit-exact either way."""
+    p = W.drum_project(seconds=1.7)
+    lua = p.to_lua(str(tmp_path / "a"))
+    ref_pcm, ref_f = p.render(oracle)
+    s = gpu_api.State("", 48000, 1024)
+    assert s.refresh(lua), gpu_api.last_error()
+    got = s.render_to_memory()
+    built = p.build(gpu_api)
+    built[2].set_option("band_mode", 1)
+    scan_pcm, scan_f = p.render(gpu_api, built=built)
+    assert np.array_equal(got, scan_pcm)
+    assert np.abs(got.astype(np.int64) - ref_pcm.astype(np.int64)).max() <= 1
+    assert np.sqrt(np.mean((scan_f.astype(np.float64) - ref_f.astype(np.float64)) ** 2)) <= 1e-6
+    s.set_option("band_mode", 0)
+    assert s.refresh(lua), gpu_api.last_error()      # (options survive State::refresh)
+    assert np.array_equal(s.render_to_memory(), ref_pcm)
+    q = W.config1(seconds=0.5)
+    s2 = gpu_api.State("", 48000, 1024)
+    assert s2.refresh(q.to_lua(str(tmp_path / "b")))
+    assert np.array_equal(s2.render_to_memory(), q.render(oracle)[0])

@@ -431,6 +431,7 @@ def test_project_with_midi_file(gpu_api, oracle, tmp_path):
     (d / "song.mid").write_bytes(data)
     lua = lua.replace(old, 'load_midi_floww("%s", "%s");' % (name, d / "song.mid"))
     s = gpu_api.State("", p.psr, p.bl)
+    s.set_option("band_mode", 0)   # (the front-end's default is scan mode: this test compares bytes)
     assert s.refresh(lua), gpu_api.last_error()
     pcm = s.render_to_memory()
     assert np.array_equal(pcm, want[0])

@@ -91,6 +91,7 @@ def test_state_renders_project_from_files(gpu_api, oracle, tmp_path):
     (tmp_path / "project.toml").write_text('[project]\nname = "t"\n[settings]\nmain = "project.lua"\nbuffer_length = 1024\nproject_samplerate = 48000\n')
     (tmp_path / "project.lua").write_text(lua + 'set_output_file("%s")\n' % str(tmp_path / "out.wav"))
     s = gpu_api.State(open_dir=str(tmp_path))
+    s.set_option("band_mode", 0)   # (the front-end's default is scan mode: this test compares bytes)
     assert s.refresh(), gpu_api.last_error()
     s.scan_exact()
     s.render()
