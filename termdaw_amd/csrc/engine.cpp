@@ -2355,8 +2355,10 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         if (norm_desc_off[i] != (size_t)-1) ptr_field(o, offsetof(BandScanDesc, norm), norm_desc_off[i]);
                         cb.sync_fix.push_back({o + offsetof(BandScanDesc, ticket), cb.sync_bytes});   // {tile counter, "states read"}
                         cb.sync_bytes += 64;
-                        {   // one granule per tile: the stage it went non-finite at
+                        {   // one granule per tile: the stage it went non-finite at; and the frame its right input did (k_band_chain)
                             cb.sync_fix.push_back({o + offsetof(BandScanDesc, poison), cb.sync_bytes});
+                            cb.sync_bytes += ((size_t)scan_plan[vs[i]].n_tiles * 8 + 63) & ~(size_t)63;
+                            cb.sync_fix.push_back({o + offsetof(BandScanDesc, rpoison), cb.sync_bytes});
                             cb.sync_bytes += ((size_t)scan_plan[vs[i]].n_tiles * 8 + 63) & ~(size_t)63;
                         }
                     }

@@ -399,7 +399,12 @@ struct BandScanDesc {
     // (n_stages: never).  The reference's state stays NaN for good once it is; the look-back forgets a tile after K tiles,
     // so every tile learns at the end of the chain whether ANY earlier tile was poisoned and turns NaN itself if so
     unsigned long long* poison;
-    unsigned long long pad2;
+    // k_band_chain: [n_tiles] granules, zeroed before the launch -- the first frame of the chunk (or 0xFFFFFFFF: none) at which
+    // the chain's RIGHT input is not finite (tile 0: frame 0 when a carried right smoother state is not).  A `pass` vertex'
+    // right output is cutr * 0 + (r - cutl) * 1 (extensions.rs:682-687): its right smoothers, which this kernel does not
+    // run, reach the output in exactly one way -- once non-finite (an infinite or NaN right input frame makes them so, for
+    // good) they turn it NaN.  Every tile publishes this at its start and reads all earlier tiles' at its end.
+    unsigned long long* rpoison;
 };
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
 int band_scan_resident_capacity(int nf);   // workgroups of k_band_scan resident at once (0: unknown)

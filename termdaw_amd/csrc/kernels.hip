@@ -2781,14 +2781,14 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         lgam = sp->lgamma; hgam = sp->hgamma;
         al = 1.0 - (double)lgam; ah = 1.0 - (double)hgam; gl = (double)lgam; gh = (double)hgam;
         awl = sp->aw[0]; awh = sp->aw[1];
-        need_r = sp->pass == 0u;
+        // (the right-channel smoothers always run here: a `pass` vertex' right output is r - cutl, but the reference's
+        // expression is cutr * 0 + (r - cutl) * 1 -- a right smoother gone non-finite does reach the output, as NaN)
+        need_r = true;
     };
     // ---- zero-state responses of x: of the lane's run (b), of the wave up to the lane (excl), of the tile up to the
     // wave (xw), of the whole tile (B).  Used for the workgroup's own tile and, should a predecessor of a single vertex
     // fail to publish in time, for that predecessor's tile: identical arithmetic, identical values.
-    // need_r: the right-channel smoothers (chains 1, 3).  A `pass` vertex' right output is r - cutl (extensions.rs:685,
-    // quirk Q7): its right smoothers reach no output, now or after any later chunk, so they are not run (their two state
-    // words are left as they are; their granules carry zeros).
+    // need_r: the right-channel smoothers (chains 1, 3) run (always, in this kernel).
     auto pass1 = [&](uint32_t s, bool is_tile0) {
         double b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
         if (need_r) {
@@ -3115,8 +3115,8 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         if (tid == 0u) granule_store(d.poison + tile, poisoned_l | (poisoned_r << 16));   // (n_stages <= 128)
         uint32_t pl = n_stages, pr = n_stages;
         (void)for_lower_granules(d.poison, tile, 0xFFFFFFFFu, [&pl, &pr](uint32_t, uint32_t v) { pl = min(pl, v & 0xFFFFu); pr = min(pr, v >> 16); });
-        pl = min(pl, poisoned_l);   // (the tile's own verdict: its arithmetic has carried the NaN into its own frames already,
-        pr = min(pr, poisoned_r);   //  the states it may have to write below have not)
+        // (EARLIER tiles only: inside the tile that goes non-finite itself the arithmetic carries the NaN from the frame it
+        // appears at -- the frames before it stay what they are -- and into the states it stores)
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
             pl = min(pl, (uint32_t)__shfl_xor((int)pl, off, 64));
@@ -3128,10 +3128,10 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         pr = min(min(pz[0][1], pz[1][1]), min(pz[2][1], pz[3][1]));
         if (pl < n_stages || pr < n_stages) {   // (rare)
             const float qnan = __uint_as_float(0x7FC00000u);
-            // a `pass` vertex' right output is r - cutl (quirk Q7): NaN with the LEFT smoothers; otherwise with the right ones
-            bool right_bad = pr < n_stages;
-            for (uint32_t s = pl; s < n_stages && !right_bad; ++s) right_bad = stages[s].pass != 0u;
-            const bool left_bad = pl < n_stages;
+            // out_l = cutl cut_mul + (l - cutl) pass_mul,  out_r = cutr cut_mul + (r - cutl) pass_mul  (extensions.rs:682-687, one
+            // of the two factors 0, the other 1): a non-finite cutl turns BOTH outputs NaN whatever the vertex passes, a
+            // non-finite cutr the right one only
+            const bool left_bad = pl < n_stages, right_bad = left_bad || pr < n_stages;
 #pragma unroll
             for (int j = 0; j < NP; ++j) {
                 if (left_bad) { x[j].x = qnan; x[j].z = qnan; }
@@ -3239,6 +3239,35 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         for (int j = 0; j < NP; ++j) x[j] = xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j];
     }
     bool state_may_be_written = tile == 0u;
+    // ---- the right channel's only way into a `pass` vertex' output other than r - cutl: cutr * 0 (extensions.rs:686-687), NaN
+    // once a right smoother is not finite -- which it is from the first non-finite right INPUT frame on, for good, in every
+    // stage from there (the NaN output is the next stage's input), or from the chunk's start when a carried right state is
+    // not.  The right smoothers are not run here; the tile says where its right input first goes non-finite (one granule,
+    // published now, read by every later tile at the chain's end).
+    __shared__ uint32_t rfirst_s[kThreads / 64];   // (read again at the chain's end: nothing is kept in a register across the stages)
+    {
+        uint32_t rf = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = NP - 1; j >= 0; --j) {
+            const uint32_t m = mf + 2u * (uint32_t)j;
+            if (m + 1u < M && !(x[j].w - x[j].w == 0.0f)) rf = m + 1u;
+            if (m < M && !(x[j].y - x[j].y == 0.0f)) rf = m;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rf = min(rf, (uint32_t)__shfl_xor((int)rf, off, 64));
+        if (tile == 0u) {   // carried right states (a vertex about to be re-seeded from buf[0] carries none); a stage per lane:
+            bool bad = false;   // tile 0 heads every dependency chain of the launch -- nothing serial in front of its first stage
+            for (uint32_t s = lane; s < n_stages; s += 64u) {
+                const BandStageDesc* const q = d.stages + s;   // (per-lane addresses: vector loads)
+                if (__float_as_uint(st_l[s][4]) != 0u) continue;
+                bad = bad || (q->lgamma != 0.0f && !(st_l[s][1] - st_l[s][1] == 0.0f)) || (q->hgamma != 0.0f && !(st_l[s][3] - st_l[s][3] == 0.0f));
+            }
+            if (__any(bad ? 1 : 0)) rf = 0u;
+        }
+        if (lane == 0u) rfirst_s[wave] = rf;
+        __syncthreads();
+        if (tid == 0u) granule_store(d.rpoison + tile, min(min(rfirst_s[0], rfirst_s[1]), min(rfirst_s[2], rfirst_s[3])));
+    }
     uint32_t poisoned_at = n_stages;   // (wave 0) the first stage at which this tile's totals or entry state were not finite
     const double* pw_cur = nullptr;
     const double* pk_cur = nullptr;
@@ -3246,7 +3275,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     double w16l = 0.0, w16h = 0.0;   // (1 - gamma)^(NF ((lane % 16) + 1)): what the row before still weighs at this lane
     double w32l = 0.0, w32h = 0.0;   // (1 - gamma)^(NF ((lane % 32) + 1)): ... the half wave before
     double pkl = 0.0, pkh = 0.0;     // (1 - gamma)^(NF 256 lane): the weight of the tile lane + 1 tiles back
-    double pkl2 = 0.0, pkh2 = 0.0;   // ... and of tile 65 + lane back
     const bool tail = wt0 + WT > M;  // (uniform: only the chunk's last wave-tiles have frames beyond M)
     const bool fin_here = mlast >= wt0 && mlast - wt0 < WT;
     // (timing experiments, flags bit 2: the wave's clock at eight points of every stage, written over its frames of the
@@ -3308,14 +3336,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         if (head.pk != pk_cur) {
             pk_cur = head.pk;
             pkl = pk_cur[lane]; pkh = pk_cur[kScanMaxK + lane];
-            pkl2 = pk_cur[64u + lane]; pkh2 = pk_cur[kScanMaxK + 64u + lane];
         }
-        // the next link's envelope gains for the lane's frames: issued now, used after the output
         const float* env_pre = ((s + 1u < n_stages || nd) && head.n_post) ? (head.env0 ? head.env0 : (head.n_post > 1u ? head.env1 : nullptr)) : nullptr;
-        float4 envv[NP / 2];
-#pragma unroll
-        for (int q = 0; q < NP / 2; ++q)
-            envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
         // ---- zero-state responses inside the lane's run
         // (the {low, high} smoother pair of a frame is one packed operand from here to the output)
         f32x2 z[NF];
@@ -3343,6 +3365,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         stamp(s, 2u);
         __syncthreads();   // barrier 1: the four waves' totals
         stamp(s, 3u);
+        // the next link's envelope gains for the lane's frames: issued now -- the look-back's round trip lies ahead, and the
+        // eight registers are not held through the recurrence and the scan --, used after the output
+        float4 envv[NP / 2];
+#pragma unroll
+        for (int q = 0; q < NP / 2; ++q)
+            envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
         double xw0 = 0.0, xw2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave; a_wave^wave
         for (uint32_t w = 0; w < wave; ++w) {   // (uniform trip count)
             awp0 *= sp->aw[0]; awp2 *= sp->aw[1];
@@ -3398,8 +3426,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                     if (mine) {
                         const double B0 = __longlong_as_double((long long)((g0 & 0xFFFFFFFFull) | (g1 << 32)));
                         const double B2 = __longlong_as_double((long long)((g2 & 0xFFFFFFFFull) | (g3 << 32)));
-                        C0 = __builtin_fma(base ? pkl2 : pkl, B0, C0);
-                        C2 = __builtin_fma(base ? pkh2 : pkh, B2, C2);
+                        // (tiles 65 + lane back -- a look-back deeper than 64 tiles, cut-offs below ~5 Hz -- fetch their weights here)
+                        C0 = __builtin_fma(base ? pk_cur[64u + lane] : pkl, B0, C0);
+                        C2 = __builtin_fma(base ? pk_cur[kScanMaxK + 64u + lane] : pkh, B2, C2);
                     }
                 }
                 // the wave's sum into lane 63: running sums inside the rows, then row / half-wave totals passed on
@@ -3512,26 +3541,62 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     __shared__ uint32_t pz[kThreads / 64], pt[kThreads / 64];
     __shared__ float nwm[kThreads / 64], npm[kThreads / 64];
     const float qnan = __uint_as_float(0x7FC00000u);
-    if (nd) {
+    // (the end phase computes its frame indices and addresses afresh, from a lane number and descriptor pointers the compiler
+    // cannot see through: shared with the input phase's identical expressions they were kept -- i.e. spilled to scratch, the
+    // stage loop runs at the register cap -- across all the stages: ~5 us per launch)
+    const BandScanDesc* dl = &d;
+    asm volatile("" : "+v"(dl));
+    const SumDesc TD_CONST* ndl = nd;
+    asm volatile("" : "+v"(ndl));
+    uint32_t lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const uint32_t mf_e = wt0 + (uint32_t)NF * lane_e;
+    float4* const xw4_e = xt + wave * 64u * (uint32_t)(NP + 1);
+    {   // the right channel from the first frame at which any tile's right input went non-finite (see rpoison above)
+        uint32_t r_from = min(min(rfirst_s[0], rfirst_s[1]), min(rfirst_s[2], rfirst_s[3]));   // the tile's own
+        (void)for_lower_granules(dl->rpoison, tile, 0xFFFFFFFFu, [&r_from](uint32_t, uint32_t v) { r_from = min(r_from, v); });
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) r_from = min(r_from, (uint32_t)__shfl_xor((int)r_from, off, 64));
+        if (lane_e == 0u) pz[wave] = r_from;
+        __syncthreads();
+        r_from = min(min(pz[0], pz[1]), min(pz[2], pz[3]));
+        __syncthreads();   // (pz is used again below)
+        if (r_from <= mlast) {   // (rare)
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
+                const uint32_t m = mf_e + 2u * (uint32_t)j;
+                if (m >= r_from) x[j].y = qnan;
+                if (m + 1u >= r_from) x[j].w = qnan;
+            }
+            if (fin_here) {   // the right states carried out of the chunk: every stage's (the NaN output of one is the input of the next)
+                for (uint32_t s = lane_e; s < n_stages; s += 64u) {
+                    float* sf = reinterpret_cast<float*>(stages[s].state);
+                    if (stages[s].lgamma != 0.0f) sf[1] = qnan;
+                    if (stages[s].hgamma != 0.0f) sf[3] = qnan;
+                }
+            }
+        }
+    }
+    if (ndl) {
         float pk = 0.0f;
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             x[j] = add4(make_float4(0.f, 0.f, 0.f, 0.f), x[j]);
-            const uint32_t m = mf + 2u * (uint32_t)j;
+            const uint32_t m = mf_e + 2u * (uint32_t)j;
             if (m < M) pk = fmaxf(fmaxf(pk, fabsf(x[j].x)), fabsf(x[j].y));   // (absmaxlen's fold: NaNs never win)
             if (m + 1u < M) pk = fmaxf(fmaxf(pk, fabsf(x[j].z)), fabsf(x[j].w));
         }
         pk = wave_max(pk);
-        if (lane == 0u) nwm[wave] = pk;
+        if (lane_e == 0u) nwm[wave] = pk;
         __syncthreads();
     }
     if (tid == 0u) {
-        if (nd) {
+        if (ndl) {
             asm volatile("" ::"v"(norm_init));   // (the carried max has been READ before this tile counts as published)
-            granule_store(nd->sync + tile, __float_as_uint(fmaxf(fmaxf(nwm[0], nwm[1]), fmaxf(nwm[2], nwm[3]))));
+            granule_store(ndl->sync + tile, __float_as_uint(fmaxf(fmaxf(nwm[0], nwm[1]), fmaxf(nwm[2], nwm[3]))));
             if (tile == 0u) {
-                nd->init_copy[0] = norm_init;
-                nd->init_copy[1] = nd->state->scan_max;
+                ndl->init_copy[0] = norm_init;
+                ndl->init_copy[1] = ndl->state->scan_max;
             }
         }
     }
@@ -3541,11 +3606,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         // (lower TICKETS: their holders are running and reach this point without waiting for anybody above them -- the
         // wait needs no bound, like the look-back's)
         const uint32_t ns = n_stages;
-        if (nd) (void)for_lower_granules2(d.poison, nd->sync, tile, 0xFFFFFFFFu, [&](uint32_t idx, uint32_t p, uint32_t v) {
+        if (ndl) (void)for_lower_granules2(dl->poison, ndl->sync, tile, 0xFFFFFFFFu, [&](uint32_t idx, uint32_t p, uint32_t v) {
                 pmin = min(pmin, p);
                 if (p < ns) ptile = min(ptile, idx);
                 pm = fmaxf(pm, __uint_as_float(v)); });
-        else (void)for_lower_granules(d.poison, tile, 0xFFFFFFFFu, [&](uint32_t idx, uint32_t p) { pmin = min(pmin, p); if (p < ns) ptile = min(ptile, idx); });
+        else (void)for_lower_granules(dl->poison, tile, 0xFFFFFFFFu, [&](uint32_t idx, uint32_t p) { pmin = min(pmin, p); if (p < ns) ptile = min(ptile, idx); });
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -3553,7 +3618,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         ptile = min(ptile, (uint32_t)__shfl_xor((int)ptile, off, 64));
     }
     pm = wave_max(pm);
-    if (lane == 0u) { pz[wave] = pmin; pt[wave] = ptile; npm[wave] = pm; }
+    if (lane_e == 0u) { pz[wave] = pmin; pt[wave] = ptile; npm[wave] = pm; }
     __syncthreads();
     pmin = min(min(pz[0], pz[1]), min(pz[2], pz[3]));
     ptile = min(min(pt[0], pt[1]), min(pt[2], pt[3]));
@@ -3563,58 +3628,58 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
 #pragma unroll
         for (int j = 0; j < NP; ++j) x[j] = make_float4(qnan, qnan, qnan, qnan);
         if (fin_here) {
-            for (uint32_t s = pmin + lane; s < n_stages; s += 64u) {
+            for (uint32_t s = pmin + lane_e; s < n_stages; s += 64u) {
                 float* sf = reinterpret_cast<float*>(stages[s].state);
                 if (stages[s].lgamma != 0.0f) sf[0] = qnan;
                 if (stages[s].hgamma != 0.0f) sf[2] = qnan;
             }
         }
-        if (nd) {
+        if (ndl) {
             // this tile's blocks hold nothing but NaN: no peak; and what the tiles after the first poisoned one published
             // was measured on frames that are NaN in truth: the maximum so far is that of the tiles up to it
             __syncthreads();
-            if (lane == 0u) nwm[wave] = 0.0f;
+            if (lane_e == 0u) nwm[wave] = 0.0f;
             float pm2 = 0.0f;
             const uint32_t upto = min(ptile + 1u, tile);
-            (void)for_lower_granules(nd->sync, upto, 0xFFFFFFFFu, [&pm2](uint32_t, uint32_t v) { pm2 = fmaxf(pm2, __uint_as_float(v)); });
+            (void)for_lower_granules(ndl->sync, upto, 0xFFFFFFFFu, [&pm2](uint32_t, uint32_t v) { pm2 = fmaxf(pm2, __uint_as_float(v)); });
             pm2 = wave_max(pm2);
-            if (lane == 0u) npm[wave] = pm2;
+            if (lane_e == 0u) npm[wave] = pm2;
             __syncthreads();
             pm = fmaxf(fmaxf(npm[0], npm[1]), fmaxf(npm[2], npm[3]));
         }
     }
-    if (nd) {
-        if (lane == 0u && wt0 < M) nd->peaks[wt] = nwm[wave];
+    if (ndl) {
+        if (lane_e == 0u && wt0 < M) ndl->peaks[wt] = nwm[wave];
         float run = fmaxf(pm, norm_init);                                   // max_(b-1) entering the tile's first block
         for (uint32_t w = 0; w <= wave; ++w) run = fmaxf(nwm[w], run);      // *max = buf_max.max(*max)
         const float r = 1.0f / run;
         PanGain npg;
-        npg.l_amp = nd->pg.l_amp; npg.r_amp = nd->pg.r_amp; npg.gain = nd->pg.gain; npg.flags = nd->pg.flags;
+        npg.l_amp = ndl->pg.l_amp; npg.r_amp = ndl->pg.r_amp; npg.gain = ndl->pg.gain; npg.flags = ndl->pg.flags;
 #pragma unroll
         for (int j = 0; j < NP; ++j)
-            xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j] = epilogue4(make_float4(x[j].x * r, x[j].y * r, x[j].z * r, x[j].w * r), npg);
+            xw4_e[lane_e * (uint32_t)(NP + 1) + (uint32_t)j] = epilogue4(make_float4(x[j].x * r, x[j].y * r, x[j].z * r, x[j].w * r), npg);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        float2* const nout = nd->out;
-        void* const npcm = nd->pcm;
-        const uint32_t nq = nd->qmode;
-        const float namp = nd->amplitude;
+        float2* const nout = ndl->out;
+        void* const npcm = ndl->pcm;
+        const uint32_t nq = ndl->qmode;
+        const float namp = ndl->amplitude;
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
-            const uint32_t m = wt0 + 2u * ((uint32_t)q * 64u + lane);
-            const float4 v = xw4[slot((uint32_t)q * 64u + lane)];
+            const uint32_t m = wt0 + 2u * ((uint32_t)q * 64u + lane_e);
+            const float4 v = xw4_e[slot((uint32_t)q * 64u + lane_e)];
             if (nout) store_pair(nout, m, M, v);
             if (nq) store_quant_pair(npcm, nq, m, M, v, namp);
         }
         // the wave holding the chunk's last frame has the running max of the chunk's last block
-        if (fin_here && lane == 0u) const_cast<NormState*>((const NormState*)nd->state)->max = run;
+        if (fin_here && lane_e == 0u) const_cast<NormState*>((const NormState*)ndl->state)->max = run;
         return;
     }
     // the last vertex' output, back through the wave's staging for coalesced stores
 #pragma unroll
-    for (int j = 0; j < NP; ++j) xw4[lane * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];
+    for (int j = 0; j < NP; ++j) xw4_e[lane_e * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
-    for (int q = 0; q < NP; ++q) store_pair(d.out, wt0 + 2u * ((uint32_t)q * 64u + lane), M, xw4[slot((uint32_t)q * 64u + lane)]);
+    for (int q = 0; q < NP; ++q) store_pair(dl->out, wt0 + 2u * ((uint32_t)q * 64u + lane_e), M, xw4_e[slot((uint32_t)q * 64u + lane_e)]);
 }
 
 // ------------------------------------------------------------------------------------------------
