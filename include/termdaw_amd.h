@@ -256,12 +256,13 @@ int td_batch_sync(td_batch* b);
 int td_batch_normalize_scan(td_batch* b, size_t chunks);    /* State::scan_exact (state.rs:473-475) per project */
 /* State::render (state.rs:477-577) for every project END TO END -- render, PCM to the host, WAV file (hound::WavWriter,
  * state.rs:508-575: the same header and words td_state_render writes) -- as a pipeline: the projects render in groups of
- * `group` (<= 0: 4), one submission each, queued back to back; a copy stream moves each project's PCM into page-locked host
- * memory as soon as its group has rendered, while later groups render; `writers` host threads write paths[i] as soon as
- * project i's copy has landed.  paths NULL (or writers 0): no files, the PCM stays readable through td_batch_host_pcm.
+ * `group` (<= 0: 8), one submission each, queued back to back, into ONE device arena (a project's PCM then lives in its slice
+ * of it: td_graph_read_pcm keeps working); a copy stream moves each group's PCM -- one contiguous transfer -- into page-locked
+ * host memory as soon as the group has rendered, while later groups render; `writers` host threads write paths[i] as soon as
+ * project i's group has landed.  paths NULL (or writers 0): no files, the PCM stays readable through td_batch_host_pcm.
  * Returns 1 when everything is written.  times (may be NULL): 8 doubles -- [0] wall ms of the call, [1] of which buffer /
  * event setup (first call), [2] GPU ms first render start -> last render end, [3] copy-stream ms first copy start -> last
- * copy end, [4] sum of the copies' own ms, [5] bytes copied, [6] host ms first file opened -> last file closed, [7] host ms
+ * copy end, [4] sum of the copies' own ms, [5] PCM bytes, [6] host ms first file opened -> last file closed, [7] host ms
  * spent enqueueing. */
 int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t render_sr, const char* const* paths, int group,
                              int writers, double* times);

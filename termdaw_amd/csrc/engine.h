@@ -316,6 +316,7 @@ struct td_graph {
     // outputs of the last render
     void* d_pcm = nullptr;
     size_t pcm_cap = 0, pcm_bytes = 0;
+    bool pcm_borrowed = false;                // d_pcm is a slice of the batch's PCM arena (td_batch_render_to_files), not the graph's own
     float2* d_out_f32 = nullptr;              // owned only for multi-chunk renders
     size_t out_f32_cap = 0;
     const float2* last_out_f32 = nullptr;
@@ -381,9 +382,11 @@ struct td_batch {
     size_t host_steps = 0;
     // td_batch_render_to_files: the PCM of every project in page-locked host memory, filled by a copy stream while later
     // projects render; events: a group's render done / a project's copy done (+ timed pairs for the report)
-    hipStream_t copy_stream = nullptr, copy_stream2 = nullptr;
+    hipStream_t copy_stream = nullptr;
     uint8_t* host_pcm = nullptr;
     size_t host_pcm_cap = 0;
+    uint8_t* d_pcm_arena = nullptr;      // device PCM of every project, in project order, slices laid out like host_pcm: a
+    size_t d_pcm_arena_cap = 0;          // group's PCM is ONE contiguous device -> host copy
     std::vector<size_t> host_pcm_off, host_pcm_bytes;
     std::vector<hipEvent_t> ev_pool;
 };
