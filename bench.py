@@ -49,7 +49,7 @@ SECONDS = 60.0
 N_SRC = 64
 PROF_EVERY = 8
 PREWARM_S = 0.25           # untimed, before the W warm-up steps: steady device clocks (see time_batch)
-PROFILE_TAG = "r03"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
+PROFILE_TAG = "r04"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
 
 
 def algorithmic_bytes_per_frame(k, fused, packed):

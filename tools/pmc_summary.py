@@ -10,6 +10,8 @@ def family(s):   # "void tdk::k_sum16w<4, true>(args)" -> ("k_sum", "tdk::k_sum1
     base = re.sub(r"<.*$", "", full).replace("tdk::", "")
     if base.startswith("k_sum"): base = "k_sum"
     if base == "k_band_chain": base = "k_band_scan"   # (the engine's launch family: a chain is a k_band_scan launch with several stages)
+    if base == "k_synth_affine": base = "k_synth"     # (the affine form of the same family)
+    if base == "k_norm1": base = "k_sum"              # (the narrow single-pass Normalize is launched as the summing family)
     return base, full
 
 def newest(pattern):
