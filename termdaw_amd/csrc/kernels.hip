@@ -3302,16 +3302,6 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         }
     };
 
-    {   // (experiment) phase groups: contiguous thirds / halves of the timeline start the stage loop a fraction of a stage apart
-        const uint32_t ng = (d.flags >> 4) & 0xFu, du = (d.flags >> 8) & 0xFFu;
-        if (ng > 1u && du) {
-            const uint32_t per = (d.n_tiles + ng - 1u) / ng, grp = tile / per;
-            if (grp) {
-                const unsigned long long t_end = wall_clock64() + (unsigned long long)grp * du * 10ull;   // du: 100-ns units (100 MHz clock)
-                while (wall_clock64() < t_end) __builtin_amdgcn_s_sleep(4);
-            }
-        }
-    }
     // What a stage needs before its first instruction -- the two gammas, the table pointers, the first envelope link -- is
     // read ONE STAGE AHEAD, in one batch of scalar loads: read where it is used, behind `&&` and `if`, it was five dependent
     // scalar-cache round trips in front of every stage's recurrence.
