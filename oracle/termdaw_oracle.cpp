@@ -302,25 +302,33 @@ bool sample_from(std::vector<float> l, std::vector<float> r, LoadMethod m, Sampl
 //   out[j] = sum_{k=0..255} in[i0 - 255 + k] * c_k,   x = j * from / to = i0 + frac   (zero outside the input):
 //   the filter centre sits sinc_len / 2 = 128 input frames behind x -- rubato's SincFixedIn delays its output by that
 //   much because it only looks at frames it has been handed (state.rs:545-560 feeds it block by block, never flushes)
-//   c_k    = T[p][k] * (1 - a) + T[p+1][k] * a,        p = floor(frac * 256), a = frac * 256 - p  (f32)
-//   T[p][k] = (f32)( fc * sinc(fc * d) * bh(u)^2 ),    d = k - 127 - p/256,  u = (d + 128) / 256,
-//             fc = 0.95 * min(1, to/from),  bh = 4-term Blackman-Harris;  table in f64, rounded once
+//   out[j] = (1 - a) y0 + a y1,  y_q = sum_k in[..] * T[p+q][k] (f32, taps in order) -- the two neighbouring phases are
+//            convolved and the RESULTS interpolated, rubato's interp_lin order;  p = floor(frac * 256), a = frac * 256 - p
+//   T[p][k] = (f32)( sinc(fc * d) * bh(u)^2 / norm ),  d = k - 127 - p/256,  u = (d + 128) / 256,
+//             fc = 0.95 * min(1, to/from),  bh = 4-term Blackman-Harris,  norm = (sum of the windowed sinc over all
+//             256 * 256 grid points) / 256 -- rubato's make_sincs normalisation;  table in f64, rounded once
 //   len_out = ceil(len * to / from); zero delay.
 const int kSincLen = 256, kSincOver = 256;
 void build_sinc_table(size_t from, size_t to, std::vector<float>* T) {
     const double ratio = (double)to / (double)from;
     const double fc = 0.95 * (ratio < 1.0 ? ratio : 1.0);
     const double pi = 3.14159265358979323846;
+    auto tap = [&](double d) {   // window^2 x sinc at d input frames from the filter centre (|d| <= 128)
+        const double z = fc * d;
+        const double sinc = z == 0.0 ? 1.0 : sin(pi * z) / (pi * z);
+        const double u = (d + 128.0) / 256.0;
+        const double bh = 0.35875 - 0.48829 * cos(2.0 * pi * u) + 0.14128 * cos(4.0 * pi * u) - 0.01168 * cos(6.0 * pi * u);
+        return sinc * bh * bh;
+    };
+    // normalisation as rubato's make_sincs does it (from the crate's published source, from memory -- unverified): the sum
+    // of ALL sinc_len * oversampling points of the windowed sinc, divided by the oversampling factor
+    double sum = 0.0;
+    for (int x = 0; x < kSincLen * kSincOver; ++x) sum += tap((double)(x - kSincLen * kSincOver / 2) / (double)kSincOver);
+    const double norm = sum / (double)kSincOver;
     T->resize((size_t)(kSincOver + 1) * kSincLen);
     for (int p = 0; p <= kSincOver; ++p)
-        for (int k = 0; k < kSincLen; ++k) {
-            const double d = (double)k - 127.0 - (double)p / (double)kSincOver;
-            const double z = fc * d;
-            const double sinc = z == 0.0 ? 1.0 : sin(pi * z) / (pi * z);
-            const double u = (d + 128.0) / 256.0;
-            const double bh = 0.35875 - 0.48829 * cos(2.0 * pi * u) + 0.14128 * cos(4.0 * pi * u) - 0.01168 * cos(6.0 * pi * u);
-            (*T)[(size_t)p * kSincLen + k] = (float)(fc * sinc * bh * bh);
-        }
+        for (int k = 0; k < kSincLen; ++k)
+            (*T)[(size_t)p * kSincLen + k] = (float)(tap((double)k - 127.0 - (double)p / (double)kSincOver) / norm);
 }
 void resample_planar(const std::vector<float>& l, const std::vector<float>& r, size_t from, size_t to,
                      std::vector<float>* ol, std::vector<float>* orr) {
@@ -339,16 +347,20 @@ void resample_planar(const std::vector<float>& l, const std::vector<float>& r, s
         const float a = (float)(ph % to) / (float)to;
         const float* t0 = &T[p * kSincLen];
         const float* t1 = &T[(p + 1) * kSincLen];
-        float al = 0.0f, ar = 0.0f;
+        // the two neighbouring phases' convolutions, then ONE interpolation of the results (rubato's interp_lin order:
+        // (1 - a) y0 + a y1 -- from the crate's published source, from memory, unverified)
+        float al0 = 0.0f, ar0 = 0.0f, al1 = 0.0f, ar1 = 0.0f;
         for (int k = 0; k < kSincLen; ++k) {
             const int64_t idx = i0 - (127 + 128) + k;   // delayed by sinc_len / 2 input frames (SincFixedIn's output delay)
             if (idx < 0 || idx >= (int64_t)len) continue;
-            const float c = t0[k] * (1.0f - a) + t1[k] * a;
-            al += l[(size_t)idx] * c;
-            ar += r[(size_t)idx] * c;
+            const float xl = l[(size_t)idx], xr = r[(size_t)idx];
+            al0 += xl * t0[k];
+            ar0 += xr * t0[k];
+            al1 += xl * t1[k];
+            ar1 += xr * t1[k];
         }
-        (*ol)[j] = al;
-        (*orr)[j] = ar;
+        (*ol)[j] = (1.0f - a) * al0 + a * al1;
+        (*orr)[j] = (1.0f - a) * ar0 + a * ar1;
     }
 }
 

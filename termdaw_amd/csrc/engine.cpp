@@ -81,16 +81,22 @@ static void build_sinc_table(size_t from, size_t to, std::vector<float>* T) {
     const double ratio = (double)to / (double)from;
     const double fc = 0.95 * (ratio < 1.0 ? ratio : 1.0);
     const double pi = 3.14159265358979323846;
+    auto tap = [&](double d) {   // window^2 x sinc at d input frames from the filter centre (|d| <= 128)
+        const double z = fc * d;
+        const double sinc = z == 0.0 ? 1.0 : sin(pi * z) / (pi * z);
+        const double u = (d + 128.0) / 256.0;
+        const double bh = 0.35875 - 0.48829 * cos(2.0 * pi * u) + 0.14128 * cos(4.0 * pi * u) - 0.01168 * cos(6.0 * pi * u);
+        return sinc * bh * bh;
+    };
+    // normalisation as rubato's make_sincs does it (from the crate's published source, from memory -- unverified): the sum
+    // of ALL sinc_len * oversampling points of the windowed sinc, divided by the oversampling factor
+    double sum = 0.0;
+    for (int x = 0; x < kSincLen * kSincOver; ++x) sum += tap((double)(x - kSincLen * kSincOver / 2) / (double)kSincOver);
+    const double norm = sum / (double)kSincOver;
     T->resize((size_t)(kSincOver + 1) * kSincLen);
     for (int p = 0; p <= kSincOver; ++p)
-        for (int k = 0; k < kSincLen; ++k) {
-            const double d = (double)k - 127.0 - (double)p / (double)kSincOver;
-            const double z = fc * d;
-            const double sinc = z == 0.0 ? 1.0 : sin(pi * z) / (pi * z);
-            const double u = (d + 128.0) / 256.0;
-            const double bh = 0.35875 - 0.48829 * cos(2.0 * pi * u) + 0.14128 * cos(4.0 * pi * u) - 0.01168 * cos(6.0 * pi * u);
-            (*T)[(size_t)p * kSincLen + k] = (float)(fc * sinc * bh * bh);
-        }
+        for (int k = 0; k < kSincLen; ++k)
+            (*T)[(size_t)p * kSincLen + k] = (float)(tap((double)k - 127.0 - (double)p / (double)kSincOver) / norm);
 }
 // Resamples `len` frames at `in` (device) from rate `from` to rate `to` into a fresh device buffer.
 int resample_device(const float2* in, size_t len, size_t from, size_t to, float2** out, size_t* nout_p, hipStream_t st) {

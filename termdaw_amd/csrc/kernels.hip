@@ -3674,7 +3674,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
 
 // ------------------------------------------------------------------------------------------------
 // k_resample: build-defined windowed-sinc resampler (specification in DESIGN.md "Resampler"; the oracle
-// implements the same arithmetic: taps in order k = 0..255, coefficient T0*(1-a) + T1*a, f32 accumulate)
+// implements the same arithmetic: taps in order k = 0..255 through BOTH neighbouring phases, f32 accumulate, then
+// (1 - a) y0 + a y1)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_resample(ResampleDesc d) {
     for (uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x; j < d.nout; j += (uint64_t)gridDim.x * kThreads) {
@@ -3686,16 +3687,17 @@ __global__ __launch_bounds__(kThreads) void k_resample(ResampleDesc d) {
         const float* __restrict__ t0 = d.table + p * kSincLen;
         const float* __restrict__ t1 = t0 + kSincLen;
         const float one_minus_a = 1.0f - a;
-        float al = 0.0f, ar = 0.0f;
+        float al0 = 0.0f, ar0 = 0.0f, al1 = 0.0f, ar1 = 0.0f;   // the two neighbouring phases' convolutions
         for (int k = 0; k < kSincLen; ++k) {
             const int64_t idx = i0 - (127 + kSincLen / 2) + k;   // (delayed by sinc_len / 2 input frames, see kernels.h)
             if (idx < 0 || idx >= (int64_t)d.len) continue;
-            const float c = t0[k] * one_minus_a + t1[k] * a;
             const float2 x = d.in[idx];
-            al += x.x * c;
-            ar += x.y * c;
+            al0 += x.x * t0[k];
+            ar0 += x.y * t0[k];
+            al1 += x.x * t1[k];
+            ar1 += x.y * t1[k];
         }
-        d.out[j] = make_float2(al, ar);
+        d.out[j] = make_float2(one_minus_a * al0 + a * al1, one_minus_a * ar0 + a * ar1);   // interp_lin over the RESULTS
     }
 }
 

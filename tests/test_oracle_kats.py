@@ -253,19 +253,23 @@ def test_graph_rules(oracle):   # graph.rs:58-174
 
 
 def test_sinc_table_sums_to_one():
-    """The stand-in resampler's taps T[p][k] = fc sinc(fc d) bh(u)^2 (the parameter set of sample.rs:152-158)
-    sum to 1 per phase within 1e-9 in double -- the unity DC gain rubato gets by normalising its table -- for up-sampling
-    (fc = 0.95) and down-sampling (fc = 0.95 * to / from) alike; and a constant input comes out as the constant."""
+    """The stand-in resampler's taps T[p][k] = sinc(fc d) bh(u)^2 / norm (the parameter set of
+    sample.rs:152-158), norm = (the sum of the windowed sinc over all 256 x 256 grid points) / 256 -- the normalisation rubato's
+    make_sincs applies -- sum to 1 per phase within 1e-9 in double for up-sampling (fc = 0.95) and down-sampling
+    (fc = 0.95 * to / from) alike; and a constant input comes out as the constant."""
+    def tap(d, fc):
+        z = fc * d
+        sinc = np.where(z == 0, 1.0, np.sin(np.pi * z) / (np.pi * np.where(z == 0, 1.0, z)))
+        u = (d + 128.0) / 256.0
+        bh = 0.35875 - 0.48829 * np.cos(2 * np.pi * u) + 0.14128 * np.cos(4 * np.pi * u) - 0.01168 * np.cos(6 * np.pi * u)
+        return sinc * bh * bh
     for frm, to in ((44100, 48000), (48000, 44100), (96000, 48000), (22050, 48000)):
         fc = 0.95 * min(1.0, to / frm)
+        norm = float(tap((np.arange(256 * 256) - 128 * 256) / 256.0, fc).sum()) / 256.0
+        assert abs(norm * fc - 1.0) < 1e-9          # (the closed form this table used before: fc sinc(fc d) bh^2)
         for p in (0, 1, 100, 255, 256):
-            k = np.arange(256)
-            d = k - 127.0 - p / 256.0
-            z = fc * d
-            sinc = np.where(z == 0, 1.0, np.sin(np.pi * z) / (np.pi * np.where(z == 0, 1.0, z)))
-            u = (d + 128.0) / 256.0
-            bh = 0.35875 - 0.48829 * np.cos(2 * np.pi * u) + 0.14128 * np.cos(4 * np.pi * u) - 0.01168 * np.cos(6 * np.pi * u)
-            assert abs(float((fc * sinc * bh * bh).sum()) - 1.0) < 1e-9
+            d = np.arange(256) - 127.0 - p / 256.0
+            assert abs(float(tap(d, fc).sum()) / norm - 1.0) < 1e-9
     from oracle import binding as oracle
     sb = oracle.SampleBank(48000)
     sb.add_decoded("s", np.full(2 * 4000, 500.0, np.float32), 2, 44100, 16, "")
