@@ -638,7 +638,18 @@ inline float wavetable_act(const WaveTable& w, float hz, float t) {
     return lerp(s0, s1, b);
 }
 
-struct SynthNote { float note, vel, env_t, rel_t; };
+// sampsyn's per-voice oscillator state (extensions.rs:542 pushes `initial_state(wave_table, 0.0)` with every voice, :569 hands
+// `&mut state` to wavetable_act_state per sample).  Its content is the crate's; the build-defined oscillator's state is the
+// phase the voice starts at -- created at note-on, carried with the voice, never changed: the oscillator is the closed form
+// of a phase accumulator (ph = phase0 + t hz, t the time since note-on), so every frame stays independent.
+struct WtState { float phase0 = 0.0f; };
+inline WtState initial_state(const WaveTable&, float phase) { return WtState{phase}; }
+struct SynthNote { float note, vel, env_t, rel_t; WtState st = WtState{}; };
+// wavetable_act_state (extensions.rs:569): the voice's state is its starting phase; phase0 == 0.0 adds nothing (x + 0.0 == x
+// for every x the oscillator sees but -0.0, whose fractional part is the same 0)
+inline float wavetable_act_state(const WaveTable& w, WtState& st, float hz, float t) {
+    return st.phase0 == 0.0f ? wavetable_act(w, hz, t) : wavetable_act(w, hz, t + st.phase0 / hz);
+}
 struct SineNote { float note, vel; };
 struct Voice3 { float t, vel, rel; };  // Adsr primary/ghost: (t_off, vel, release_val)
 
@@ -875,7 +886,7 @@ void sampsyn_gen(Sample& buf, FlowwBank& fb, size_t len, VertexExt& e, size_t sr
     for (size_t i = 0; i < len; ++i) {
         for (auto& ev : fb.get_block_simple(e.floww_index, i)) {
             if (ev.on) {
-                e.notes.push_back({ev.note, ev.vel, -((float)i / (float)sr), 0.0f});   // (+ initial_state: none here)
+                e.notes.push_back({ev.note, ev.vel, -((float)i / (float)sr), 0.0f, initial_state(e.wave_table, 0.0f)});   // :542
             } else {
                 std::vector<SynthNote> kept;
                 for (auto& x : e.notes)
@@ -901,7 +912,7 @@ void sampsyn_gen(Sample& buf, FlowwBank& fb, size_t len, VertexExt& e, size_t sr
             float env = x.rel_t == 0.0f ? apply_ads(adsr, env_time) : apply_r_rt(adsr, env_time, x.rel_t);
             float s = 0.0f;
             float vel = x.vel * env * amp_multiplier;
-            s += wavetable_act(e.wave_table, hz, env_time + x.rel_t) * vel;   // build-defined oscillator
+            s += wavetable_act_state(e.wave_table, x.st, hz, env_time + x.rel_t) * vel;   // :569, build-defined oscillator
             buf.l[i] += s;
             buf.r[i] += s;
         }
