@@ -2556,6 +2556,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         }
         if (arena_same && ar.graph_exec && gkey == ar.graph_key) {
             const auto tp3r = std::chrono::steady_clock::now();
+            ar.pending_fix = ar.graph_pending;   // (the replayed launches carry the same deferred check)
             TD_HIP(hipGraphLaunch(ar.graph_exec, stream));
             host_ms[0] += ms_between(tp2, tp3r);
             host_ms[1] += ms_between(tp3r, std::chrono::steady_clock::now());
@@ -2654,6 +2655,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         if (ie != hipSuccess) return fail(std::string("HIP error: ") + hipGetErrorString(ie) + " at hipGraphInstantiate");
         ar.graph_exec = exec;
         ar.graph_key.swap(gkey);
+        ar.graph_pending = ar.pending_fix;
         TD_HIP(hipGraphLaunch(ar.graph_exec, stream));
     }
     TD_HIP(hipGetLastError());
@@ -3767,11 +3769,15 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
     std::vector<double> first_write(nw, -1.0), last_write(nw, 0.0);
     std::atomic<size_t> queued{0};   // groups whose copy has been enqueued (their events are recorded)
     const int dev = b->device;
+    // a file is written in `parts` slices by as many threads (pwrite at their own offsets): the last group's files -- nothing
+    // renders or copies under them any more -- are then finished by all the writers, not by one thread per file
+    const size_t parts = (bits == 16 || bits == 32) ? (size_t)std::max<long>(1, std::min<long>(8, (long)nw * 2 / (long)std::max<size_t>(G, 1))) : 1;
     auto writer = [&](size_t w) {
         (void)hipSetDevice(dev);
         for (;;) {
-            const size_t i = next.fetch_add(1);
-            if (i >= P) return;
+            const size_t task = next.fetch_add(1);
+            if (task >= P * parts) return;
+            const size_t i = task / parts, part = task % parts;
             const size_t gi = i / G;
             while (queued.load(std::memory_order_acquire) <= gi) {
                 if (failed.load()) return;
@@ -3781,7 +3787,11 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
             const double t_a = ms_between(w0, std::chrono::steady_clock::now());
             if (first_write[w] < 0) first_write[w] = t_a;
             std::string err;
-            if (!tdw::write_wav_int(paths[i], b->host_pcm + b->host_pcm_off[i], n_blocks * b->graphs[i]->bl, 2, render_sr, bits, &err)) {
+            const void* words = b->host_pcm + b->host_pcm_off[i];
+            const size_t frames = n_blocks * b->graphs[i]->bl;
+            const bool ok_w = parts > 1 ? tdw::write_wav_int_part(paths[i], words, frames, 2, render_sr, bits, (int)part, (int)parts, &err)
+                                        : tdw::write_wav_int(paths[i], words, frames, 2, render_sr, bits, &err);
+            if (!ok_w) {
                 failed = 1;
                 errs[w] = err;
                 return;

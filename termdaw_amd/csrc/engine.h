@@ -206,6 +206,7 @@ struct Arena {
     uint32_t* d_flag = nullptr;
     struct PendingFix { size_t off; int n; uint32_t M, bl; };
     std::vector<PendingFix> pending_fix;
+    std::vector<PendingFix> graph_pending;   // ... of the captured submission (graph_replay): a replay queues the same deferred fix
     size_t fix_runs = 0;       // how often that happened (td_graph_norm_fix_runs)
 };
 

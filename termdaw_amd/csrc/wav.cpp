@@ -3,6 +3,10 @@
 // chunk is what parity tests compare; the header is sanity-checked separately).
 #include "wav.h"
 
+#include <fcntl.h>
+#include <unistd.h>
+#include <algorithm>
+
 #include <stdio.h>
 #include <string.h>
 
@@ -147,11 +151,9 @@ bool read_wav_raw(const char* path, WavRaw* out, std::string* err) {
 static void put16(std::vector<uint8_t>& b, uint32_t v) { b.push_back(v & 0xFF); b.push_back((v >> 8) & 0xFF); }
 static void put32(std::vector<uint8_t>& b, uint32_t v) { put16(b, v & 0xFFFF); put16(b, v >> 16); }
 
-bool write_wav_int(const char* path, const void* words, size_t frames, int channels, size_t sample_rate, int bits,
-                   std::string* err) {
+static std::vector<uint8_t> wav_header(size_t frames, int channels, size_t sample_rate, int bits) {
     const size_t bps = (size_t)bits / 8;
-    const size_t n = frames * (size_t)channels;
-    const size_t data_bytes = n * bps;
+    const size_t data_bytes = frames * (size_t)channels * bps;
     std::vector<uint8_t> h;
     const bool ext = bits > 16;
     h.insert(h.end(), {'R', 'I', 'F', 'F'});
@@ -174,6 +176,52 @@ bool write_wav_int(const char* path, const void* words, size_t frames, int chann
     }
     h.insert(h.end(), {'d', 'a', 't', 'a'});
     put32(h, (uint32_t)data_bytes);
+    return h;
+}
+
+// One of `parts` equal slices of the file write_wav_int would write (bits 16 / 32 only: the words are the file's bytes), by
+// pwrite at its own offset -- several threads write one file side by side; part 0 also writes the header and sets the
+// file's length (a longer file of that name is cut, a slice written before that stays).
+bool write_wav_int_part(const char* path, const void* words, size_t frames, int channels, size_t sample_rate, int bits,
+                        int part, int parts, std::string* err) {
+    if (!(bits == 16 || bits == 32) || parts < 1 || part < 0 || part >= parts) {
+        *err = "write_wav_int_part: 16- and 32-bit files only";
+        return false;
+    }
+    const std::vector<uint8_t> h = wav_header(frames, channels, sample_rate, bits);
+    const size_t data_bytes = frames * (size_t)channels * ((size_t)bits / 8);
+    const int fd = open(path, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) {
+        *err = std::string("could not create \"") + path + "\"";
+        return false;
+    }
+    bool ok = true;
+    auto put = [&](const void* p, size_t n, size_t at) {
+        const uint8_t* b = (const uint8_t*)p;
+        while (n && ok) {
+            const ssize_t w = pwrite(fd, b, n, (off_t)at);
+            if (w <= 0) { ok = false; break; }
+            b += w; at += (size_t)w; n -= (size_t)w;
+        }
+    };
+    if (part == 0) {
+        ok = ftruncate(fd, (off_t)(h.size() + data_bytes + (data_bytes & 1))) == 0;   // (the pad byte of an odd chunk reads 0)
+        put(h.data(), h.size(), 0);
+    }
+    const size_t per = ((data_bytes + (size_t)parts - 1) / (size_t)parts + 4095) & ~(size_t)4095;
+    const size_t lo = std::min(data_bytes, per * (size_t)part), hi = std::min(data_bytes, lo + per);
+    put((const uint8_t*)words + lo, hi - lo, h.size() + lo);
+    ok = (close(fd) == 0) && ok;
+    if (!ok) *err = std::string("short write to \"") + path + "\"";
+    return ok;
+}
+
+bool write_wav_int(const char* path, const void* words, size_t frames, int channels, size_t sample_rate, int bits,
+                   std::string* err) {
+    const size_t bps = (size_t)bits / 8;
+    const size_t n = frames * (size_t)channels;
+    const size_t data_bytes = n * bps;
+    const std::vector<uint8_t> h = wav_header(frames, channels, sample_rate, bits);
     FILE* f = fopen(path, "wb");
     if (!f) {
         *err = std::string("could not create \"") + path + "\"";

@@ -36,4 +36,8 @@ bool read_wav_raw(const char* path, WavRaw* out, std::string* err);
 bool write_wav_int(const char* path, const void* words, size_t frames, int channels, size_t sample_rate, int bits,
                    std::string* err);
 
+// The same file in `parts` slices, written by pwrite at their own offsets (several threads, one file); bits 16 / 32 only.
+bool write_wav_int_part(const char* path, const void* words, size_t frames, int channels, size_t sample_rate, int bits,
+                        int part, int parts, std::string* err);
+
 }  // namespace tdw
