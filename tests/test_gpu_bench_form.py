@@ -171,3 +171,19 @@ def test_bench_one_rank_over_rccl():
     assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and out["value"] > 0
     assert out["exchange_backend"] == "nccl"
     assert out["peak_table_entries"] == 3 and all(v > 0 for v in out["peak_table"])
+
+
+def test_forced_give_up_under_graph_replay(gpu_api, oracle):
+    """Engine option graph_replay 1 replays the captured launches of an unchanged submission; the deferred check launch of a
+    single-pass Normalize is not part of that capture -- it must still run when the replayed launch gives up."""
+    p = W.config1(seconds=3.0)
+    sb, fb, g = p.build(gpu_api)
+    g.set_option("graph_replay", 1)
+    g.set_option("norm_debug", 1)
+    osb, ofb, og = p.build(oracle)
+    ref = og.render_all(osb, ofb, p.cs, 16)
+    for rep in range(4):   # (the first submission captures, the later ones replay)
+        g.reset_normalize_vertices()
+        fb.set_time(0)
+        assert_bit_exact(g.render_all(sb, fb, p.cs, 16), ref)
+    assert g.norm_fix_runs() >= 4
