@@ -2732,6 +2732,7 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t n_stages = d.n_stages;
     const bool chain = n_stages > 1u;
+    const uint32_t dflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.flags);   // (read once: see k_band_chain)
     const BandStageDesc TD_CONST* const stages = (const BandStageDesc TD_CONST*)(const TD_CONST char*)d.stages;   // (uniform: scalar loads)
     // Tile number: a ticket.  A workgroup only ever waits for LOWER tiles, and whoever drew a lower ticket is running -- no
     // assumption about the order workgroups are dispatched in, nor about how many of them the device holds at once.
@@ -2909,7 +2910,7 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
                     }
                 }
                 if (n_pred == 0u) break;
-                if (d.flags & 2u) {   // (timing experiments only: no look-back -- wrong results)
+                if (dflags & 2u) {   // (timing experiments only: no look-back -- wrong results)
                     for (uint32_t i = tid; i < n_pred * 8u; i += kThreads) pb[i] = 0u;
                     break;
                 }
@@ -2917,7 +2918,7 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
                     const unsigned long long* g0 = sync + (size_t)first_pred * 8u;
                     const uint32_t n8 = n_pred * 8u;
                     if (lane < kScanMaxK / 32u) have_s[lane] = 0u;
-                    const bool forced = !chain && (d.flags & 1u) != 0u;
+                    const bool forced = !chain && (dflags & 1u) != 0u;
                     bool done = false;
                     if (!forced) {
                         for (uint32_t spin = 0;; ++spin) {
@@ -3279,7 +3280,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     const bool fin_here = mlast >= wt0 && mlast - wt0 < WT;
     // (timing experiments, flags bit 2: the wave's clock at eight points of every stage, written over its frames of the
     // output instead of the result -- tools/band_chain_phases.py)
-    const bool prof = (d.flags & 4u) != 0u;
+    // (the descriptor's flag word, read ONCE: tested inside the poll loop -- between atomic loads the compiler must assume memory
+    // changes -- it was a vector load + s_waitcnt vmcnt(0) in front of every stage's granule loads: a second, serialised memory
+    // round trip per stage)
+    const uint32_t dflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.flags);
+    const bool prof = (dflags & 4u) != 0u;
     unsigned long long* const pb = reinterpret_cast<unsigned long long*>(d.out + wt0);
     if (prof && lane == 0u && wt0 + WT <= M) {   // where the wave runs: HW_ID (wave / SIMD / CU / SE) and XCC_ID, and its tile
         pb[WT - 1u] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) << 32) |
@@ -3405,7 +3410,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                     unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
                     bool ok = !mine;
                     for (;;) {
-                        if (d.flags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
+                        if (dflags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
                         if (!ok) {   // (a lane whose four words have arrived reads no more: the queue is left to the late ones)
                             g0 = granule_load(g); g1 = granule_load(g + 1); g2 = granule_load(g + 2); g3 = granule_load(g + 3);
                             ok = (uint32_t)(g0 >> 32) == 1u && (uint32_t)(g1 >> 32) == 1u && (uint32_t)(g2 >> 32) == 1u && (uint32_t)(g3 >> 32) == 1u;
