@@ -3092,6 +3092,8 @@ static void free_prof(ProfCtx& pc) {
 }
 void td_graph_free(td_graph* g) {
     if (!g) return;
+    // (a deferred k_norm_fix -- the graph's own arena's or its batch's -- holds pointers into this graph's state: settled first)
+    if (g->stream && hipSetDevice(g->device) == hipSuccess) (void)drain(g);
     if (g->batch) {   // leave the batch first: it must not keep a dangling handle
         td_batch* b = g->batch;
         for (size_t i = 0; i < b->graphs.size(); ++i)

@@ -187,3 +187,36 @@ def test_forced_give_up_under_graph_replay(gpu_api, oracle):
         fb.set_time(0)
         assert_bit_exact(g.render_all(sb, fb, p.cs, 16), ref)
     assert g.norm_fix_runs() >= 4
+
+
+def test_handles_freed_with_a_deferred_check_pending(gpu_api):
+    """A render whose deferred check launch is still pending (forced give-up, no sync yet) followed by freeing the graph --
+    alone and as a member of a batch -- settles first: no launch on freed state, no crash, the survivors still render."""
+    p = W.config1(seconds=1.0)
+    for in_batch in (False, True):
+        built = [p.build(gpu_api) for _ in range(2)]
+        for sb, fb, g in built:
+            g.set_option("norm_debug", 1)
+        batch = None
+        if in_batch:
+            batch = gpu_api.Batch()
+            for b in built:
+                batch.add(*b)
+            batch.rewind()
+            batch.render_all_async(p.cs, 16)
+        else:
+            for sb, fb, g in built:
+                g.render_all_async(sb, fb, p.cs, 16)
+        sb1, fb1, g1 = built.pop()
+        del g1, sb1, fb1                      # freed with the pending fix of its last render un-settled
+        import gc
+        gc.collect()
+        sb0, fb0, g0 = built[0]
+        if batch is not None:
+            batch.sync()
+        g0.sync()
+        g0.reset_normalize_vertices()
+        fb0.set_time(0)
+        pcm, _ = g0.render_all(sb0, fb0, p.cs, 16)
+        assert pcm.shape[0] == p.cs * 1024 and np.abs(pcm).max() > 1000
+        del batch
