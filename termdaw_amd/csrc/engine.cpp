@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <atomic>
 #include <thread>
 #include <limits>
@@ -164,6 +165,46 @@ void* td_samplebank::alloc(int pool, size_t bytes) {
     s.live += 1;
     return p;
 }
+namespace tde {
+// Arenas with a deferred k_norm_fix outstanding (Arena::pending_fix).  The fix, if it runs, gathers again from the sample
+// tables: a bank about to give memory back settles every such arena on its device first.
+static std::mutex g_fix_mu;
+static std::vector<Arena*> g_fix_arenas;
+static int settle_arena(Arena& ar, hipStream_t stream);
+static int cur_device() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return d;
+}
+static void note_pending(Arena& ar, hipStream_t stream, int device) {
+    ar.fix_stream = stream;
+    ar.fix_device = device;
+    if (ar.listed) return;
+    std::lock_guard<std::mutex> lk(g_fix_mu);
+    g_fix_arenas.push_back(&ar);
+    ar.listed = true;
+}
+static void unlist_arena(Arena& ar) {
+    if (!ar.listed) return;
+    std::lock_guard<std::mutex> lk(g_fix_mu);
+    g_fix_arenas.erase(std::remove(g_fix_arenas.begin(), g_fix_arenas.end(), &ar), g_fix_arenas.end());
+    ar.listed = false;
+}
+static void drop_pending(Arena& ar) {
+    ar.pending_fix.clear();
+    unlist_arena(ar);
+}
+static void settle_device_arenas(int device) {
+    std::vector<Arena*> todo;
+    {
+        std::lock_guard<std::mutex> lk(g_fix_mu);
+        for (Arena* a : g_fix_arenas)
+            if (a->fix_device == device && !a->pending_fix.empty()) todo.push_back(a);
+    }
+    for (Arena* a : todo) (void)settle_arena(*a, a->fix_stream);
+}
+}  // namespace tde
+
 void td_samplebank::release(void* p) {
     if (!p) return;
     for (auto& v : slabs)
@@ -175,6 +216,7 @@ void td_samplebank::release(void* p) {
                     // (kernels queued by td_graph_render_all_async / td_batch_render_all_async on the engines' non-blocking
                     // streams may still gather from this memory: the per-sample hipFree of the old path synchronised implicitly)
                     (void)hipSetDevice(device);   // (the BANK's device, whatever the calling thread last selected)
+                    tde::settle_device_arenas(device);   // (... and a deferred k_norm_fix would gather from it once more)
                     (void)hipDeviceSynchronize();
                     if (i + 1 == v.size()) s.used = 0;
                     else { (void)hipFree(s.base); v.erase(v.begin() + (long)i); }
@@ -185,6 +227,8 @@ void td_samplebank::release(void* p) {
     (void)hipFree(p);   // a stand-alone allocation (resampled entries)
 }
 void td_samplebank::release_all() {
+    tde::settle_device_arenas(device);
+    (void)hipDeviceSynchronize();
     for (auto& v : slabs) {
         for (auto& s : v) (void)hipFree(s.base);
         v.clear();
@@ -1125,14 +1169,14 @@ static int settle_arena(Arena& ar, hipStream_t stream) {
     if (!stream) return 1;
     TD_HIP(hipStreamSynchronize(stream));
     if (!ar.h_flag || !*(volatile uint32_t*)ar.h_flag) {
-        ar.pending_fix.clear();   // (settled: the launch needed no fix)
+        drop_pending(ar);   // (settled: the launch needed no fix)
         return 1;
     }
     for (const auto& f : ar.pending_fix) launch_norm_fix((const SumDesc*)(ar.d + f.off), f.n, f.M, f.bl, stream);
     TD_HIP(hipGetLastError());
     TD_HIP(hipStreamSynchronize(stream));
     *(volatile uint32_t*)ar.h_flag = 0u;
-    ar.pending_fix.clear();
+    drop_pending(ar);
     ar.fix_runs += 1;
     return 1;
 }
@@ -1146,7 +1190,7 @@ static int ensure_arena(Arena& ar, size_t bytes, hipStream_t stream) {
     if (bytes <= ar.cap) return 1;
     const size_t cap = std::max<size_t>(bytes * 2, 1 << 20);
     if (stream && !settle_arena(ar, stream)) return 0;   // (a pending fix reads descriptors in the buffer about to go)
-    ar.pending_fix.clear();
+    drop_pending(ar);
     if (ar.h) (void)hipHostFree(ar.h);
     if (ar.d) (void)hipFree(ar.d);
     ar.h = nullptr;
@@ -1164,6 +1208,7 @@ static int ensure_arena(Arena& ar, size_t bytes, hipStream_t stream) {
     return 1;
 }
 static void free_arena(Arena& ar) {
+    drop_pending(ar);
     if (ar.h) (void)hipHostFree(ar.h);
     if (ar.d) (void)hipFree(ar.d);
     if (ar.copied) (void)hipEventDestroy(ar.copied);
@@ -2557,6 +2602,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         if (arena_same && ar.graph_exec && gkey == ar.graph_key) {
             const auto tp3r = std::chrono::steady_clock::now();
             ar.pending_fix = ar.graph_pending;   // (the replayed launches carry the same deferred check)
+            if (!ar.pending_fix.empty()) note_pending(ar, stream, cur_device());
             TD_HIP(hipGraphLaunch(ar.graph_exec, stream));
             host_ms[0] += ms_between(tp2, tp3r);
             host_ms[1] += ms_between(tp3r, std::chrono::steady_clock::now());
@@ -2659,6 +2705,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         TD_HIP(hipGraphLaunch(ar.graph_exec, stream));
     }
     TD_HIP(hipGetLastError());
+    if (!ar.pending_fix.empty()) note_pending(ar, stream, cur_device());
     const auto tp4 = std::chrono::steady_clock::now();
     host_ms[0] += ms_between(tp2, tp3);   // arena upload (or the compare that skips it)
     host_ms[1] += ms_between(tp3, tp4);   // launches
@@ -3654,7 +3701,7 @@ long td_batch_add(td_batch* b, td_graph* g, const td_samplebank* sb, td_flowwban
     }
     // the graph's launches, state copies and memsets move to the batch's stream
     if (g->stream) {
-        (void)hipStreamSynchronize(g->stream);
+        (void)drain(g);   // (its own arena's deferred check, if any, runs on the stream about to go)
         if (g->owns_stream) (void)hipStreamDestroy(g->stream);
     }
     g->stream = b->stream;

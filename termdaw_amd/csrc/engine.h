@@ -208,6 +208,11 @@ struct Arena {
     std::vector<PendingFix> pending_fix;
     std::vector<PendingFix> graph_pending;   // ... of the captured submission (graph_replay): a replay queues the same deferred fix
     size_t fix_runs = 0;       // how often that happened (td_graph_norm_fix_runs)
+    // While pending_fix is non-empty the arena is on a process-wide list (engine.cpp: note_pending / unlist_arena), so that
+    // whoever frees device memory such a fix would read -- a SampleBank's slabs -- can settle it first.
+    hipStream_t fix_stream = nullptr;
+    int fix_device = 0;
+    bool listed = false;
 };
 
 // HIP-event timing of launch families (bench hook)

@@ -220,3 +220,24 @@ def test_handles_freed_with_a_deferred_check_pending(gpu_api):
         pcm, _ = g0.render_all(sb0, fb0, p.cs, 16)
         assert pcm.shape[0] == p.cs * 1024 and np.abs(pcm).max() > 1000
         del batch
+
+
+def test_a_bank_freed_before_the_deferred_check_has_run(gpu_api):
+    """The deferred k_norm_fix gathers from the sample tables once more: a SampleBank freed between the asynchronous
+    render and the sync settles the check first (it ran, on live memory), and the PCM equals a render whose bank lived."""
+    import gc
+    p = W.config2(seconds=1.0, n_src=6)
+    got = []
+    for free_early in (True, False):
+        sb, fb, g = p.build(gpu_api)
+        g.set_option("norm_debug", 1)
+        g.render_all_async(sb, fb, p.cs, 16)
+        if free_early:
+            del sb
+            gc.collect()
+        g.sync()
+        assert g.norm_fix_runs() == 1
+        pcm = np.zeros((p.cs * 1024, 2), "<i2")
+        gpu_api._check(gpu_api.lib().td_graph_read_pcm(g.h, pcm.ctypes.data_as(gpu_api.C.c_void_p), pcm.nbytes))
+        got.append(pcm)
+    assert np.abs(got[0]).max() > 1000 and np.array_equal(got[0], got[1])
