@@ -11,7 +11,10 @@
  *   - functions returning int: 1 = ok/true, 0 = failed/false (mirrors the reference's bool / Result /
  *     Option); td_last_error() returns the message of the last failure on the calling thread
  *   - audio is f32; "frames" are stereo frames; PCM out is interleaved L,R little-endian
- *   - one host thread per graph handle; handles bound to different GPUs are independent
+ *   - one host thread per graph handle; handles bound to different GPUs are independent.  Handles may be
+ *     freed in any order, also with asynchronous renders not yet synced; a SampleBank that gives device
+ *     memory back (td_samplebank_free, an entry replaced) first completes what is queued on its GPU, so do
+ *     that from the thread that renders the graphs using the bank
  *   - the library never falls back to a CPU implementation: without a usable gfx950 device every
  *     render call fails with an error
  */
