@@ -195,6 +195,9 @@ size_t td_graph_device_bytes(const td_graph* g);
  * `pass` band-pass vertices linked by single-input Sum / Adsr vertices, with the Sum vertex in front and the Normalize
  * vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers never reach
  * an output (extensions.rs:685) and are not run in this mode);
+ * "one_grid_sources" 0|1 (default 1: the launches of a level that read no edge buffer -- affine Synth, wavetable voice,
+ *   SampleLerp, the Adsr vertices' envelope buffers -- go out as ONE grid, each workgroup running its own family's code: same
+ *   values as the separate launches, one ramp and one tail instead of up to four) /
  * "band_chain" 0|1 (default 1; 0: scan mode launches every band-pass vertex on its own) / "fuse_normalize" 0|1 (default 1:
  * in scan mode a Normalize vertex whose one input is a scan launch's last vertex is evaluated by that launch) / "band_scan_nf" 8|16 (frames
  * per lane of a single vertex' launch) / "band_scan_depth" n (default 64: the look-back reaches back until what a tile

@@ -1217,10 +1217,11 @@ static void free_arena(Arena& ar) {
     ar = Arena{};
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_ENV, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT, F_COUNT };
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_ENV, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT,
+              F_SOURCES /* (no descriptors of its own: several of the families above as ONE grid, submit_chunk) */, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
                                            "k_synth",       "k_sampsyn", "k_adsr_env", "k_sum",          "k_scale",       "k_norm_fix",
-                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise"};
+                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise", "k_sources"};
 
 static hipEvent_t get_event(ProfCtx& pc) {
     if (!pc.free_ev.empty()) {
@@ -1388,6 +1389,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     const auto tp0 = std::chrono::steady_clock::now();
     Staging& st = *cb.st;   // capacity kept from render to render
     cb.n_graphs += 1;
+    cb.one_grid_sources = cb.one_grid_sources && g->one_grid_sources;
     std::vector<VTables> vt(nv);
     std::map<std::string, size_t> chunk_keys;   // table key -> first vertex of this chunk compiled from it
     std::string key;
@@ -1724,7 +1726,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 tf(offsetof(IntervalTab, ivoff), vt[envs[i]].ivoff_off);
                 tf(offsetof(IntervalTab, voices), vt[envs[i]].voices_off);
             }
-            add_launch(F_ENV, off, (int)envs.size(), 0u, -1);
+            add_launch(F_ENV, off, (int)envs.size(), 0u, 0);   // (level 0: beside the source vertices, which it may share a grid with -- k_sources)
         }
     }
 
@@ -2592,6 +2594,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         gkey.push_back(upload);
         gkey.push_back(sync_at);
         gkey.push_back(cb.sync_bytes);
+        gkey.push_back(cb.one_grid_sources ? 1u : 0u);
         for (auto& z : cb.zero) { gkey.push_back(z.off); gkey.push_back(z.bytes); }
         for (auto& L : launches) {
             gkey.push_back(((uint64_t)(uint32_t)L.fam << 32) | (uint32_t)L.n);
@@ -2646,8 +2649,46 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
             for (int a = 0; a < td_graph::kAuxStreams; ++a)
                 if (groups & (2u << a)) TD_HIP(hipStreamWaitEvent(fork_g->aux[a], fork_g->ev_fork, 0));
         }
+        // The level's launches that read no edge buffer -- affine Synth, wavetable voice, SampleLerp, the envelope buffers -- as
+        // ONE grid (k_sources, kernels.hip): the first launch of each kind, the longest-running kind first.
+        uint64_t in_one_grid = 0;   // bit q - li: launched as a part of it
+        if (cb.one_grid_sources && !fork && lj - li <= 64) {
+            auto kind_of = [](const Launch& L) -> int {
+                switch (L.fam) {
+                    case F_SYNTH: return (L.aux & 1u) ? (int)SRC_SYNTH_AFFINE : -1;
+                    case F_SAMPSYN: return (int)SRC_SAMPSYN;
+                    case F_LERP: return (int)SRC_LERP;
+                    case F_ENV: return (int)SRC_ENV;
+                    default: return -1;
+                }
+            };
+            long pick[4] = {-1, -1, -1, -1};
+            uint32_t M0 = 0;
+            int found = 0;
+            for (size_t q = li; q < lj; ++q) {
+                const int kd = kind_of(launches[q]);
+                if (kd < 0 || pick[kd] >= 0 || !launches[q].n || !launches[q].M) continue;
+                if (found && launches[q].M != M0) continue;
+                M0 = launches[q].M;
+                pick[kd] = (long)q;
+                ++found;
+            }
+            if (found >= 2) {
+                SourceParts P{};
+                for (int kd = 0; kd < 4; ++kd) {   // (SourceKind order = longest-running first; the reverse measured slower on config 3)
+                    if (pick[kd] >= 0) {
+                        const Launch& L = launches[(size_t)pick[kd]];
+                        P.part[P.n_parts++] = SourcePart{ar.d + L.off, (uint32_t)L.n, (uint32_t)kd, 0u, 0u};
+                        in_one_grid |= 1ull << ((size_t)pick[kd] - li);
+                    }
+                }
+                Prof pr(prof, F_SOURCES, stream);
+                launch_sources(P, M0, stream);
+            }
+        }
         for (size_t q = li; q < lj; ++q) {
             const Launch& L = launches[q];
+            if (in_one_grid & (1ull << (q - li))) continue;
             if (L.fam == F_NORMFIX && (L.aux & 1u)) {   // deferred: launched by settle_arena() only if a tile raised the host-visible word
                 ar.pending_fix.push_back({L.off, L.n, L.M, L.bl});
                 continue;
@@ -3646,6 +3687,7 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "single_pass_normalize") { g->single_pass_normalize = value != 0; return 1; }
     if (k == "norm_debug") { g->norm_debug = (int)value; return 1; }
     if (k == "fuse_normalize") { g->fuse_normalize = value != 0; return 1; }
+    if (k == "one_grid_sources") { g->one_grid_sources = value != 0; return 1; }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "table_cache") { g->table_cache = value != 0; return 1; }
     if (k == "graph_replay") { g->graph_replay = value != 0; return 1; }

@@ -255,6 +255,7 @@ struct ChunkBuild {
     std::vector<size_t> flag_fix;   // pointer fields -> the arena's host-visible word (SumDesc::host_flag)
     std::vector<Launch> launches;
     size_t n_graphs = 0;
+    bool one_grid_sources = true;   // every graph compiled in has engine option "one_grid_sources" set (submit_chunk: k_sources)
     void clear() {
         st->b.clear();
         scratch_bytes = 0;
@@ -266,6 +267,7 @@ struct ChunkBuild {
         flag_fix.clear();
         launches.clear();
         n_graphs = 0;
+        one_grid_sources = true;
     }
 };
 }  // namespace tde
@@ -338,6 +340,7 @@ struct td_graph {
     bool graph_replay = false;                 // replay the captured launch sequence of an unchanged submission (measured: no gain)
     bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
+    bool one_grid_sources = true;              // a level's source launches (affine Synth, wavetable voice, SampleLerp) and the envelope launch go out as ONE grid (k_sources)
     bool fuse_normalize = true;                // band_mode 1: a Normalize vertex right behind a scan launch is evaluated by that launch (BandScanDesc::norm)
     bool single_pass_normalize = true;         // fresh renders of wide all-loop sums find the running peak inside the sum launch (SumDesc mode 4)
     int norm_debug = 0;                        // (tests) bit 0: every single-pass Normalize tile gives up its wait at once -> k_norm_fix

@@ -469,6 +469,13 @@ void launch_sample_lerp(const LerpDesc* d, int n_desc, uint32_t frames, hipStrea
 void launch_debug_sine(const SineDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
 void launch_synth(const SynthDesc* d, int n_desc, uint32_t frames, bool affine, hipStream_t s);   // every descriptor: SynthDesc::affine == affine
 void launch_sampsyn(const SampsynDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+// k_sources: the source launches of a level and the envelope launch as the parts of ONE grid (kernels.hip); the engine lists
+// the parts longest-running family first, launch_sources fills in the grid geometry
+enum SourceKind : uint32_t { SRC_SYNTH_AFFINE = 0, SRC_SAMPSYN = 1, SRC_LERP = 2, SRC_ENV = 3 };
+constexpr uint32_t kMaxSourceParts = 4;
+struct SourcePart { const void* descs; uint32_t n, kind, gx, first; };
+struct SourceParts { SourcePart part[kMaxSourceParts]; uint32_t n_parts, pad; };
+int launch_sources(SourceParts& P, uint32_t frames, hipStream_t s);
 void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 

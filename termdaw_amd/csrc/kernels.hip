@@ -1151,9 +1151,8 @@ TD_DEV float2 lerp_frame(const LerpDesc& d, int64_t m) {
     }
     return make_float2(l, r);
 }
-__global__ __launch_bounds__(kThreads) void k_sample_lerp(const LerpDesc* __restrict__ descs, uint32_t M) {
-    const LerpDesc& d = descs[blockIdx.y];
-    const uint32_t m0 = blockIdx.x * kTileFrames + 2 * threadIdx.x;
+TD_DEV void sample_lerp_block(const LerpDesc& d, uint32_t bx, uint32_t M) {
+    const uint32_t m0 = bx * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
     if (m0 < M) {
         float2 a = lerp_frame(d, m0), b = lerp_frame(d, (int64_t)m0 + 1);
@@ -1163,6 +1162,9 @@ __global__ __launch_bounds__(kThreads) void k_sample_lerp(const LerpDesc* __rest
         float2 a = lerp_frame(d, m1), b = lerp_frame(d, (int64_t)m1 + 1);
         store_pair(d.out, m1, M, epilogue4(make_float4(a.x, a.y, b.x, b.y), d.pg));
     }
+}
+__global__ __launch_bounds__(kThreads) void k_sample_lerp(const LerpDesc* __restrict__ descs, uint32_t M) {
+    sample_lerp_block(descs[blockIdx.y], blockIdx.x, M);
 }
 
 // envelope math: adsr_math.h (shared with the host event compiler)
@@ -1597,9 +1599,8 @@ __global__ __launch_bounds__(kThreads, 6) void k_synth(const SynthDesc* __restri
     if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(p1.x, p1.x, p1.y, p1.y), d.pg));
 }
 // the affine form (every descriptor of the launch has SynthDesc::affine set: the engine groups them)
-__global__ __launch_bounds__(kThreads, 6) void k_synth_affine(const SynthDesc* __restrict__ descs, uint32_t M) {
-    const SynthDesc& d = descs[blockIdx.y];
-    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
+TD_DEV void synth_affine_block(const SynthDesc& d, uint32_t bx, uint32_t M) {
+    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[bx] : bx;
     const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
     const uint32_t mc0 = min(m0, M - 1u), mc1 = min(m1, M - 1u);
@@ -1607,6 +1608,9 @@ __global__ __launch_bounds__(kThreads, 6) void k_synth_affine(const SynthDesc* _
     synth_quad_affine(d, mc0, mc1, M, p0, p1);
     if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(p0.x, p0.x, p0.y, p0.y), d.pg));
     if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(p1.x, p1.x, p1.y, p1.y), d.pg));
+}
+__global__ __launch_bounds__(kThreads, 6) void k_synth_affine(const SynthDesc* __restrict__ descs, uint32_t M) {
+    synth_affine_block(descs[blockIdx.y], blockIdx.x, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1659,10 +1663,9 @@ TD_DEV float sampsyn_voice(const SampsynDesc& d, const float4 n, float off) {   
     s += wavetable_act(d.wt, n.x, env_time + n.w) * vel;
     return s;
 }
-__global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restrict__ descs, uint32_t M) {
-    const SampsynDesc& d = descs[blockIdx.y];
+TD_DEV void sampsyn_block(const SampsynDesc& d, uint32_t bx, uint32_t M) {
     // (tiles with an interval start inside them first, as in k_synth: IntervalTab::tile_order)
-    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
+    const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[bx] : bx;
     const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
     // A wave's frames nearly always lie in ONE interval: the voice records then come in through scalar loads, once per wave,
@@ -1695,6 +1698,9 @@ __global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restr
     }
     if (m0 < M) store_pair(d.out, m0, M, epilogue4(make_float4(v[0], v[0], m0 + 1 < M ? v[1] : 0.0f, m0 + 1 < M ? v[1] : 0.0f), d.pg));
     if (m1 < M) store_pair(d.out, m1, M, epilogue4(make_float4(v[2], v[2], m1 + 1 < M ? v[3] : 0.0f, m1 + 1 < M ? v[3] : 0.0f), d.pg));
+}
+__global__ __launch_bounds__(kThreads) void k_sampsyn(const SampsynDesc* __restrict__ descs, uint32_t M) {
+    sampsyn_block(descs[blockIdx.y], blockIdx.x, M);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1823,12 +1829,11 @@ TD_DEV float adsr_voice_value(const AdsrRunConsts& u, const AdsrPieceRow* tab, c
     if (r.same) return adsr_piece_value(r.pc, t, r.mode, u.sus_v) * r.vel;
     return adsr_piece_value(adsr_piece(tab, adsr_piece_index(u, t)), t, r.mode, u.sus_v) * r.vel;
 }
-__global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restrict__ descs, uint32_t M) {
-    const AdsrVDesc& d = descs[blockIdx.y];
+TD_DEV void adsr_env_block(const AdsrVDesc& d, uint32_t bx, uint32_t M) {
     __shared__ AdsrPieceRow ptab[4];
     if (threadIdx.x == 0u) adsr_piece_table(adsr_run_consts(d), ptab);
     __syncthreads();
-    const uint32_t m0 = (blockIdx.x * kThreads + threadIdx.x) * (uint32_t)kEnvRun;
+    const uint32_t m0 = (bx * kThreads + threadIdx.x) * (uint32_t)kEnvRun;
     if (m0 >= M) return;
     float* const out = d.env;
     const uint32_t mlast = min(m0 + (uint32_t)kEnvRun - 1u, M - 1u);
@@ -1864,6 +1869,34 @@ __global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restri
 #pragma unroll 1
         for (uint32_t m = m0; m <= mlast; ++m) out[m] = adsr_vel(d, m);
     }
+}
+__global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restrict__ descs, uint32_t M) {
+    adsr_env_block(descs[blockIdx.y], blockIdx.x, M);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_sources: the launches of one level that read no edge buffer, as ONE grid
+// ------------------------------------------------------------------------------------------------
+// A level's source vertices (affine Synth, wavetable voice, SampleLerp) and the envelope buffers of the Adsr vertices (k_adsr_env)
+// depend on nothing on the device and on one another: queued one behind the other on a stream each pays its own ramp and
+// tail -- the envelope launch 18 us for 12 MB.  Here their workgroups are the parts of one 1-D grid, the longest-running
+// family first (its slow tiles first inside it: IntervalTab::tile_order), the short ones filling its tail; every
+// workgroup runs the block function of its family unchanged (same values as the separate launches by construction).
+// KINDS: the families compiled in (the register budget is that of the largest); MINB: workgroups per CU to allocate for.
+template <uint32_t KINDS, int MINB>
+__global__ __launch_bounds__(kThreads, MINB) void k_sources(const SourceParts P, uint32_t M) {
+    const uint32_t b = blockIdx.x;
+    uint32_t pi = 0u;
+#pragma unroll
+    for (uint32_t i = 1; i < kMaxSourceParts; ++i)
+        if (i < P.n_parts && b >= P.part[i].first) pi = i;
+    const uint32_t kind = P.part[pi].kind, gx = P.part[pi].gx, local = b - P.part[pi].first;
+    const uint32_t by = local / gx, bx = local - by * gx;
+    const void* const descs = P.part[pi].descs;
+    if ((KINDS & (1u << SRC_SYNTH_AFFINE)) && kind == SRC_SYNTH_AFFINE) synth_affine_block(((const SynthDesc*)descs)[by], bx, M);
+    else if ((KINDS & (1u << SRC_SAMPSYN)) && kind == SRC_SAMPSYN) sampsyn_block(((const SampsynDesc*)descs)[by], bx, M);
+    else if ((KINDS & (1u << SRC_LERP)) && kind == SRC_LERP) sample_lerp_block(((const LerpDesc*)descs)[by], bx, M);
+    else if ((KINDS & (1u << SRC_ENV)) && kind == SRC_ENV) adsr_env_block(((const AdsrVDesc*)descs)[by], bx, M);
 }
 
 template <int TMODE>
@@ -3978,6 +4011,30 @@ void launch_adsr_env(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t s) 
     if (!n || !frames) return;
     const uint32_t per = (uint32_t)kThreads * (uint32_t)kEnvRun;
     TD_BATCHED(k_adsr_env, (frames + per - 1u) / per, kThreads, d, n, frames);
+}
+uint32_t source_part_grid(uint32_t kind, uint32_t frames) {
+    if (kind == SRC_ENV) {
+        const uint32_t per = (uint32_t)kThreads * (uint32_t)kEnvRun;
+        return (frames + per - 1u) / per;
+    }
+    return tiles(frames);
+}
+int launch_sources(SourceParts& P, uint32_t frames, hipStream_t s) {
+    if (!frames || !P.n_parts) return 1;
+    uint32_t kinds = 0u, total = 0u;
+    for (uint32_t i = 0; i < P.n_parts; ++i) {
+        P.part[i].gx = source_part_grid(P.part[i].kind, frames);
+        P.part[i].first = total;
+        total += P.part[i].gx * P.part[i].n;
+        kinds |= 1u << P.part[i].kind;
+    }
+    constexpr uint32_t S = 1u << SRC_SYNTH_AFFINE, Y = 1u << SRC_SAMPSYN, L = 1u << SRC_LERP, E = 1u << SRC_ENV;
+    // (the combinations the engine forms: an affine Synth launch keeps its six workgroups per CU; everything else is compiled
+    // with all four block functions)
+    if (kinds == (S | E)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<S | E, 6>), dim3(total), dim3(kThreads), 0, s, P, frames);
+    else if (!(kinds & S)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<Y | L | E, 4>), dim3(total), dim3(kThreads), 0, s, P, frames);   // (108 registers; five per CU spill 11 and lose 2 us on config 4, six 26 us)
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<S | Y | L | E, 4>), dim3(total), dim3(kThreads), 0, s, P, frames);
+    return 1;
 }
 void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {
     if (!n || !frames) return;
