@@ -404,7 +404,7 @@ def other_configs(api, workloads, ub, chain_ns):
             entry["bound"] = {"kind": "launch latency", "floor_ms": round(floor, 5), "frac": round(floor / ms, 4),
                               "note": "%d dependent launches x 1.45 us (guide: same-stream kernel boundary); the kernels themselves move "
                                       "%.1f MB" % (launches, frames * (2 * 4 + 8 + 20) / 1e6)}
-        elif dom[0] in ("k_synth", "k_band_scan"):
+        elif dom[0] in ("k_synth", "k_sources", "k_band_scan"):
             if insts and issue_ns > 0:
                 floor = insts * issue_ns / SIMDS * 1e-6
                 entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4),

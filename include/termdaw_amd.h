@@ -193,8 +193,9 @@ size_t td_graph_device_bytes(const td_graph* g);
  * Normalize vertex brings the rest back up (8 of 18 000 random graphs, at most 3.3e-6).  A state that goes
  * NaN / infinite stays NaN, as in the reference.  One launch per band-pass vertex, and ONE launch for a whole chain of
  * `pass` band-pass vertices linked by single-input Sum / Adsr vertices, with the Sum vertex in front and the Normalize
- * vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers never reach
- * an output (extensions.rs:685) and are not run in this mode);
+ * vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers reach its
+ * output only as NaN once they are not finite (extensions.rs:685-687): the chain launch does not run them and tracks the
+ * first non-finite right input frame instead);
  * "one_grid_sources" 0|1 (default 1: the launches of a level that read no edge buffer -- affine Synth, wavetable voice,
  *   SampleLerp, the Adsr vertices' envelope buffers -- go out as ONE grid, each workgroup running its own family's code: same
  *   values as the separate launches, one ramp and one tail instead of up to four) /

@@ -1,7 +1,7 @@
 # Round profile set (run on the MI355X box through gpurun):  bash tools/prof_round.sh <tag>
 #   gpurun_out/prof_<tag>_<mode>/   rocprofv3 --kernel-trace --stats of bench.py (fused = default engine, nofuse = edge-buffer model)
 #   gpurun_out/pmc_<tag>_<mode>_*/  separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | VALU counters
-#   gpurun_out/pmc_<tag>_c3_VALU, _c4_VALU   the same VALU pass for configs 3 and 4 (tools/time_configs.py)
+#   gpurun_out/pmc_<tag>_c3_VALU, _c4_VALU   the same VALU pass for configs 3 and 4 (tools/time_configs.py); ..scan: band_mode 1; ..sep: one_grid_sources 0
 # then tools/pmc_summary.py <tag> writes profiles/<tag>_pmc_summary.json and profiles/<tag>_valu.json.
 TAG=${1:-r03}
 R=/root/repo
@@ -27,6 +27,12 @@ export TD_OPTS=band_mode=1
 for c in c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}scan -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}scan.log 2>&1
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}scan_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
+done
+# ... and with every source family launched on its own (engine option one_grid_sources 0): k_synth / k_sampsyn / k_adsr_env by themselves
+export TD_OPTS=one_grid_sources=0
+for c in c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}sep -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}sep.log 2>&1
+  rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}sep_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
 done
 unset TD_OPTS
 cd $R
