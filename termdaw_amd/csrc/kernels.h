@@ -472,10 +472,14 @@ void launch_sampsyn(const SampsynDesc* d, int n_desc, uint32_t frames, hipStream
 // k_sources: the source launches of a level and the envelope launch as the parts of ONE grid (kernels.hip); the engine lists
 // the parts longest-running family first, launch_sources fills in the grid geometry
 enum SourceKind : uint32_t { SRC_SYNTH_AFFINE = 0, SRC_SAMPSYN = 1, SRC_LERP = 2, SRC_ENV = 3 };
-constexpr uint32_t kMaxSourceParts = 4;
-struct SourcePart { const void* descs; uint32_t n, kind, gx, first; };
-struct SourceParts { SourcePart part[kMaxSourceParts]; uint32_t n_parts, pad; };
-int launch_sources(SourceParts& P, uint32_t frames, hipStream_t s);
+struct SourceParts {   // the launches that become parts (n_* 0: none of that kind)
+    const SynthDesc* synth = nullptr; int n_synth = 0;       // every descriptor: SynthDesc::affine set
+    const SampsynDesc* sampsyn = nullptr; int n_sampsyn = 0;
+    const LerpDesc* lerp = nullptr; int n_lerp = 0;
+    const AdsrVDesc* env = nullptr; int n_env = 0;
+};
+struct SourceGrid { uint32_t gx[4], end[4]; };   // per SourceKind: workgroups per descriptor; the first workgroup BEHIND the part
+int launch_sources(const SourceParts& P, uint32_t frames, hipStream_t s);
 void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 

@@ -1880,23 +1880,29 @@ __global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restri
 // A level's source vertices (affine Synth, wavetable voice, SampleLerp) and the envelope buffers of the Adsr vertices (k_adsr_env)
 // depend on nothing on the device and on one another: queued one behind the other on a stream each pays its own ramp and
 // tail -- the envelope launch 18 us for 12 MB.  Here their workgroups are the parts of one 1-D grid, the longest-running
-// family first (its slow tiles first inside it: IntervalTab::tile_order), the short ones filling its tail; every
-// workgroup runs the block function of its family unchanged (same values as the separate launches by construction).
+// family first (its slow tiles first inside it: IntervalTab::tile_order), the short ones filling its tail (SourceKind's
+// order); every workgroup runs the block function of its family unchanged (same values as the separate launches by construction).
 // KINDS: the families compiled in (the register budget is that of the largest); MINB: workgroups per CU to allocate for.
 template <uint32_t KINDS, int MINB>
-__global__ __launch_bounds__(kThreads, MINB) void k_sources(const SourceParts P, uint32_t M) {
+__global__ __launch_bounds__(kThreads, MINB) void k_sources(const SynthDesc* __restrict__ sd, const SampsynDesc* __restrict__ yd,
+                                                            const LerpDesc* __restrict__ ld, const AdsrVDesc* __restrict__ ed,
+                                                            const SourceGrid G, uint32_t M) {
+    // (the descriptor arrays are kernel arguments of their own, `__restrict__` like the families' own kernels': read through a
+    // pointer taken from a table in the argument block they were vector loads -- the envelope part's table build 25 dependent ones)
     const uint32_t b = blockIdx.x;
-    uint32_t pi = 0u;
-#pragma unroll
-    for (uint32_t i = 1; i < kMaxSourceParts; ++i)
-        if (i < P.n_parts && b >= P.part[i].first) pi = i;
-    const uint32_t kind = P.part[pi].kind, gx = P.part[pi].gx, local = b - P.part[pi].first;
-    const uint32_t by = local / gx, bx = local - by * gx;
-    const void* const descs = P.part[pi].descs;
-    if ((KINDS & (1u << SRC_SYNTH_AFFINE)) && kind == SRC_SYNTH_AFFINE) synth_affine_block(((const SynthDesc*)descs)[by], bx, M);
-    else if ((KINDS & (1u << SRC_SAMPSYN)) && kind == SRC_SAMPSYN) sampsyn_block(((const SampsynDesc*)descs)[by], bx, M);
-    else if ((KINDS & (1u << SRC_LERP)) && kind == SRC_LERP) sample_lerp_block(((const LerpDesc*)descs)[by], bx, M);
-    else if ((KINDS & (1u << SRC_ENV)) && kind == SRC_ENV) adsr_env_block(((const AdsrVDesc*)descs)[by], bx, M);
+    if ((KINDS & (1u << SRC_SYNTH_AFFINE)) && b < G.end[SRC_SYNTH_AFFINE]) {
+        const uint32_t by = b / G.gx[SRC_SYNTH_AFFINE];
+        synth_affine_block(sd[by], b - by * G.gx[SRC_SYNTH_AFFINE], M);
+    } else if ((KINDS & (1u << SRC_SAMPSYN)) && b < G.end[SRC_SAMPSYN]) {
+        const uint32_t local = b - G.end[SRC_SAMPSYN - 1], by = local / G.gx[SRC_SAMPSYN];
+        sampsyn_block(yd[by], local - by * G.gx[SRC_SAMPSYN], M);
+    } else if ((KINDS & (1u << SRC_LERP)) && b < G.end[SRC_LERP]) {
+        const uint32_t local = b - G.end[SRC_LERP - 1], by = local / G.gx[SRC_LERP];
+        sample_lerp_block(ld[by], local - by * G.gx[SRC_LERP], M);
+    } else if (KINDS & (1u << SRC_ENV)) {
+        const uint32_t local = b - G.end[SRC_ENV - 1], by = local / G.gx[SRC_ENV];
+        adsr_env_block(ed[by], local - by * G.gx[SRC_ENV], M);
+    }
 }
 
 template <int TMODE>
@@ -4019,21 +4025,25 @@ uint32_t source_part_grid(uint32_t kind, uint32_t frames) {
     }
     return tiles(frames);
 }
-int launch_sources(SourceParts& P, uint32_t frames, hipStream_t s) {
-    if (!frames || !P.n_parts) return 1;
+int launch_sources(const SourceParts& P, uint32_t frames, hipStream_t s) {
+    if (!frames) return 1;
+    SourceGrid G{};
     uint32_t kinds = 0u, total = 0u;
-    for (uint32_t i = 0; i < P.n_parts; ++i) {
-        P.part[i].gx = source_part_grid(P.part[i].kind, frames);
-        P.part[i].first = total;
-        total += P.part[i].gx * P.part[i].n;
-        kinds |= 1u << P.part[i].kind;
+    const int n[4] = {P.n_synth, P.n_sampsyn, P.n_lerp, P.n_env};
+    for (uint32_t k = 0; k < 4u; ++k) {
+        G.gx[k] = source_part_grid(k, frames);
+        total += G.gx[k] * (uint32_t)n[k];
+        G.end[k] = total;
+        if (n[k]) kinds |= 1u << k;
     }
+    if (!total) return 1;
     constexpr uint32_t S = 1u << SRC_SYNTH_AFFINE, Y = 1u << SRC_SAMPSYN, L = 1u << SRC_LERP, E = 1u << SRC_ENV;
     // (the combinations the engine forms: an affine Synth launch keeps its six workgroups per CU; everything else is compiled
-    // with all four block functions)
-    if (kinds == (S | E)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<S | E, 6>), dim3(total), dim3(kThreads), 0, s, P, frames);
-    else if (!(kinds & S)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<Y | L | E, 4>), dim3(total), dim3(kThreads), 0, s, P, frames);   // (108 registers; five per CU spill 11 and lose 2 us on config 4, six 26 us)
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<S | Y | L | E, 4>), dim3(total), dim3(kThreads), 0, s, P, frames);
+    // with all the block functions it may need -- 108 registers, k_sample_lerp's: capped to five workgroups per CU it spills 11
+    // and loses 2 us on config 4, to six 26 us)
+    if (kinds == (S | E)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<S | E, 6>), dim3(total), dim3(kThreads), 0, s, P.synth, P.sampsyn, P.lerp, P.env, G, frames);
+    else if (!(kinds & S)) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<Y | L | E, 4>), dim3(total), dim3(kThreads), 0, s, P.synth, P.sampsyn, P.lerp, P.env, G, frames);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sources<S | Y | L | E, 4>), dim3(total), dim3(kThreads), 0, s, P.synth, P.sampsyn, P.lerp, P.env, G, frames);
     return 1;
 }
 void launch_adsr(const AdsrVDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {

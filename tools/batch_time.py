@@ -9,7 +9,8 @@ if __name__ == "__main__":
     mode = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     seconds = float(sys.argv[4]) if len(sys.argv) > 4 else 60.0
     mk = {"c3": W.config3, "c4": W.config4}[which]
-    b, first = tb.build_shard(api, lambda pid: mk(seconds=seconds, variant=pid), list(range(P)), {"band_mode": mode})
+    b, first = tb.build_shard(api, lambda pid: mk(seconds=seconds, variant=pid), list(range(P)),
+                                 dict({"band_mode": mode}, **{k: int(v) for k, v in (kv.split("=") for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")))}))
     def step():
         b.rewind()
         b.render_all_async(first.cs, 16)
