@@ -3224,6 +3224,7 @@ void td_graph_free(td_graph* g) {
             }
         if (g->owns_stream && g->stream) (void)hipStreamDestroy(g->stream);
     }
+    drop_pending(g->arena);   // (off the process-wide list whatever happened above: the list holds the arena's address)
     delete g;
 }
 void td_graph_reset(td_graph* g) {
@@ -3721,6 +3722,10 @@ void td_batch_free(td_batch* b) {
     const bool dev_ok = hipSetDevice(b->device) == hipSuccess;
     if (b->stream && dev_ok) (void)settle_arena(b->arena, b->stream);   // (the projects' results stay readable through their own handles)
     for (td_graph* g : b->graphs) {   // the projects outlive the batch: give each its own stream back (made on next use)
+        // (a member rendered on its own queues on the batch's stream with its own arena: its deferred check, if one is
+        // outstanding, must run before that stream goes)
+        if (b->stream && dev_ok) (void)settle_arena(g->arena, b->stream);
+        drop_pending(g->arena);
         g->batch = nullptr;
         g->stream = nullptr;
         g->owns_stream = true;
@@ -3739,6 +3744,7 @@ void td_batch_free(td_batch* b) {
         if (b->host_pcm) (void)hipHostFree(b->host_pcm);
         if (b->stream) (void)hipStreamDestroy(b->stream);
     }
+    drop_pending(b->arena);
     delete b;
 }
 long td_batch_add(td_batch* b, td_graph* g, const td_samplebank* sb, td_flowwbank* fb) {

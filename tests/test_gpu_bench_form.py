@@ -241,3 +241,28 @@ def test_a_bank_freed_before_the_deferred_check_has_run(gpu_api):
         gpu_api._check(gpu_api.lib().td_graph_read_pcm(g.h, pcm.ctypes.data_as(gpu_api.C.c_void_p), pcm.nbytes))
         got.append(pcm)
     assert np.abs(got[0]).max() > 1000 and np.array_equal(got[0], got[1])
+
+
+def test_a_member_rendered_on_its_own_then_the_batch_is_freed(gpu_api, oracle):
+    """A batch member rendered through its own handle queues on the BATCH's stream with its own table arena; with the
+    deferred check outstanding (norm_debug 1, no sync) the batch is freed -- its stream goes -- and the member, on the
+    stream it is given back, reads the oracle's bytes and keeps rendering."""
+    import gc
+    p = W.config1(seconds=1.0)
+    built = [p.build(gpu_api) for _ in range(2)]
+    batch = gpu_api.Batch()
+    for b in built:
+        b[2].set_option("norm_debug", 1)
+        batch.add(*b)
+    sb, fb, g = built[0]
+    g.render_all_async(sb, fb, p.cs, 16)
+    del batch
+    gc.collect()
+    g.sync()
+    assert g.norm_fix_runs() >= 1
+    osb, ofb, og = p.build(oracle)
+    ref = og.render_all(osb, ofb, p.cs, 16)
+    pcm = np.zeros_like(ref[0])
+    gpu_api._check(gpu_api.lib().td_graph_read_pcm(g.h, pcm.ctypes.data_as(gpu_api.C.c_void_p), pcm.nbytes))
+    assert np.array_equal(pcm, ref[0])
+    assert_bit_exact(g.render_all(sb, fb, p.cs, 16), og.render_all(osb, ofb, p.cs, 16))
