@@ -1205,6 +1205,7 @@ static int ensure_arena(Arena& ar, size_t bytes, hipStream_t stream) {
     ar.inflight = false;
     ar.valid = 0;
     ar.graph_key.clear();
+    ar.esync_len = 0;   // (new memory: the epoch-tagged words are zeroed by the next submission that has any)
     return 1;
 }
 static void free_arena(Arena& ar) {
@@ -2113,8 +2114,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             norm_scratch[vs[i]] = {pk, ic};
                             sum_desc_of[vs[i]] = d[i];
                             if (d[i].mode >= 4u) {   // one granule per workgroup (at most one per block)
-                                cb.sync_fix.push_back({o + offsetof(SumDesc, sync), cb.sync_bytes});
-                                cb.sync_bytes += (nb * 8 + 63) & ~(size_t)63;
+                                cb.esync_fix.push_back({o + offsetof(SumDesc, sync), cb.esync_bytes});
+                                cb.esync_bytes += (nb * 8 + 63) & ~(size_t)63;
                                 cb.flag_fix.push_back(o + offsetof(SumDesc, host_flag));
                             }
                             scratch_field(o, offsetof(SumDesc, peaks), pk);
@@ -2552,9 +2553,14 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     // ---- 3. upload
     const size_t upload = (st.b.size() + 255) & ~(size_t)255;
     const size_t sync_at = upload + ((cb.scratch_bytes + 255) & ~(size_t)255);
-    if (!ensure_arena(ar, sync_at + cb.sync_bytes + 256, stream)) return 0;
+    const size_t esync_at = sync_at + ((cb.sync_bytes + 255) & ~(size_t)255);
+    if (!ensure_arena(ar, esync_at + cb.esync_bytes + 256, stream)) return 0;
     for (auto& f : cb.sync_fix) {
         uint64_t p = (uint64_t)(uintptr_t)(ar.d + sync_at + f.off);
+        memcpy(&st.b[f.at], &p, 8);
+    }
+    for (auto& f : cb.esync_fix) {
+        uint64_t p = (uint64_t)(uintptr_t)(ar.d + esync_at + f.off);
         memcpy(&st.b[f.at], &p, 8);
     }
     for (size_t at : cb.flag_fix) {
@@ -2594,6 +2600,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         gkey.push_back(upload);
         gkey.push_back(sync_at);
         gkey.push_back(cb.sync_bytes);
+        gkey.push_back(cb.esync_bytes);
         gkey.push_back(cb.one_grid_sources ? 1u : 0u);
         for (auto& z : cb.zero) { gkey.push_back(z.off); gkey.push_back(z.bytes); }
         for (auto& L : launches) {
@@ -2630,6 +2637,27 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     } capture_guard{stream, want_graph};
     for (auto& z : cb.zero) TD_HIP(hipMemsetAsync(ar.d + upload + z.off, 0, z.bytes, stream));
     if (cb.sync_bytes) TD_HIP(hipMemsetAsync(ar.d + sync_at, 0, cb.sync_bytes, stream));
+    // The tile words of the stand-alone single-pass Normalize launches carry the submission's EPOCH beside their value (a
+    // kernel argument: the descriptors stay byte-identical from render to render and are not uploaded again).  A word of an
+    // earlier submission never compares equal, so the region is not zeroed between launches -- the memset was 2 us of the
+    // headline render's 66.  It is zeroed once whenever it lies elsewhere than last time (what was there before is not
+    // known to be words), when the arena is new, and before the epoch counter would wrap.  A captured submission
+    // (graph_replay) replays its arguments: it keeps zeroed words and tag 1.
+    uint32_t sum_tag = 1u;
+    if (!cb.esync_bytes || want_graph) ar.esync_len = 0;   // (this submission may write anything where the words lay)
+    if (cb.esync_bytes) {
+        if (want_graph) {
+            TD_HIP(hipMemsetAsync(ar.d + esync_at, 0, cb.esync_bytes, stream));
+        } else {
+            if (ar.esync_at != esync_at || ar.esync_len != cb.esync_bytes || ar.epoch == 0xFFFFFFFFu) {
+                TD_HIP(hipMemsetAsync(ar.d + esync_at, 0, cb.esync_bytes, stream));
+                ar.esync_at = esync_at;
+                ar.esync_len = cb.esync_bytes;
+                if (ar.epoch == 0xFFFFFFFFu) ar.epoch = 1u;
+            }
+            sum_tag = ++ar.epoch;
+        }
+    }
 
     // ---- 4. launch, level by level
     const auto tp3 = std::chrono::steady_clock::now();
@@ -2715,8 +2743,8 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
                 case F_ENV: launch_adsr_env((const AdsrVDesc*)d, L.n, L.M, s); break;
                 case F_SUM:
-                    if (L.aux >> 12) launch_norm1((const SumDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)(L.aux >> 12), s);   // single-pass Normalize, narrow forms
-                    else launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, (L.aux & 0x200u) != 0u, s);
+                    if (L.aux >> 12) launch_norm1((const SumDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)(L.aux >> 12), sum_tag, s);   // single-pass Normalize, narrow forms
+                    else launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, (L.aux & 0x200u) != 0u, sum_tag, s);
                     break;
                 case F_SCALE: launch_scale((const ScaleDesc*)d, L.n, L.M, L.bl, L.is_scan, s); break;
                 case F_NORMFIX: launch_norm_fix((const SumDesc*)d, L.n, L.M, L.bl, s); break;

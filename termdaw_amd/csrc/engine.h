@@ -213,6 +213,11 @@ struct Arena {
     hipStream_t fix_stream = nullptr;
     int fix_device = 0;
     bool listed = false;
+    // Epoch-tagged tile words (ChunkBuild::esync_bytes): where the region lay in the last submission that used epochs, and
+    // the last epoch handed out (>= 2 once used; 1 is the tag of zeroed words).  Same place -> everything in it is zero or a
+    // word of an earlier epoch, and no memset is needed; anywhere else -> zeroed once.
+    size_t esync_at = 0, esync_len = 0;
+    uint32_t epoch = 1;
 };
 
 // HIP-event timing of launch families (bench hook)
@@ -252,6 +257,10 @@ struct ChunkBuild {
     // memset per submission
     size_t sync_bytes = 0;
     std::vector<Fix> sync_fix;
+    // ... and the tile words of the stand-alone single-pass Normalize launches (SumDesc::sync of k_sum16w / k_norm1): a region
+    // of its own behind the zeroed one, NOT zeroed per submission -- the words carry the submission's epoch (submit_chunk)
+    size_t esync_bytes = 0;
+    std::vector<Fix> esync_fix;
     std::vector<size_t> flag_fix;   // pointer fields -> the arena's host-visible word (SumDesc::host_flag)
     std::vector<Launch> launches;
     size_t n_graphs = 0;
@@ -264,6 +273,8 @@ struct ChunkBuild {
         zero.clear();
         sync_bytes = 0;
         sync_fix.clear();
+        esync_bytes = 0;
+        esync_fix.clear();
         flag_fix.clear();
         launches.clear();
         n_graphs = 0;

@@ -455,10 +455,12 @@ void launch_band_fix(const BandSpecDesc* d, int n_desc, uint32_t frames, uint32_
 // k_norm1 (SumDesc mode 5 outside the wide all-loop sums): tiles per workgroup (1 | 2 | 4) with which the whole grid of a
 // `frames`-long chunk is resident at once, 0 if none; and its launch
 int norm1_tiles_per_workgroup(uint32_t term_mode, uint32_t frames);
-void launch_norm1(const SumDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int tpw, hipStream_t s);
+void launch_norm1(const SumDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int tpw, uint32_t tag, hipStream_t s);   // tag: see launch_sum
 int sum16w_resident_capacity(int nq, bool packed);   // workgroups of k_sum16w<nq, packed> the device holds at once (0: unknown)
 // must_wide: the descriptors hold a mode-4 / mode-5 Normalize, which only the k_sum16w forms implement (the engine sets it where they would run anyway)
-void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s);
+// tag: what a tile word of a single-pass Normalize (SumDesc::sync, modes 4 / 5) carries beside its value -- 1 when the engine has
+// zeroed the words before the launch, otherwise the submission's epoch (engine.cpp, submit_chunk)
+void launch_sum(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, uint32_t tag, hipStream_t s);
 void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, int is_scan, hipStream_t s);
 // second half of the speculative single-pass normalize: a no-op unless a block peak exceeded the carried max
 void launch_norm_fix(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);

@@ -132,8 +132,10 @@ TD_DEV float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y
 // before every launch (ONE memset per submission).
 typedef unsigned long long TD_GLOBAL* gu64;
 typedef uint32_t TD_GLOBAL* gu32;
-TD_DEV void granule_store(unsigned long long* p, uint32_t value) {
-    __hip_atomic_store((gu64)(TD_GLOBAL char*)p, (1ull << 32) | (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// (tag: 1 for words the engine zeroes before the launch; the single-pass Normalize's tile words carry the submission's EPOCH
+// instead -- a kernel argument, larger than every earlier one -- and are not zeroed between launches: engine.cpp, submit_chunk)
+TD_DEV void granule_store(unsigned long long* p, uint32_t value, uint32_t tag = 1u) {
+    __hip_atomic_store((gu64)(TD_GLOBAL char*)p, ((unsigned long long)tag << 32) | (unsigned long long)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 TD_DEV unsigned long long granule_load(const unsigned long long* p) {
     return __hip_atomic_load((gu64)(TD_GLOBAL char*)const_cast<unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -150,7 +152,7 @@ TD_DEV void raise_violated(NormState* st, uint32_t* host_flag) {
 // did not show within `limit` polls.  Four loads per thread are in flight before the first is looked at -- a thread's
 // granules, one dependent round trip after the other, were 2 - 3 us of every launch that ends in such a gather.
 template <typename F>
-TD_DEV bool for_lower_granules(const unsigned long long* sync, uint32_t n, uint32_t limit, F f) {
+TD_DEV bool for_lower_granules(const unsigned long long* sync, uint32_t n, uint32_t limit, F f, uint32_t tag = 1u) {
     bool ok = true;
     for (uint32_t base = threadIdx.x; base < n; base += 4u * (uint32_t)kThreads) {
         unsigned long long g[4];
@@ -163,11 +165,11 @@ TD_DEV bool for_lower_granules(const unsigned long long* sync, uint32_t n, uint3
         for (uint32_t u = 0; u < 4u; ++u) {
             const uint32_t idx = base + u * (uint32_t)kThreads;
             if (idx >= n) continue;
-            for (uint32_t spin = 0; (uint32_t)(g[u] >> 32) != 1u && spin < limit; ++spin) {
+            for (uint32_t spin = 0; (uint32_t)(g[u] >> 32) != tag && spin < limit; ++spin) {
                 __builtin_amdgcn_s_sleep(2);
                 g[u] = granule_load(sync + idx);
             }
-            if ((uint32_t)(g[u] >> 32) == 1u) f(idx, (uint32_t)g[u]);
+            if ((uint32_t)(g[u] >> 32) == tag) f(idx, (uint32_t)g[u]);
             else ok = false;
         }
     }
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
 // k_sum for all-packed-loop (or, PACKED = false, all-f32-loop) terms with 4 * NQ frames per lane: Sum vertices, and Normalize pass A when the
 // reference block is the 1024-frame tile (a workgroup then covers NQ whole blocks, a block 4 / NQ waves).
 template <int NQ, bool PACKED = true>
-__global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__ descs, uint32_t M) {
+__global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__ descs, uint32_t M, uint32_t tag) {
     const SumDesc& d = descs[blockIdx.y];
     const uint32_t m = blockIdx.x * (kTileFrames * NQ) + 4u * NQ * threadIdx.x;
     // (mode 4: the carried max, read before anything else -- the last tile replaces it once every tile has published)
@@ -756,12 +758,12 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         unsigned long long* const sync = d.sync;
         if (threadIdx.x == 0) {
             asm volatile("" ::"v"(init));   // (the carried max has been READ before this tile counts as published: the last tile replaces it)
-            granule_store(sync + blockIdx.x, __float_as_uint(T));
+            granule_store(sync + blockIdx.x, __float_as_uint(T), tag);
         }
         float pm = 0.0f;
         const bool forced = (d.debug & 1u) != 0u && blockIdx.x != 0u;   // (tests: every wait gives up at once)
         const bool ok = !forced && for_lower_granules(sync, blockIdx.x, kScanSpinLimitSum,
-                                                      [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); });
+                                                      [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); }, tag);
         pm = wave_max(pm);
         if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
         if (!ok) bad4 = 1u;
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
 // registers with the running peak  max_b = peak_b.max(max_{b-1})  (extensions.rs:321-329): same f32 operations as k_sum
 // mode 1 + k_scale, one launch instead of two and no raw-sum round trip.
 template <int TMODE, int TPW>
-__global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ descs, uint32_t M, uint32_t n_tiles) {
+__global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ descs, uint32_t M, uint32_t n_tiles, uint32_t tag) {
     const SumDesc& d = descs[blockIdx.y];
     // (the carried max, read before anything else: the last workgroup replaces it once every workgroup has published)
     const float init = d.use_init ? d.init_max : gload1(&d.state->max);
@@ -899,7 +901,7 @@ __global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ 
     }
     if (threadIdx.x == 0) {
         asm volatile("" ::"v"(init));   // (the carried max has been READ before this workgroup counts as published)
-        granule_store(d.sync + blockIdx.x, __float_as_uint(T));
+        granule_store(d.sync + blockIdx.x, __float_as_uint(T), tag);
         if (blockIdx.x == 0) {
             d.init_copy[0] = init;
             d.init_copy[1] = d.state->scan_max;
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(kThreads) void k_norm1(const SumDesc* __restrict__ 
     float pm = 0.0f;
     // (bounded, as in k_sum16w: a workgroup that gives up raises `violated` and k_norm_fix redoes the vertex)
     const bool forced = (d.debug & 1u) != 0u && blockIdx.x != 0u;   // (tests: every wait gives up at once)
-    const bool ok = !forced && for_lower_granules(d.sync, blockIdx.x, kScanSpinLimitSum, [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); });
+    const bool ok = !forced && for_lower_granules(d.sync, blockIdx.x, kScanSpinLimitSum, [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); }, tag);
     pm = wave_max(pm);
     if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
     if (!ok) bad1 = 1u;
@@ -3884,32 +3886,32 @@ int norm1_tiles_per_workgroup(uint32_t term_mode, uint32_t frames) {
     return 0;
 }
 template <int TMODE, int TPW>
-static void launch_norm1_of(const SumDesc* d, int n, uint32_t frames, hipStream_t s) {
+static void launch_norm1_of(const SumDesc* d, int n, uint32_t frames, uint32_t tag, hipStream_t s) {
     static const auto kern = &k_norm1<TMODE, TPW>;   // (a name without a comma for the launch macro)
     const uint32_t nt = (frames + kTileFrames - 1) / kTileFrames, gx = (nt + TPW - 1) / TPW;
     const int per = std::max(1, norm1_capacity_of<TMODE, TPW>() / (int)gx);   // (a slice must be resident at once)
     for (int o = 0; o < n; o += per)
-        hipLaunchKernelGGL(kern, dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames, nt);
+        hipLaunchKernelGGL(kern, dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames, nt, tag);
 }
 template <int TMODE>
-static void launch_norm1_mode(const SumDesc* d, int n, uint32_t frames, int tpw, hipStream_t s) {
-    if (tpw == 1) launch_norm1_of<TMODE, 1>(d, n, frames, s);
-    else if (tpw == 2) launch_norm1_of<TMODE, 2>(d, n, frames, s);
-    else launch_norm1_of<TMODE, 4>(d, n, frames, s);
+static void launch_norm1_mode(const SumDesc* d, int n, uint32_t frames, int tpw, uint32_t tag, hipStream_t s) {
+    if (tpw == 1) launch_norm1_of<TMODE, 1>(d, n, frames, tag, s);
+    else if (tpw == 2) launch_norm1_of<TMODE, 2>(d, n, frames, tag, s);
+    else launch_norm1_of<TMODE, 4>(d, n, frames, tag, s);
 }
-void launch_norm1(const SumDesc* d, int n, uint32_t frames, uint32_t term_mode, int tpw, hipStream_t s) {
+void launch_norm1(const SumDesc* d, int n, uint32_t frames, uint32_t term_mode, int tpw, uint32_t tag, hipStream_t s) {
     if (!n || !frames) return;
     switch (term_mode) {
-        case TERMS_ALL_EDGE: launch_norm1_mode<TERMS_ALL_EDGE>(d, n, frames, tpw, s); break;
-        case TERMS_ALL_LOOP32: launch_norm1_mode<TERMS_ALL_LOOP32>(d, n, frames, tpw, s); break;
-        case TERMS_ALL_LOOP16: launch_norm1_mode<TERMS_ALL_LOOP16>(d, n, frames, tpw, s); break;
-        case TERMS_EDGE_FEW: launch_norm1_mode<TERMS_EDGE_FEW>(d, n, frames, tpw, s); break;
-        case TERMS_ADSR1: launch_norm1_mode<TERMS_ADSR1>(d, n, frames, tpw, s); break;
-        case TERMS_WITH_ADSR: launch_norm1_mode<TERMS_WITH_ADSR>(d, n, frames, tpw, s); break;
-        default: launch_norm1_mode<TERMS_MIXED>(d, n, frames, tpw, s); break;
+        case TERMS_ALL_EDGE: launch_norm1_mode<TERMS_ALL_EDGE>(d, n, frames, tpw, tag, s); break;
+        case TERMS_ALL_LOOP32: launch_norm1_mode<TERMS_ALL_LOOP32>(d, n, frames, tpw, tag, s); break;
+        case TERMS_ALL_LOOP16: launch_norm1_mode<TERMS_ALL_LOOP16>(d, n, frames, tpw, tag, s); break;
+        case TERMS_EDGE_FEW: launch_norm1_mode<TERMS_EDGE_FEW>(d, n, frames, tpw, tag, s); break;
+        case TERMS_ADSR1: launch_norm1_mode<TERMS_ADSR1>(d, n, frames, tpw, tag, s); break;
+        case TERMS_WITH_ADSR: launch_norm1_mode<TERMS_WITH_ADSR>(d, n, frames, tpw, tag, s); break;
+        default: launch_norm1_mode<TERMS_MIXED>(d, n, frames, tpw, tag, s); break;
     }
 }
-void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, hipStream_t s) {
+void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t term_mode, bool wide_ok, bool must_wide, uint32_t tag, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tpb = (bl % kTileFrames == 0) ? bl / kTileFrames : 0;
     static const int env_nq = getenv("TD_FORCE_NQ") ? atoi(getenv("TD_FORCE_NQ")) : 0;   // tuning aid: 1 | 2 | 4
@@ -3925,7 +3927,7 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
                 const uint32_t gx = (frames + kTileFrames * 2 - 1) / (kTileFrames * 2);
                 const int per = must_wide ? std::max(1, sum16w_resident_capacity(2, false) / (int)gx) : n;
                 for (int o = 0; o < n; o += per)
-                    hipLaunchKernelGGL(k_sum32w_2, dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+                    hipLaunchKernelGGL(k_sum32w_2, dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames, tag);
             }
             else
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP32>), tiles(frames), kThreads, d, n, frames, bl, tpb);
@@ -3948,13 +3950,13 @@ void launch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl, uint32_t 
                 int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
                 if (must_wide) per = std::max(1, std::min(per, sum16w_resident_capacity(4, true) / (int)gx));   // (mode 5: a slice must be resident at once)
                 for (int o = 0; o < n; o += per)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<4>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<4>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames, tag);
             } else if (wide_ok && (forced_nq ? forced_nq == 2 : frames >= 1800u * kTileFrames)) {
                 const uint32_t gx = (frames + kTileFrames * 2 - 1) / (kTileFrames * 2);
                 int per = slice_env > 0 ? slice_env : (int)std::max(1u, (256u * 4u) / gx);
                 if (must_wide) per = std::max(1, std::min(per, sum16w_resident_capacity(2, true) / (int)gx));
                 for (int o = 0; o < n; o += per)
-                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<2>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_sum16w<2>), dim3(gx, std::min(per, n - o)), dim3(kThreads), 0, s, d + o, frames, tag);
             }
             else
                 TD_BATCHED(HIP_KERNEL_NAME(k_sum<TERMS_ALL_LOOP16>), tiles(frames), kThreads, d, n, frames, bl, tpb);

@@ -266,3 +266,48 @@ def test_a_member_rendered_on_its_own_then_the_batch_is_freed(gpu_api, oracle):
     gpu_api._check(gpu_api.lib().td_graph_read_pcm(g.h, pcm.ctypes.data_as(gpu_api.C.c_void_p), pcm.nbytes))
     assert np.array_equal(pcm, ref[0])
     assert_bit_exact(g.render_all(sb, fb, p.cs, 16), og.render_all(osb, ofb, p.cs, 16))
+
+
+def test_tile_words_carry_the_submissions_epoch(gpu_api, oracle):
+    """The single-pass Normalize's tile words are not zeroed between launches: they carry the submission's epoch.  Renders
+    of one graph back to back (same region: no memset), another layout in between (a scan, a block pull, a chunked
+    render: the region is written over and zeroed again when it comes back), a second graph on its own arena, graph
+    replay (captured arguments: zeroed words) -- every render the oracle's bytes, `violated` never raised."""
+    p = W.config2(seconds=8.0, n_src=12)
+    sb, fb, g = p.build(gpu_api)
+    for k, v in BENCH_OPTS.items():
+        g.set_option(k, v)
+    osb, ofb, og = p.build(oracle)
+
+    def both(n_blocks=None, fresh=True):
+        for be_g, be_fb in ((g, fb), (og, ofb)):
+            if fresh:
+                be_g.reset_normalize_vertices()
+            be_fb.set_time(0)
+            be_g.set_time(0)
+        got = g.render_all(sb, fb, n_blocks or p.cs, 16, want_f32=False)
+        ref = og.render_all(osb, ofb, n_blocks or p.cs, 16, want_f32=False)
+        assert np.array_equal(got[0], ref[0])
+        assert g.get_normalization_value("sum") == og.get_normalization_value("sum")
+
+    for _ in range(5):
+        both()
+    both(fresh=False)                       # (continues the running peak)
+    g.true_normalize_scan(sb, fb, p.cs)     # another launch list on the same arena
+    og.true_normalize_scan(osb, ofb, p.cs)
+    both(fresh=False)
+    for _ in range(3):
+        both()
+    both(n_blocks=7)                        # a shorter render: other offsets
+    both()
+    g.set_option("max_chunk_frames", 40000) # chunked: one submission per chunk, an epoch each
+    for _ in range(2):
+        both()
+    g.set_option("max_chunk_frames", 1 << 24)
+    g.set_option("graph_replay", 1)
+    for _ in range(3):
+        both()
+    g.set_option("graph_replay", 0)
+    for _ in range(3):
+        both()
+    assert g.norm_fix_runs() == 0
