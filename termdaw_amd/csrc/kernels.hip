@@ -129,7 +129,8 @@ TD_DEV float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y
 // Inter-workgroup hand-off inside a launch: 8-byte {tag = 1, value} granules, one agent-scope atomic store each, read back
 // with agent-scope atomic loads (global_store / global_load ... sc1: L1 bypassed, the data word carries its own validity,
 // so no fence on either side; cdna_hip_programming.md Guideline 16, form R2); the granule words are zeroed by the engine
-// before every launch (ONE memset per submission).
+// before every launch (ONE memset per submission) -- except the single-pass Normalize's tile words, whose tag is the
+// submission's epoch (granule_store's `tag`).
 typedef unsigned long long TD_GLOBAL* gu64;
 typedef uint32_t TD_GLOBAL* gu32;
 // (tag: 1 for words the engine zeroes before the launch; the single-pass Normalize's tile words carry the submission's EPOCH
