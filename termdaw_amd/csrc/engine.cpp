@@ -1115,12 +1115,14 @@ static int ensure_state_slots(td_graph* g) {
         }
         g->dstate = nd;
         g->dstate_cap = cap;
+        g->band_first_filled = false;   // (slots beyond the old capacity hold nothing yet)
     }
     if (g->state_host_dirty && need) {
         // host mirror is authoritative only right after construction / explicit host edits
         TD_HIP(hipStreamSynchronize(g->stream));
         TD_HIP(hipMemcpy(g->dstate, g->hstate.data(), need * sizeof(StateSlot), hipMemcpyHostToDevice));
         g->state_host_dirty = false;
+        g->band_first_filled = false;
     }
     return 1;
 }
@@ -2470,6 +2472,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     g->host_ms[0] += ms_between(tp0, tp1);   // event compile
     g->host_ms[1] += ms_between(tp1, tp2);   // descriptors
     g->state_dev_dirty = true;
+    g->band_first_filled = false;
     return 1;
 }
 
@@ -2983,7 +2986,7 @@ static int graph_set_time_impl(td_graph* g, size_t time) {   // graph.rs:123-128
             default: break;
         }
     }
-    if (any_band && g->dstate && !g->state_host_dirty && !g->hstate.empty()) {
+    if (any_band && g->dstate && !g->state_host_dirty && !g->hstate.empty() && !g->band_first_filled) {   // (a second set_time with nothing rendered in between -- the caller's own rewind after render_all's -- fills nothing)
         // ONE strided fill for every band-pass vertex' `first` word instead of one memset per vertex (a 256-vertex chain
         // paid 2 x 84 of them per render: 0.5 ms of host calls and as many tiny fill kernels).  The word at offset 16 of a
         // 32-byte slot is BandState::first; in a Normalize vertex' slot (NormState, 16 bytes) it is padding.  The fill
@@ -2992,6 +2995,7 @@ static int graph_set_time_impl(td_graph* g, size_t time) {   // graph.rs:123-128
         if (!ensure_device(g->device)) return 0;
         TD_HIP(hipMemset2DAsync(reinterpret_cast<char*>(g->dstate) + offsetof(tdk::BandState, first), sizeof(StateSlot), 1, 4,
                                 std::min(g->hstate.size(), g->dstate_cap), g->stream));
+        g->band_first_filled = true;
     }
     return 1;
 }
@@ -3538,6 +3542,7 @@ static int scan_end(td_graph* g, td_flowwbank* fb) {
                                   hipMemcpyDeviceToDevice, g->stream));
         }
     g->state_dev_dirty = true;
+    g->band_first_filled = false;
     if (!graph_set_time_impl(g, 0)) return 0;
     fb->set_time(0);
     return 1;

@@ -327,6 +327,7 @@ struct td_graph {
     tde::StateSlot* dstate = nullptr;
     size_t dstate_cap = 0;
     bool state_host_dirty = true, state_dev_dirty = false;
+    bool band_first_filled = false;   // every band-pass vertex' `first` word on the device is set and nothing has been submitted since (set_time fills once)
     // per-chunk table arena (pinned host + device); unused while the graph renders as part of a batch
     tde::Arena arena;
     tde::ChunkBuild build;
