@@ -1115,14 +1115,12 @@ static int ensure_state_slots(td_graph* g) {
         }
         g->dstate = nd;
         g->dstate_cap = cap;
-        g->band_first_filled = false;   // (slots beyond the old capacity hold nothing yet)
     }
     if (g->state_host_dirty && need) {
         // host mirror is authoritative only right after construction / explicit host edits
         TD_HIP(hipStreamSynchronize(g->stream));
         TD_HIP(hipMemcpy(g->dstate, g->hstate.data(), need * sizeof(StateSlot), hipMemcpyHostToDevice));
         g->state_host_dirty = false;
-        g->band_first_filled = false;
     }
     return 1;
 }
@@ -1133,6 +1131,8 @@ static int pull_state(td_graph* g) {
         if (!drain(g)) return 0;
         TD_HIP(hipMemcpy(g->hstate.data(), g->dstate, g->hstate.size() * sizeof(StateSlot), hipMemcpyDeviceToHost));
         g->state_dev_dirty = false;
+        for (const auto& v : g->vertices)   // (a set_time not yet carried to the device by a submission)
+            if (v.kind == K_BAND_PASS && v.state_slot >= 0 && v.first_pending) g->hstate[(size_t)v.state_slot].band.first = 1u;
     }
     return 1;
 }
@@ -2209,10 +2209,12 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 case F_BAND: {
                     std::vector<BandDesc> d;
                     for (size_t vi : vs) {
-                        const Vertex& v = g->vertices[vi];
+                        Vertex& v = g->vertices[vi];
                         BandDesc x{};
                         x.out = g->vbuf[vi];
                         x.state = &g->dstate[v.state_slot].band;
+                        x.first_override = v.first_pending ? 1u : 0u;   // (consumed here, like a Normalize vertex' init override)
+                        v.first_pending = false;
                         x.k = (uint32_t)g->edges[vi].size();
                         x.term_mode = term_mode[vi];
                         x.pass = v.pass;
@@ -2235,6 +2237,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.xq4 = bp.tmpq;
                         x.out = g->vbuf[vi];
                         x.state = &g->dstate[v.state_slot].band;
+                        x.first_override = g->vertices[vi].first_pending ? 1u : 0u;
+                        g->vertices[vi].first_pending = false;
                         x.nseg = bp.nseg;
                         x.S = bp.S;
                         x.W = bp.W;
@@ -2301,6 +2305,8 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             ScanPlan& sp = scan_plan[piece[i]];
                             BandStageDesc x{};
                             x.state = &g->dstate[v.state_slot].band;
+                            x.first_override = v.first_pending ? 1u : 0u;
+                            g->vertices[piece[i]].first_pending = false;
                             x.lgamma = v.lgamma;
                             x.hgamma = v.hgamma;
                             x.pass = v.pass;
@@ -2472,7 +2478,6 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     g->host_ms[0] += ms_between(tp0, tp1);   // event compile
     g->host_ms[1] += ms_between(tp1, tp2);   // descriptors
     g->state_dev_dirty = true;
-    g->band_first_filled = false;
     return 1;
 }
 
@@ -2917,6 +2922,7 @@ void HostSnapshot::take(const td_graph* g, const td_flowwbank* fb) {
         v[i].loop_t = x.loop_t;
         v[i].has_init_override = x.has_init_override;
         v[i].peak_known = x.peak_known;
+        v[i].first_pending = x.first_pending;
         v[i].init_override = x.init_override;
         v[i].state.clear();
         save_state(x, v[i].state);
@@ -2931,6 +2937,7 @@ void HostSnapshot::put(td_graph* g, td_flowwbank* fb) const {
         x.loop_t = v[i].loop_t;
         x.has_init_override = v[i].has_init_override;
         x.peak_known = v[i].peak_known;
+        x.first_pending = v[i].first_pending;
         x.init_override = v[i].init_override;
         load_state(x, v[i].state);
     }
@@ -2980,23 +2987,14 @@ static int graph_set_time_impl(td_graph* g, size_t time) {   // graph.rs:123-128
             case K_BAND_PASS:
                 if (v.state_slot >= 0) {
                     g->hstate[v.state_slot].band.first = 1u;
+                    v.first_pending = true;
                     any_band = true;
                 }
                 break;
             default: break;
         }
     }
-    if (any_band && g->dstate && !g->state_host_dirty && !g->hstate.empty() && !g->band_first_filled) {   // (a second set_time with nothing rendered in between -- the caller's own rewind after render_all's -- fills nothing)
-        // ONE strided fill for every band-pass vertex' `first` word instead of one memset per vertex (a 256-vertex chain
-        // paid 2 x 84 of them per render: 0.5 ms of host calls and as many tiny fill kernels).  The word at offset 16 of a
-        // 32-byte slot is BandState::first; in a Normalize vertex' slot (NormState, 16 bytes) it is padding.  The fill
-        // writes bytes, so `first` reads 0x01010101: every reader tests it against zero.
-        static_assert(sizeof(StateSlot) == 32 && offsetof(tdk::BandState, first) == 16, "state slot layout");
-        if (!ensure_device(g->device)) return 0;
-        TD_HIP(hipMemset2DAsync(reinterpret_cast<char*>(g->dstate) + offsetof(tdk::BandState, first), sizeof(StateSlot), 1, 4,
-                                std::min(g->hstate.size(), g->dstate_cap), g->stream));
-        g->band_first_filled = true;
-    }
+    (void)any_band;   // (no device work: the next submission's descriptors carry the vertices' first_override)
     return 1;
 }
 
@@ -3542,7 +3540,6 @@ static int scan_end(td_graph* g, td_flowwbank* fb) {
                                   hipMemcpyDeviceToDevice, g->stream));
         }
     g->state_dev_dirty = true;
-    g->band_first_filled = false;
     if (!graph_set_time_impl(g, 0)) return 0;
     fb->set_time(0);
     return 1;

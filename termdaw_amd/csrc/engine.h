@@ -125,6 +125,7 @@ struct Vertex {
     // carried device state slot (Normalize / BandPass), index into Graph::dstate
     int state_slot = -1;
     // reset_normalization (extensions.rs:295-299) is kept on the host until the next render consumes it
+    bool first_pending = false;         // band-pass: set_time since the vertex was last compiled into a submission (its descriptor's first_override)
     bool has_init_override = false;
     float init_override = 0.0f;
     // Normalize: the carried max is the result of a normalize scan (graph.rs:222-237), so a render is expected to
@@ -291,7 +292,7 @@ namespace tde {
 struct HostSnapshot {
     size_t t = 0, fb_frame = 0;
     std::vector<size_t> fb_start;
-    struct V { uint64_t loop_t; bool has_init_override, peak_known; float init_override; std::string state; };
+    struct V { uint64_t loop_t; bool has_init_override, peak_known, first_pending; float init_override; std::string state; };
     std::vector<V> v;
     void take(const td_graph* g, const td_flowwbank* fb);
     void put(td_graph* g, td_flowwbank* fb) const;
@@ -327,7 +328,6 @@ struct td_graph {
     tde::StateSlot* dstate = nullptr;
     size_t dstate_cap = 0;
     bool state_host_dirty = true, state_dev_dirty = false;
-    bool band_first_filled = false;   // every band-pass vertex' `first` word on the device is set and nothing has been submitted since (set_time fills once)
     // per-chunk table arena (pinned host + device); unused while the graph renders as part of a batch
     tde::Arena arena;
     tde::ChunkBuild build;

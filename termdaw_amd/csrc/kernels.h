@@ -284,6 +284,9 @@ struct BandDesc {
     uint32_t pass;
     float lgamma, hgamma;
     PanGain pg;
+    // set_time since the vertex last ran (extensions.rs:196-204 sets BandPass.first): the kernel treats the state's `first`
+    // word as set whatever the device copy says -- a descriptor bit instead of a fill kernel per set_time
+    uint32_t first_override, pad_fo;
 };
 
 // band_pass_gen, exact AND parallel: speculative segments.
@@ -319,6 +322,7 @@ struct BandSpecDesc {
     float decay1, decay4;   // e^(-gamma_min * 256), and its 4th power: decay of a state over one / four 256-frame blocks
     uint32_t post_blocks;   // blocks right before the segment that must not be held constants (~20 / gamma frames)
     uint32_t pass;
+    uint32_t first_override;   // see BandDesc
     float lgamma, hgamma;
     PanGain pg;
     // warm-up guess from the block responses (BandRespParam): state at a block boundary = Horner over the last K blocks
@@ -371,7 +375,7 @@ struct BandStageDesc {          // one band-pass vertex
     PanGain pg;                 // the vertex' own epilogue
     // what lies between this vertex' output and the next stage's input, in graph order (unused by the last stage);
     // each link first does its own sum_inputs `0.0 + x`, and so does the next band-pass vertex
-    uint32_t n_post, pad;
+    uint32_t n_post, first_override;   // first_override: see BandDesc
     BandPost post[3];
     // k_band_chain (a chain's launch; `pass` vertices only)
     float pn[16][2];            // (1 - gamma)^(n + 1), n = 0 .. NF - 1, {low, high} smoother: what an entry state still weighs after n + 1 frames

@@ -1943,7 +1943,7 @@ __global__ __launch_bounds__(kThreads) void k_band_pass(const BandDesc* __restri
     float y = 0.0f;
     const uint32_t c = lane & 3u;
     const float gam = (c & 2u) ? d.hgamma : d.lgamma;
-    bool first = d.state->first != 0;
+    bool first = d.state->first != 0 || d.first_override != 0u;
     if (lane < 4) y = reinterpret_cast<const float*>(d.state)[lane];
     const float lmul = d.lgamma == 0.0f ? 0.0f : 1.0f;
     const float hmul = d.hgamma == 0.0f ? 0.0f : 1.0f;
@@ -2046,7 +2046,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     const uint32_t start = seg * d.S;
     const uint32_t end = min(start + d.S, M);
     // exact state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
-    const float y_true0 = d.state->first ? gload1(xf + ch) : gload1(reinterpret_cast<const float*>(d.state) + c);
+    const float y_true0 = (d.state->first || d.first_override) ? gload1(xf + ch) : gload1(reinterpret_cast<const float*>(d.state) + c);
     // Input fetch: the four lanes of a quad load four consecutive 16-byte words (8 frames, 64 B) with ONE
     // instruction and hand them round with DPP quad broadcasts -- one vector-memory instruction per 8
     // steps instead of 8, which is what the address path of 16 independent streams per wave can sustain.
@@ -2787,7 +2787,7 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         for (uint32_t i = tid; i < n_stages * 5u; i += kThreads) {
             const uint32_t s = i / 5u, e = i - 5u * s;
             const uint32_t TD_GLOBAL* sw = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)stages[s].state);
-            st_l[s][e] = __uint_as_float(sw[e]);
+            st_l[s][e] = __uint_as_float((e == 4u && stages[s].first_override) ? 1u : sw[e]);   // (e == 4: `first`; set_time since the vertex last ran)
         }
         __syncthreads();
         if (tid == 0u) __hip_atomic_store((gu32)(TD_GLOBAL char*)(d.ticket + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3246,7 +3246,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         for (uint32_t i = tid; i < n_stages * 5u; i += kThreads) {
             const uint32_t s = i / 5u, e = i - 5u * s;
             const uint32_t TD_GLOBAL* sw = reinterpret_cast<const uint32_t TD_GLOBAL*>((const TD_GLOBAL char*)stages[s].state);
-            st_l[s][e] = __uint_as_float(sw[e]);
+            st_l[s][e] = __uint_as_float((e == 4u && stages[s].first_override) ? 1u : sw[e]);   // (e == 4: `first`; set_time since the vertex last ran)
         }
         __syncthreads();
         if (tid == 0u) __hip_atomic_store((gu32)(TD_GLOBAL char*)(d.ticket + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

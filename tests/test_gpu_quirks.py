@@ -416,3 +416,63 @@ def test_adsr_vertex_evaluated_by_its_consumer(gpu_api, oracle, consumer, stage,
         outs.append(seq)
     for a, b in zip(*outs):
         assert_bit_exact(a, b)
+
+
+@pytest.mark.parametrize("band_mode", [0, 1])
+def test_q4_band_first_travels_in_the_descriptors(gpu_api, oracle, band_mode):
+    """set_time re-arms BandPass.first (extensions.rs:196-204, quirk Q4) without device work: the next submission's
+    descriptors say so (first_override).  The sequences that could lose it: renders WITHOUT a set_time in between (the
+    state continues), two set_time calls in a row, a set_time followed by a graph edit (the host copy of the states is
+    pulled and pushed back: it must carry the re-armed word), a band-pass vertex that does not reach the output while
+    another does (quirk Q12: its word stays armed until it runs), and block pulls."""
+    def mk():
+        p = W.ProjectScript(48000, 1024)
+        p.set_length(0.9)
+        p.assets["a"] = W.Asset(W.noise_int16(77, 30001))
+        p.load_sample("a", "a", "")
+        p.add_sampleloop("src", 1.0, 0.0, "a")
+        p.add_bandpass("b1", 1.0, 0.0, 1.0, 300.0, 5000.0, True)
+        p.add_bandpass("b2", 1.2, 10.0, 1.0, 80.0, 0.0, False)
+        p.add_bandpass("side", 1.0, 0.0, 1.0, 500.0, 2000.0, True)      # (reaches the output only after the edit below)
+        p.add_sum("out", 1.0, 0.0)
+        p.connect("src", "b1")
+        p.connect("b1", "b2")
+        p.connect("src", "side")
+        p.connect("b2", "out")
+        p.set_output("out")
+        return p
+    p = mk()
+    built = []
+    for be in (gpu_api, oracle):
+        sb, fb, g = p.build(be)
+        if be is gpu_api:
+            g.set_option("band_mode", band_mode)
+        built.append((sb, fb, g))
+    cmp = assert_close if band_mode else assert_bit_exact
+
+    def both(fn):
+        outs = [fn(*b) for b in built]
+        if outs[0] is not None:
+            cmp(outs[0], outs[1])
+
+    cs = p.cs
+    both(lambda sb, fb, g: g.render_all(sb, fb, cs, 16))                       # first render: states seeded from buf[0]
+    both(lambda sb, fb, g: (fb.set_time(0), g.render_all(sb, fb, cs, 16))[1])   # render_all rewound the graph: re-armed
+    def no_rewind(sb, fb, g):                                                  # block pulls: no set_time in between
+        outs = []
+        for _ in range(3):
+            l, r = g.render(sb, fb)
+            fb.set_time_to_next_block()
+            outs.append(np.stack([l, r], 1))
+        return np.concatenate(outs)
+    got, ref = [no_rewind(*b) for b in built]
+    if band_mode:
+        assert float(np.sqrt(np.mean((got.astype(np.float64) - ref) ** 2))) <= 1e-6 * max(1.0, float(np.abs(ref).max()))
+    else:
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    def twice_then_edit(sb, fb, g):
+        g.set_time(0); g.set_time(0); fb.set_time(0)
+        g.connect("side", "out")                                                # the edit: host copy of the states pulled, pushed back
+        return g.render_all(sb, fb, cs, 16)
+    both(twice_then_edit)
+    both(lambda sb, fb, g: (fb.set_time(0), g.render_all(sb, fb, cs, 16))[1])
