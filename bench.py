@@ -566,7 +566,8 @@ def compact(o):
               "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic")}
         tp = r.get("traffic_profiled") or {}
         if tp:
-            rr["traffic_profiled"] = {"bytes": tp.get("bytes_per_launch"), "l2_hit": tp.get("l2_hit_rate"), "file": tp.get("profile")}
+            rr["traffic_profiled"] = {"bytes": tp.get("bytes_per_launch"), "l2_hit": tp.get("l2_hit_rate"), "avg_us_rocprof": tp.get("avg_us_rocprof"),
+                                      "file": tp.get("profile")}
         for k in ("bytes_per_frame", "ceiling_ms", "hbm_compulsory_bytes", "hbm_compulsory_frac", "frac_of_l2_peak", "frac_of_measured_copy", "measured_copy_GBs"):
             if k in r:
                 rr[k] = r[k]
@@ -808,6 +809,7 @@ def main():
                    "traffic": None,
                    "traffic_profiled": None if "hbm_side_bytes_per_launch" not in prof else {
                        "bytes_per_launch": prof["hbm_side_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate"),
+                       "avg_us_rocprof": prof.get("avg_us"),
                        "profile": "profiles/%s_pmc_summary.json" % PROFILE_TAG,
                        "note": "separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 per the gfx950 half-count rule + "
                                "WRITE_SIZE); fabric-side bytes: Infinity-Cache hits are included, so HBM bytes are at most this"}}
