@@ -11,6 +11,7 @@
 
 #include <fstream>
 #include <sstream>
+#include <thread>
 
 #include <hip/hip_runtime.h>
 
@@ -590,7 +591,28 @@ int td_state_render(td_state* s, const char* path_override) {
     if (!state_render_device(s)) return 0;
     std::string err;
     const std::string path = path_override ? path_override : s->output_file;
-    if (!tdw::write_wav_int(path.c_str(), s->host_pcm.data(), s->out_frames, 2, s->render_sr, (int)s->bd, &err)) return fail(err);
+    // A 60 s render is 11.5 MB of words that ARE the file's bytes (16- / 32-bit): one thread copying them into the page cache
+    // took 2.0 of td_state_render's 2.3 ms.  Slices written side by side (pwrite at their own offsets, wav.cpp) make the same file.
+    const size_t data_bytes = s->host_pcm.size();
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int parts = ((s->bd == 16 || s->bd == 32) && data_bytes >= ((size_t)1 << 20)) ? (int)std::max(1u, std::min(8u, hw / 2)) : 1;
+    if (parts == 1) {
+        if (!tdw::write_wav_int(path.c_str(), s->host_pcm.data(), s->out_frames, 2, s->render_sr, (int)s->bd, &err)) return fail(err);
+        return 1;
+    }
+    {   // (a file of that name is rewritten from its first byte, as File::create + write would leave it)
+        std::vector<std::string> errs((size_t)parts);
+        std::vector<char> ok((size_t)parts, 0);
+        std::vector<std::thread> pool;
+        for (int part = 1; part < parts; ++part)
+            pool.emplace_back([&, part] {
+                ok[(size_t)part] = tdw::write_wav_int_part(path.c_str(), s->host_pcm.data(), s->out_frames, 2, s->render_sr, (int)s->bd, part, parts, &errs[(size_t)part]);
+            });
+        ok[0] = tdw::write_wav_int_part(path.c_str(), s->host_pcm.data(), s->out_frames, 2, s->render_sr, (int)s->bd, 0, parts, &errs[0]);
+        for (auto& t : pool) t.join();
+        for (int part = 0; part < parts; ++part)
+            if (!ok[(size_t)part]) return fail(errs[(size_t)part]);
+    }
     return 1;
 }
 

@@ -105,3 +105,33 @@ def test_front_end_default_is_scan_mode(gpu_api, oracle, tmp_path):
     s2 = gpu_api.State("", 48000, 1024)
     assert s2.refresh(q.to_lua(str(tmp_path / "b")))
     assert np.array_equal(s2.render_to_memory(), q.render(oracle)[0])
+
+
+@pytest.mark.parametrize("bits", [16, 32, 24])
+def test_state_render_writes_a_large_file_in_slices(gpu_api, oracle, tmp_path, bits):
+    """td_state_render on an output of several MB: 16- / 32-bit files go out in slices written side by side (24-bit keeps the
+    one-writer form).  Byte for byte the canonical header + the oracle's words -- over a LONGER file of that name too (the
+    reference's File::create + write leaves nothing of it)."""
+    import struct
+    p = W.config2(seconds=12.0, n_src=6)
+    p.set_render_bitdepth(bits)
+    lua = p.to_lua(str(tmp_path / "a"))
+    osb, ofb, og = p.build(oracle)
+    ref = og.render_all(osb, ofb, p.cs, bits, want_f32=False)[0]
+    if bits == 24:
+        body = np.ascontiguousarray(ref.reshape(-1).astype("<i4")).view(np.uint8).reshape(-1, 4)[:, :3].tobytes()
+    else:
+        body = np.ascontiguousarray(ref, dtype="<i2" if bits == 16 else "<i4").tobytes()
+    bps = bits // 8
+    fmt = struct.pack("<HHIIHH", 1 if bits <= 16 else 0xFFFE, 2, 48000, 48000 * 2 * bps, 2 * bps, bits)
+    s = gpu_api.State("", 48000, 1024)
+    assert s.refresh(lua), gpu_api.last_error()
+    out = tmp_path / "o.wav"
+    out.write_bytes(b"\xAA" * (len(body) + 100000))         # a longer file of that name
+    s.render(str(out))
+    raw = out.read_bytes()
+    assert raw[:4] == b"RIFF" and raw[8:12] == b"WAVE" and struct.unpack("<I", raw[4:8])[0] == len(raw) - 8
+    data_at = raw.index(b"data") + 8
+    assert struct.unpack("<I", raw[data_at - 4:data_at])[0] == len(body)
+    assert raw[20:36] == fmt[:16]
+    assert raw[data_at:] == body
