@@ -231,3 +231,18 @@ def test_bench_line_compact_form_fits_the_drivers_tail():
     assert keys.index("edge_buffer_mode") < keys.index("configs") and keys.index("config5") < keys.index("configs")
     assert keys.index("scanned") < keys.index("configs")
     assert os.path.exists(os.path.join(ROOT, "profiles", "NOTES.md"))
+
+
+def test_the_complete_rust_binding_follows_the_header():
+    """docs/amd_ffi.rs (the full `extern "C"` block INTEGRATION.md points to) is what tools/gen_rust_extern.py makes of
+    include/termdaw_amd.h today, and names every entry point the header declares."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_extern.py")], capture_output=True, text=True, check=True).stdout
+    assert out == open(os.path.join(root, "docs", "amd_ffi.rs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(root, "include", "termdaw_amd.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(td_[a-z0-9_]+)\s*\(", header))
+    bound = set(re.findall(r"pub fn (td_[a-z0-9_]+)\(", out))
+    assert declared == bound and len(bound) > 90
