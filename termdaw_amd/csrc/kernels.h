@@ -101,7 +101,8 @@ struct SumDesc {
                                //    of k_band_chain).  Same kernel code as mode 4: the wait for earlier tiles is BOUNDED, a tile
                                //    that gives up raises state->violated (and *host_flag) and k_norm_fix redoes the vertex
     uint32_t term_mode;        // TermMode: lets the kernel pick a loop specialised for the term kinds
-    uint32_t debug;            // (tests) bit 0: every wait for an earlier tile's granule gives up at once -> violated -> k_norm_fix
+    uint32_t debug;            // (tests) bit 0: every wait for an earlier tile's granule gives up at once -> violated -> k_norm_fix;
+                               // bit 1 (k_sum16w, timing experiments only -- WRONG results): the earlier tiles' words are not read at all
     PanGain pg;
     // mode 2: a second copy of the raw sum, planar within every aligned 4-frame block --
     // {l0 l1 l2 l3}{r0 r1 r2 r3} instead of {l0 r0 l1 r1}{l2 r2 l3 r3} -- the form k_band_spec's warm-up

@@ -763,7 +763,7 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
         }
         float pm = 0.0f;
         const bool forced = (d.debug & 1u) != 0u && blockIdx.x != 0u;   // (tests: every wait gives up at once)
-        const bool ok = !forced && for_lower_granules(sync, blockIdx.x, kScanSpinLimitSum,
+        const bool ok = (d.debug & 2u) ? true : !forced && for_lower_granules(sync, blockIdx.x, kScanSpinLimitSum,
                                                       [&pm](uint32_t, uint32_t v) { pm = fmaxf(pm, __uint_as_float(v)); }, tag);
         pm = wave_max(pm);
         if ((threadIdx.x & 63) == 0) pm4[wave] = pm;
