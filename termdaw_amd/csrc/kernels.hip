@@ -3405,9 +3405,14 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         // the next link's envelope gains for the lane's frames: issued now -- the look-back's round trip lies ahead, and the
         // eight registers are not held through the recurrence and the scan --, used after the output
         float4 envv[NP / 2];
+        // (wave 0 issues them BEHIND its serial section: in front of it they are four more loads the hand-off's own loads queue
+        // behind -- vmcnt counts in order: 0.331 -> 0.321 ms)
+        auto load_env = [&]() {
 #pragma unroll
-        for (int q = 0; q < NP / 2; ++q)
-            envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < NP / 2; ++q)
+                envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        if (wave != 0u) load_env();
         double xw0 = 0.0, xw2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave; a_wave^wave
         for (uint32_t w = 0; w < wave; ++w) {   // (uniform trip count)
             awp0 *= sp->aw[0]; awp2 *= sp->aw[1];
@@ -3415,6 +3420,9 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             xw2 = __builtin_fma(xw2, sp->aw[1], wtot[w][1]);
         }
         if (wave == 0u) {
+            // The tile's serial section -- the other three waves wait at barrier 2 for it -- goes ahead of the other tiles' waves
+            // on this SIMD (0.340 -> 0.331 ms on config 4: the first change to this kernel's arithmetic side that moved it)
+            __builtin_amdgcn_s_setprio(3);
             // the whole tile's response (wave 0: xw is still 0), then the state at the chunk's first frame: carried, or seeded
             // from buf[0] (extensions.rs:664-670)
             double T0 = 0.0, T2 = 0.0;
@@ -3424,6 +3432,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 T2 = __builtin_fma(T2, sp->aw[1], wtot[w][1]);
             }
             double C0 = 0.0, C2 = 0.0;
+            uint32_t c_lane = 63u;   // the lane that ends up with the state entering the tile
             unsigned long long* const sync = sp->sync;
             if (tile == 0u) {
                 const bool first = __float_as_uint(st_l[s][4]) != 0u;
@@ -3451,6 +3460,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                     const unsigned long long* g = sync + (size_t)(tile - 1u - (mine ? j : 0u)) * 8u;
                     unsigned long long g0 = 0, g1 = 0, g2 = 0, g3 = 0;
                     bool ok = !mine;
+
                     for (;;) {
                         if (dflags & 2u) break;   // (timing experiments only: no look-back -- wrong results)
                         if (!ok) {   // (a lane whose four words have arrived reads no more: the queue is left to the late ones)
@@ -3473,15 +3483,21 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                 C0 += dpp_f64<kDppRowShr + 2, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 2, 0xF>(C2);
                 C0 += dpp_f64<kDppRowShr + 4, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 4, 0xF>(C2);
                 C0 += dpp_f64<kDppRowShr + 8, 0xF>(C0); C2 += dpp_f64<kDppRowShr + 8, 0xF>(C2);
-                C0 += dpp_f64<kDppRowBcast15, 0xA>(C0); C2 += dpp_f64<kDppRowBcast15, 0xA>(C2);
-                C0 += dpp_f64<kDppRowBcast31, 0xC>(C0); C2 += dpp_f64<kDppRowBcast31, 0xC>(C2);
+                if (n_pred > 16u) {   // (uniform; up to 16 predecessors sit in row 0: its total is in lane 15, the other rows add zeros)
+                    C0 += dpp_f64<kDppRowBcast15, 0xA>(C0); C2 += dpp_f64<kDppRowBcast15, 0xA>(C2);
+                    C0 += dpp_f64<kDppRowBcast31, 0xC>(C0); C2 += dpp_f64<kDppRowBcast31, 0xC>(C2);
+                } else {
+                    c_lane = 15u;
+                }
             }
             // (x - x == 0 only for finite x: the tile's response -- every lane's run feeds it -- and, in lane 63, the state entering it)
             if (poisoned_at == n_stages && __any((!(T0 - T0 == 0.0) || !(T2 - T2 == 0.0) || !(C0 - C0 == 0.0) || !(C2 - C2 == 0.0)) ? 1 : 0)) poisoned_at = s;
-            if (lane == 63u) { carry_s[0] = C0; carry_s[1] = C2; }
+            if (lane == c_lane) { carry_s[0] = C0; carry_s[1] = C2; }
             // (the last stage: the tile's verdict is final -- out it goes now, a stage's output phase ahead of the gather at the end)
             if (s + 1u == n_stages && lane == 0u) granule_store(d.poison + tile, poisoned_at);
             stamp(s, 5u);
+            __builtin_amdgcn_s_setprio(0);
+            load_env();
         }
         __syncthreads();   // barrier 2: the state entering the tile
         stamp(s, 6u);
