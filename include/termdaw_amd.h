@@ -300,7 +300,7 @@ void td_state_free(td_state* s);
  * against the reference's serial recurrence (measured 6.3e-8 RMS through 84 band-pass vertices in a row; above 1e-6 of the
  * output peak only where a band-pass vertex removes >= 30 dB of its input and a Normalize vertex brings the rest back up: 8 of
  * 18 000 random graphs, at most 3.3e-6).  That is the bound BASELINE's north_star sets for float filter paths, and it is what
- * makes a deep effect chain fast: BASELINE config 4 (84 band-pass vertices) renders in 0.415 ms in scan mode and 12.0 ms with the
+ * makes a deep effect chain fast: BASELINE config 4 (84 band-pass vertices) renders in 0.39 ms in scan mode and 12.0 ms with the
  * exact kernels.  td_state_set_option(s, "band_mode", 0) selects the exact kernels -- bit-identical to the reference's
  * recurrence, the mode every bit-exact parity test runs in; a project without band-pass vertices renders the same bytes in
  * both. */
