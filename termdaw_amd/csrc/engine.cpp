@@ -2644,7 +2644,46 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         }
     } capture_guard{stream, want_graph};
     for (auto& z : cb.zero) TD_HIP(hipMemsetAsync(ar.d + upload + z.off, 0, z.bytes, stream));
-    if (cb.sync_bytes) TD_HIP(hipMemsetAsync(ar.d + sync_at, 0, cb.sync_bytes, stream));
+    // The launches of a level that read no edge buffer -- affine Synth, wavetable voice, SampleLerp, the envelope buffers -- go
+    // out as ONE grid (k_sources, kernels.hip): the first launch of each kind, the longest-running kind first.  `pick`: the
+    // launch index per SourceKind, -1: none; returns the common frame count, 0: no such grid for launches [li, lj).
+    auto sources_grid = [&](size_t li, size_t lj, long pick[4]) -> uint32_t {
+        pick[0] = pick[1] = pick[2] = pick[3] = -1;
+        if (!cb.one_grid_sources || lj - li > 64) return 0u;
+        uint32_t M0 = 0;
+        int found = 0, n_desc = 0;
+        for (size_t q = li; q < lj; ++q) {
+            const Launch& L = launches[q];
+            int kd = -1;
+            switch (L.fam) {
+                case F_SYNTH: kd = (L.aux & 1u) ? (int)SRC_SYNTH_AFFINE : -1; break;
+                case F_SAMPSYN: kd = (int)SRC_SAMPSYN; break;
+                case F_LERP: kd = (int)SRC_LERP; break;
+                case F_ENV: kd = (int)SRC_ENV; break;
+                default: break;
+            }
+            if (kd < 0 || pick[kd] >= 0 || !L.n || !L.M) continue;
+            if (found && L.M != M0) continue;
+            M0 = L.M;
+            pick[kd] = (long)q;
+            n_desc += L.n;
+            ++found;
+        }
+        // (a large batch gains nothing -- its grids have no ramp or tail to speak of -- and the envelope part would run at the
+        // Synth part's register budget: 32 config-3 projects measured 2 % slower in one grid, 8 the same)
+        return (found >= 2 && n_desc <= 16) ? M0 : 0u;
+    };
+    // The zeroed hand-off words: by a fill kernel of their own -- or, when the submission opens with a k_sources grid, by that
+    // grid's threads (everything that reads the words is behind it on the stream): one launch less in front of a scan render.
+    bool zero_in_sources = false;
+    if (cb.sync_bytes) {
+        size_t l0 = 0;
+        while (l0 < launches.size() && launches[l0].level == launches[0].level) ++l0;
+        long pick0[4];
+        const bool forks = fork_g && fork_g->branch_streams;
+        zero_in_sources = !forks && !launches.empty() && cb.sync_bytes <= ((size_t)1 << 28) && sources_grid(0, l0, pick0) != 0u;
+        if (!zero_in_sources) TD_HIP(hipMemsetAsync(ar.d + sync_at, 0, cb.sync_bytes, stream));
+    }
     // The tile words of the stand-alone single-pass Normalize launches carry the submission's EPOCH beside their value (a
     // kernel argument: the descriptors stay byte-identical from render to render and are not uploaded again).  A word of an
     // earlier submission never compares equal, so the region is not zeroed between launches -- the memset was 2 us of the
@@ -2685,35 +2724,11 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
             for (int a = 0; a < td_graph::kAuxStreams; ++a)
                 if (groups & (2u << a)) TD_HIP(hipStreamWaitEvent(fork_g->aux[a], fork_g->ev_fork, 0));
         }
-        // The level's launches that read no edge buffer -- affine Synth, wavetable voice, SampleLerp, the envelope buffers -- as
-        // ONE grid (k_sources, kernels.hip): the first launch of each kind, the longest-running kind first.
-        uint64_t in_one_grid = 0;   // bit q - li: launched as a part of it
-        if (cb.one_grid_sources && !fork && lj - li <= 64) {
-            auto kind_of = [](const Launch& L) -> int {
-                switch (L.fam) {
-                    case F_SYNTH: return (L.aux & 1u) ? (int)SRC_SYNTH_AFFINE : -1;
-                    case F_SAMPSYN: return (int)SRC_SAMPSYN;
-                    case F_LERP: return (int)SRC_LERP;
-                    case F_ENV: return (int)SRC_ENV;
-                    default: return -1;
-                }
-            };
-            long pick[4] = {-1, -1, -1, -1};
-            uint32_t M0 = 0;
-            int found = 0;
-            for (size_t q = li; q < lj; ++q) {
-                const int kd = kind_of(launches[q]);
-                if (kd < 0 || pick[kd] >= 0 || !launches[q].n || !launches[q].M) continue;
-                if (found && launches[q].M != M0) continue;
-                M0 = launches[q].M;
-                pick[kd] = (long)q;
-                ++found;
-            }
-            // (a large batch gains nothing -- its grids have no ramp or tail to speak of -- and the envelope part would run at the
-            // Synth part's register budget: 32 config-3 projects measured 2 % slower in one grid, 8 the same)
-            int n_desc = 0;
-            for (int kd = 0; kd < 4; ++kd) n_desc += pick[kd] >= 0 ? launches[(size_t)pick[kd]].n : 0;
-            if (found >= 2 && n_desc <= 16) {
+        uint64_t in_one_grid = 0;   // bit q - li: launched as a part of the level's k_sources grid
+        if (!fork) {
+            long pick[4];
+            const uint32_t M0 = sources_grid(li, lj, pick);
+            if (M0) {
                 SourceParts P{};
                 for (int kd = 0; kd < 4; ++kd) {
                     if (pick[kd] < 0) continue;
@@ -2727,8 +2742,9 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                     }
                     in_one_grid |= 1ull << ((size_t)pick[kd] - li);
                 }
+                const bool z = zero_in_sources && li == 0;   // (the submission's first grid clears the hand-off words)
                 Prof pr(prof, F_SOURCES, stream);
-                launch_sources(P, M0, stream);
+                launch_sources(P, M0, z ? ar.d + sync_at : nullptr, z ? (cb.sync_bytes + 15) & ~(size_t)15 : 0, stream);
             }
         }
         for (size_t q = li; q < lj; ++q) {

@@ -485,8 +485,14 @@ struct SourceParts {   // the launches that become parts (n_* 0: none of that ki
     const LerpDesc* lerp = nullptr; int n_lerp = 0;
     const AdsrVDesc* env = nullptr; int n_env = 0;
 };
-struct SourceGrid { uint32_t gx[4], end[4]; };   // per SourceKind: workgroups per descriptor; the first workgroup BEHIND the part
-int launch_sources(const SourceParts& P, uint32_t frames, hipStream_t s);
+struct SourceGrid {
+    uint32_t gx[4], end[4];   // per SourceKind: workgroups per descriptor; the first workgroup BEHIND the part
+    // The submission's zeroed hand-off words (ChunkBuild::sync_bytes: tickets and granules of the scan launches BEHIND this one
+    // on the stream), cleared by this grid's threads instead of by a fill kernel of their own (16-byte words; 0: nothing)
+    uint4* zero;
+    uint32_t zero_n16, pad;
+};
+int launch_sources(const SourceParts& P, uint32_t frames, void* zero, size_t zero_bytes, hipStream_t s);   // zero_bytes: a multiple of 16
 void launch_adsr(const AdsrVDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);
 void launch_band_pass(const BandDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 

@@ -1893,6 +1893,10 @@ __global__ __launch_bounds__(kThreads, MINB) void k_sources(const SynthDesc* __r
     // (the descriptor arrays are kernel arguments of their own, `__restrict__` like the families' own kernels': read through a
     // pointer taken from a table in the argument block they were vector loads -- the envelope part's table build 25 dependent ones)
     const uint32_t b = blockIdx.x;
+    if (G.zero_n16) {   // (one store per thread at most for a deep chain's 3.8 MB: ahead of the block's own work, off its critical path)
+        uint4* const z = G.zero;
+        for (uint32_t i = b * kThreads + threadIdx.x; i < G.zero_n16; i += gridDim.x * kThreads) z[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
     if ((KINDS & (1u << SRC_SYNTH_AFFINE)) && b < G.end[SRC_SYNTH_AFFINE]) {
         const uint32_t by = b / G.gx[SRC_SYNTH_AFFINE];
         synth_affine_block(sd[by], b - by * G.gx[SRC_SYNTH_AFFINE], M);
@@ -4044,9 +4048,11 @@ uint32_t source_part_grid(uint32_t kind, uint32_t frames) {
     }
     return tiles(frames);
 }
-int launch_sources(const SourceParts& P, uint32_t frames, hipStream_t s) {
+int launch_sources(const SourceParts& P, uint32_t frames, void* zero, size_t zero_bytes, hipStream_t s) {
     if (!frames) return 1;
     SourceGrid G{};
+    G.zero = (uint4*)zero;
+    G.zero_n16 = (uint32_t)(zero_bytes / 16);
     uint32_t kinds = 0u, total = 0u;
     const int n[4] = {P.n_synth, P.n_sampsyn, P.n_lerp, P.n_env};
     for (uint32_t k = 0; k < 4u; ++k) {
