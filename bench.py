@@ -279,12 +279,23 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     # (a short timed region -- the driver's K = 20 -- carries ONE sampled step, a middle one, not K / 8 + 1: each costs ~15 us of the
     # region; the sampling counter starts at this call, so `every` = K with K // 2 untimed-warm steps' worth of offset is not
     # available -- the engine samples submissions 0, every, 2 every, ...: every = K makes it the first step of the region)
-    every = PROF_EVERY if steps >= 64 else max(PROF_EVERY, steps)
+    # A short timed region -- the driver's K = 20 -- carries NO per-launch event pair (one cost ~15 us of the 1.3 ms region):
+    # two marks on the engine's stream bracket the K submissions instead, and a family's average duration is the marked
+    # time over its launches (valid where a step is that family's launches only: the headline's one launch per step).
+    batch.set_profiling(1)                   # (one sampled step outside the region: which families a step launches, how often)
+    step()
+    batch.sync()
+    fam0 = batch.kernel_times()
+    batch.set_profiling(0)
+    by_marks = steps < 64 and len(fam0) == 1
+    every = PROF_EVERY if steps >= 64 else (0 if by_marks else max(PROF_EVERY, steps))
     batch.set_profiling(every)
     barrier()
     t0 = time.perf_counter()
+    batch.mark(0)
     for _ in range(steps):
         step()
+    batch.mark(1)
     # The closing barrier.  With more than one rank it IS the path's only exchange -- one all-reduce(max) of the peak table on
     # device memory, which no rank leaves before every rank has contributed, i.e. has finished its K steps (each contributes
     # only after synchronising its engine stream) -- followed by torch.cuda.synchronize(): a second collective (dist.barrier)
@@ -299,7 +310,11 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     peaks = exchange.host()                  # (the report's copy of the table: outside the timed region, like the PCM it stays in HBM)
     ktimes = batch.kernel_times()
     batch.set_profiling(0)
-    return dt, ktimes, peaks, every
+    marked = batch.marked_ms()
+    if by_marks and marked > 0:
+        (fam, (_, per_step)), = fam0.items()
+        ktimes = {fam: (marked, steps * per_step)}
+    return dt, ktimes, peaks, every, marked
 
 
 def time_project(p, api, opts, reps):
@@ -622,7 +637,7 @@ def compact(o):
     elif cf:
         c["configs"] = cf
     c["rooflines"] = [{k: r2.get(k) for k in ("kernel", "avg_ms", "launches", "achieved", "peak", "frac", "bytes_per_frame") if k in r2} for r2 in o.get("rooflines", [])]
-    for k in ("kernel_timing_every", "host_ms_per_step", "peak_table_entries", "device_bytes", "vertex_frames_per_s"):
+    for k in ("kernel_timing_every", "marked_ms", "host_ms_per_step", "peak_table_entries", "device_bytes", "vertex_frames_per_s"):
         if k in o:
             c[k] = o[k]
     c["peak_table"] = o.get("peak_table", [])[:4]
@@ -705,7 +720,7 @@ def main():
     batch, project = build_batch(api, workloads, rank, world, P, args.seconds, args.no_fuse, args.no_pack)
     cs, bl = project.cs, project.bl
     frames = cs * bl
-    dt, ktimes, peaks, prof_every = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
+    dt, ktimes, peaks, prof_every, marked_ms = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
     dt = reduce_max(dt)
     device_bytes = sum(g.device_bytes() for _, _, g in batch.projects)
     host = batch.host_times()
@@ -723,7 +738,7 @@ def main():
     if want_c5:
         c5_steps = max(2, min(10, args.steps))
         b64, _ = build_batch(api, workloads, rank, world, 64, args.seconds, False, False)
-        dt5, kt5, pk5, _ = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
+        dt5, kt5, pk5, _, _ = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
         dt5 = reduce_max(dt5)
         c5 = {"projects_per_gpu": 64, "projects": 64 * world, "steps": c5_steps, "ms_per_step": round(dt5 / c5_steps * 1e3, 4),
               "ms_per_project": round(dt5 / c5_steps / 64 * 1e3, 5),
@@ -908,7 +923,9 @@ def main():
                        "parallelism": "projects sharded across GPUs; RCCL all-reduce(max) of the %d-entry peak table only" % (P * world)},
             "roofline": roofline,
             "rooflines": kernels,
-            "kernel_timing": "HIP events around each launch of every %dth step of the timed region, engine stream" % prof_every,
+            "kernel_timing": ("HIP events around each launch of every %dth step of the timed region, engine stream" % prof_every) if prof_every else
+                             "two HIP-event marks on the engine's stream around the K submissions of the timed region (a step launches one family only): average = marked time / launches",
+            "marked_ms": round(marked_ms, 5),
             "kernel_timing_every": prof_every,
             "prewarm": "%.2f s of untimed steps before the W warm-up steps (steady device clocks)" % PREWARM_S,
             "host_ms_per_step": {k: round(v / max(host["steps"], 1), 5) for k, v in host.items() if k != "steps"},

@@ -287,6 +287,10 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
 void td_batch_set_profiling(td_batch* b, int on);
 size_t td_batch_last_kernel_times(td_batch* b, const char** names, float* ms, size_t* launches, size_t cap);
 size_t td_batch_host_times(td_batch* b, double* ms4, int reset);
+/* ... and two marks on the batch's stream: td_batch_mark(b, 0) before a run of submissions, td_batch_mark(b, 1) behind it;
+ * td_batch_marked_ms: the time between them on the device (HIP events; waits for the second; < 0: not both set). */
+int td_batch_mark(td_batch* b, int which);
+double td_batch_marked_ms(td_batch* b);
 
 /* ---- Project front-end: State (state.rs:27-578) -------------------------------------------- */
 /* State{..} as constructed at main.rs:75-98 (render_sr 48000, bd 16, output "outp.wav"). */

@@ -108,6 +108,8 @@ SIGNATURES = {
     "td_batch_set_profiling": (None, [_vp, _i32]),
     "td_batch_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
     "td_batch_host_times": (_sz, [_vp, C.POINTER(C.c_double), _i32]),
+    "td_batch_mark": (_i32, [_vp, _i32]),
+    "td_batch_marked_ms": (C.c_double, [_vp]),
     "td_state_new": (_vp, [_cp, _sz, _sz]),
     "td_state_open": (_vp, [_cp]),
     "td_state_free": (None, [_vp]),
@@ -539,6 +541,13 @@ class Batch:
         cnt = (_sz * cap)()
         n = lib().td_batch_last_kernel_times(self.h, names, ms, cnt, cap)
         return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
+
+    def mark(self, which):
+        """A mark on the batch's stream: 0 before a run of submissions, 1 behind it (marked_ms: device time between them)."""
+        _check(lib().td_batch_mark(self.h, int(which)))
+
+    def marked_ms(self):
+        return float(lib().td_batch_marked_ms(self.h))
 
     def host_times(self, reset=True):
         out = (C.c_double * 4)()

@@ -3787,6 +3787,7 @@ void td_batch_free(td_batch* b) {
         if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
         if (b->d_pcm_arena) (void)hipFree(b->d_pcm_arena);
         for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
+        for (hipEvent_t e : b->ev_mark) if (e) (void)hipEventDestroy(e);
         if (b->host_pcm) (void)hipHostFree(b->host_pcm);
         if (b->stream) (void)hipStreamDestroy(b->stream);
     }
@@ -4078,6 +4079,22 @@ int td_batch_peaks(td_batch* b, float* out) {   // host copy of this batch's own
     return ok;
 }
 void td_batch_set_profiling(td_batch* b, int on) { prof_set(b->prof, on); }
+int td_batch_mark(td_batch* b, int which) {
+    if (which < 0 || which > 1) return fail("td_batch_mark: which is 0 or 1");
+    if (!ensure_device(b->device)) return 0;
+    if (!b->stream) TD_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    if (!b->ev_mark[which]) TD_HIP(hipEventCreate(&b->ev_mark[which]));
+    TD_HIP(hipEventRecord(b->ev_mark[which], b->stream));
+    b->mark_set[which] = true;
+    if (which == 0) b->mark_set[1] = false;
+    return 1;
+}
+double td_batch_marked_ms(td_batch* b) {
+    if (!(b->mark_set[0] && b->mark_set[1]) || hipSetDevice(b->device) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventSynchronize(b->ev_mark[1]) != hipSuccess || hipEventElapsedTime(&ms, b->ev_mark[0], b->ev_mark[1]) != hipSuccess) return -1.0;
+    return (double)ms;
+}
 size_t td_batch_last_kernel_times(td_batch* b, const char** names, float* ms, size_t* launches, size_t cap) {
     if (!(b->stream && hipSetDevice(b->device) == hipSuccess)) return 0;
     (void)hipStreamSynchronize(b->stream);

@@ -410,6 +410,8 @@ struct td_batch {
     size_t d_pcm_arena_cap = 0;          // group's PCM is ONE contiguous device -> host copy
     std::vector<size_t> host_pcm_off, host_pcm_bytes;
     std::vector<hipEvent_t> ev_pool;
+    hipEvent_t ev_mark[2] = {nullptr, nullptr};   // td_batch_mark
+    bool mark_set[2] = {false, false};
 };
 
 namespace tde {
