@@ -279,16 +279,16 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     # (a short timed region -- the driver's K = 20 -- carries ONE sampled step, a middle one, not K / 8 + 1: each costs ~15 us of the
     # region; the sampling counter starts at this call, so `every` = K with K // 2 untimed-warm steps' worth of offset is not
     # available -- the engine samples submissions 0, every, 2 every, ...: every = K makes it the first step of the region)
-    # A short timed region -- the driver's K = 20 -- carries NO per-launch event pair (one cost ~15 us of the 1.3 ms region):
-    # two marks on the engine's stream bracket the K submissions instead, and a family's average duration is the marked
-    # time over its launches (valid where a step is that family's launches only: the headline's one launch per step).
+    # Where a step launches ONE family only (the headline: one launch per step) the region carries no per-launch event pair --
+    # one costs ~15 us, a quarter of a step -- but two marks on the engine's stream around the K submissions; the family's
+    # average duration is the marked time over its launches.  Steps of several families (--no-fuse) keep sampled steps.
     batch.set_profiling(1)                   # (one sampled step outside the region: which families a step launches, how often)
     step()
     batch.sync()
     fam0 = batch.kernel_times()
     batch.set_profiling(0)
-    by_marks = steps < 64 and len(fam0) == 1
-    every = PROF_EVERY if steps >= 64 else (0 if by_marks else max(PROF_EVERY, steps))
+    by_marks = len(fam0) == 1
+    every = 0 if by_marks else (PROF_EVERY if steps >= 64 else max(PROF_EVERY, steps))
     batch.set_profiling(every)
     barrier()
     t0 = time.perf_counter()
