@@ -4028,41 +4028,52 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
     if (n_total > 0xFFFFFFFFull) return fail("td_batch_peak_table_device: table too large");
     if (!ensure_device(b->device)) return 0;
     if (!b->stream) TD_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-    // (the carried max of a single-pass Normalize is final once a deferred k_norm_fix has had its chance)
-    if (!b->arena.pending_fix.empty() && !settle_arena(b->arena, b->stream)) return 0;
-    if (P > b->peaks_cap) {
-        TD_HIP(hipStreamSynchronize(b->stream));
-        if (b->d_peaks) (void)hipFree(b->d_peaks);
-        b->d_peaks = nullptr;
-        b->peaks_cap = 0;
-        TD_HIP(hipMalloc(&b->d_peaks, (P + 10) * (sizeof(float) + sizeof(float*))));
-        b->peaks_cap = P + 8;
-        b->peak_src.clear();   // (the device copy of the pointer table went with the old allocation)
-    }
-    const float** d_src = reinterpret_cast<const float**>(b->d_peaks + ((b->peaks_cap + 1) & ~(size_t)1));
-    std::vector<const float*> src(P);
-    for (size_t i = 0; i < P; ++i) {
-        td_graph* g = b->graphs[i];
-        const Vertex* outv = g->output_vertex >= 0 ? &g->vertices[(size_t)g->output_vertex] : nullptr;
-        if (outv && outv->kind == K_NORMALIZE && g->dstate && !outv->has_init_override) {
-            src[i] = &g->dstate[outv->state_slot].norm.max;
-        } else {
-            src[i] = b->d_peaks + i;
-            if (g->last_out_f32 && g->last_frames)
-                launch_absmax((const float*)g->last_out_f32, (uint32_t)std::min<size_t>(g->last_frames * 2, 0xFFFFFFFFu), b->d_peaks + i, b->stream);
-            else
-                TD_HIP(hipMemsetAsync(b->d_peaks + i, 0, sizeof(float), b->stream));
+    // The table kernel goes out right behind whatever is queued -- no host wait in front of it.  The carried max of a single-pass
+    // Normalize is final only once a deferred k_norm_fix has had its chance: with one outstanding the stream is drained
+    // afterwards, and in the rare case that the check then redid a vertex the table is made again.
+    auto enqueue_table = [&]() -> int {
+        if (P > b->peaks_cap) {
+            TD_HIP(hipStreamSynchronize(b->stream));
+            if (b->d_peaks) (void)hipFree(b->d_peaks);
+            b->d_peaks = nullptr;
+            b->peaks_cap = 0;
+            TD_HIP(hipMalloc(&b->d_peaks, (P + 10) * (sizeof(float) + sizeof(float*))));
+            b->peaks_cap = P + 8;
+            b->peak_src.clear();   // (the device copy of the pointer table went with the old allocation)
         }
+        const float** d_src = reinterpret_cast<const float**>(b->d_peaks + ((b->peaks_cap + 1) & ~(size_t)1));
+        std::vector<const float*> src(P);
+        for (size_t i = 0; i < P; ++i) {
+            td_graph* g = b->graphs[i];
+            const Vertex* outv = g->output_vertex >= 0 ? &g->vertices[(size_t)g->output_vertex] : nullptr;
+            if (outv && outv->kind == K_NORMALIZE && g->dstate && !outv->has_init_override) {
+                src[i] = &g->dstate[outv->state_slot].norm.max;
+            } else {
+                src[i] = b->d_peaks + i;
+                if (g->last_out_f32 && g->last_frames)
+                    launch_absmax((const float*)g->last_out_f32, (uint32_t)std::min<size_t>(g->last_frames * 2, 0xFFFFFFFFu), b->d_peaks + i, b->stream);
+                else
+                    TD_HIP(hipMemsetAsync(b->d_peaks + i, 0, sizeof(float), b->stream));
+            }
+        }
+        // the pointer table rarely changes (carried normalize states keep their addresses from render to render): the
+        // device copy is reused, and the exchange then costs one small launch and no synchronisation
+        if (src != b->peak_src) {
+            b->peak_src = src;
+            if (P) TD_HIP(hipMemcpyAsync(d_src, b->peak_src.data(), P * sizeof(float*), hipMemcpyHostToDevice, b->stream));
+            TD_HIP(hipStreamSynchronize(b->stream));
+        }
+        if (n_total) launch_peak_table(d_src, d_table, (uint32_t)n_total, (uint32_t)P, (uint32_t)first, (uint32_t)stride, b->stream);
+        TD_HIP(hipGetLastError());
+        return 1;
+    };
+    const bool pending = !b->arena.pending_fix.empty();
+    const size_t runs0 = b->arena.fix_runs;
+    if (!enqueue_table()) return 0;
+    if (pending) {
+        if (!settle_arena(b->arena, b->stream)) return 0;
+        if (b->arena.fix_runs != runs0 && !enqueue_table()) return 0;
     }
-    // the pointer table rarely changes (carried normalize states keep their addresses from render to render): the
-    // device copy is reused, and the exchange then costs one small launch and no synchronisation
-    if (src != b->peak_src) {
-        b->peak_src = src;
-        if (P) TD_HIP(hipMemcpyAsync(d_src, b->peak_src.data(), P * sizeof(float*), hipMemcpyHostToDevice, b->stream));
-        TD_HIP(hipStreamSynchronize(b->stream));
-    }
-    if (n_total) launch_peak_table(d_src, d_table, (uint32_t)n_total, (uint32_t)P, (uint32_t)first, (uint32_t)stride, b->stream);
-    TD_HIP(hipGetLastError());
     return 1;
 }
 int td_batch_peaks(td_batch* b, float* out) {   // host copy of this batch's own entries, in td_batch_add order
