@@ -186,7 +186,7 @@ size_t td_graph_device_bytes(const td_graph* g);
  * one single-input Sum -- is a Sum / Normalize / band-pass is evaluated inside that consumer's summing kernel, as one
  * of its input terms: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
  * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
- * "band_mode" 0|1 (default 0 = exact: band_pass_gen, extensions.rs:654-689, bit-identical to the reference's serial
+ * "band_mode" 0|1|2 (default 0 = exact: band_pass_gen, extensions.rs:654-689, bit-identical to the reference's serial
  * recurrence -- the parity mode.  1 = scan: the same filter as a blocked affine scan, TOLERANCE class: another
  * realisation of the reference's own f32 rounding noise -- measured 6.3e-8 RMS through 84 band-pass vertices in a row,
  * +-1 LSB on the PCM; above 1e-6 of the output peak only where a band-pass vertex removes >= 30 dB of its input and a
@@ -195,7 +195,11 @@ size_t td_graph_device_bytes(const td_graph* g);
  * `pass` band-pass vertices linked by single-input Sum / Adsr vertices, with the Sum vertex in front and the Normalize
  * vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers reach its
  * output only as NaN once they are not finite (extensions.rs:685-687): the chain launch does not run them and tracks the
- * first non-finite right input frame instead);
+ * first non-finite right input frame instead.  2 = the scan UNDER THE GUARD -- what a State defaults to: `pass` vertices take
+ * the chain launch wherever its own estimate of its deviation can be carried to the output (any static path, at most one
+ * Normalize vertex on it; no sample loop shorter than 2 048 frames upstream), every other band-pass vertex keeps the exact
+ * kernels, and a render whose estimate is over "band_guard_ppb" x 1e-9 RMS (default 200) is rendered again with the exact
+ * kernels when the graph is drained: td_graph_band_guard_stats);
  * "one_grid_sources" 0|1 (default 1: the launches of a level that read no edge buffer -- affine Synth, wavetable voice,
  *   SampleLerp, the Adsr vertices' envelope buffers -- go out as ONE grid, each workgroup running its own family's code: same
  *   values as the separate launches, one ramp and one tail instead of up to four) /
@@ -234,6 +238,17 @@ int td_graph_set_option(td_graph* g, const char* key, long value);
  * re-checks after optimistic repairs), out[1] segments recomputed, out[2] of those cut short by a fixed point
  * under constant input. */
 int td_graph_band_stats(const td_graph* g, uint32_t out[3]);
+/* The guard of "band_mode" 2 (the scan kernels with a bound that is checked, not assumed): every render that holds scan
+ * launches ends in one small launch that adds up the launches' own estimates of how far their output lies from the
+ * reference's f32 trajectory (band_pass_gen, extensions.rs:654-689: the rounding of the smoother's state, once per frame --
+ * the one thing the scan gives up), carried to the graph's output through the gains behind them (normalize_gen's 1 / max
+ * included, extensions.rs:321-329).  An estimate over "band_guard_ppb" x 1e-9 RMS (default 200 = 2e-7; the class's bar is
+ * 1e-6) raises a word in page-locked memory; whoever drains the graph next (td_graph_sync, the read functions,
+ * td_batch_sync, a render that continues from carried state) then renders the same thing again from the state the render
+ * started in, with the exact kernels.  The banks handed to a render must therefore stay alive until the graph has been
+ * synced.  out[0] renders that carried an audit, out[1] renders done again, out[2] the last estimate (RMS, full scale 1),
+ * out[3] the largest one seen. */
+int td_graph_band_guard_stats(const td_graph* g, double out[4]);
 
 /* ---- Batch of independent projects (BASELINE config 5) ---------------------------------------
  * The reference renders one project per process: State::render's loop `for _ in 0..cs { g.render(..); write;

@@ -92,6 +92,7 @@ SIGNATURES = {
     "td_graph_device_bytes": (_sz, [_vp]),
     "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
     "td_graph_band_stats": (_i32, [_vp, C.POINTER(C.c_uint32)]),
+    "td_graph_band_guard_stats": (_i32, [_vp, C.POINTER(C.c_double)]),
     "td_batch_new": (_vp, []),
     "td_batch_free": (None, [_vp]),
     "td_batch_add": (_lng, [_vp, _vp, _vp, _vp]),
@@ -445,6 +446,12 @@ class Graph:
         out = (C.c_uint32 * 3)()
         _check(lib().td_graph_band_stats(self.h, out))
         return {"mismatched": out[0], "recomputed": out[1], "parked": out[2]}
+
+    def band_guard_stats(self):
+        """band_mode 2: renders audited, renders done again with the exact kernels, last / largest estimated RMS deviation."""
+        out = (C.c_double * 4)()
+        _check(lib().td_graph_band_guard_stats(self.h, out))
+        return {"audits": int(out[0]), "redos": int(out[1]), "last_est": out[2], "max_est": out[3]}
 
     def set_option(self, key, value):
         _check(lib().td_graph_set_option(self.h, key.encode(), int(value)))

@@ -1093,6 +1093,12 @@ static int ensure_graph_device(td_graph* g) {
         TD_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
         TD_HIP(hipMalloc(&g->d_scalar, 256));
     }
+    if (!g->guard.h_word) {   // (band_mode 2: k_band_audit's verdict lands here)
+        TD_HIP(hipHostMalloc((void**)&g->guard.h_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        g->guard.h_word[0] = 0u;
+        g->guard.h_word[1] = 0u;
+        TD_HIP(hipHostGetDevicePointer((void**)&g->guard.d_word, g->guard.h_word, 0));
+    }
     if (g->branch_streams && !g->aux[0]) {   // branch streams are made on first use (a batch of 64 graphs never needs them)
         for (int a = 0; a < td_graph::kAuxStreams; ++a) {
             TD_HIP(hipStreamCreateWithFlags(&g->aux[a], hipStreamNonBlocking));
@@ -1220,11 +1226,11 @@ static void free_arena(Arena& ar) {
     ar = Arena{};
 }
 
-enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_ENV, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT,
+enum Family { F_LOOP, F_MULTI, F_LERP, F_SINE, F_SYNTH, F_SAMPSYN, F_ENV, F_SUM, F_SCALE, F_NORMFIX, F_ADSR, F_BAND, F_BAND_SPEC, F_BAND_FIX, F_BAND_FILL, F_BAND_SCAN, F_QUANT, F_AUDIT,
               F_SOURCES /* (no descriptors of its own: several of the families above as ONE grid, submit_chunk) */, F_COUNT };
 static const char* kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
                                            "k_synth",       "k_sampsyn", "k_adsr_env", "k_sum",          "k_scale",       "k_norm_fix",
-                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise", "k_sources"};
+                                           "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise", "k_band_audit", "k_sources"};
 
 static hipEvent_t get_event(ProfCtx& pc) {
     if (!pc.free_ev.empty()) {
@@ -1558,12 +1564,76 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     std::map<size_t, ScanPlan> scan_plan;                        // band-pass vertices that take k_band_scan
     std::map<size_t, std::vector<size_t>> chain_of;              // last vertex of a launch -> its vertices, first to last
     std::map<size_t, std::vector<ChainLink>> links_before;       // band-pass vertex -> the links between its predecessor and it
-    if (g->band_mode == 1) {
+    const bool scan_on = g->band_mode >= 1;
+    // ---- the guard (band_mode 2, engine.h tde::Guard): a band-pass vertex takes the scan only where the launch's own estimate
+    // of its deviation can be carried to the graph's output -- `down[u]`: the static gain from vertex u's output to the
+    // graph's (pan / gain of everything downstream, largest channel; several paths add up; an Adsr vertex on the way at the
+    // largest gain its conf and its events' velocities allow) and the ONE Normalize vertex every path runs through, if any
+    // (its 1 / max is read from its peak table by k_band_audit); anything else -- two Normalize vertices in a row, paths that
+    // differ in it -- keeps the exact kernels.  So does a vertex downstream of a sample loop shorter than 2 048 frames:
+    // a period shorter than the smoother's memory repeats its rounding pattern, the offsets add up coherently and no
+    // level-based estimate bounds them (DESIGN.md 3e "The guard").
+    const bool guard_on = g->band_mode == 2 && !g->guard.in_redo && g->band_chain;
+    struct PathGain { double g; long norm; };   // norm: -1 none, >= 0 that Normalize vertex, -2 not analysable
+    std::vector<PathGain> down;
+    std::vector<char> short_up;
+    auto own_gain = [](const Vertex& v) {
+        const PanGain pg = make_pg(v.gain, v.angle);
+        double a = 1.0;
+        if (pg.flags & 1u) a *= std::max(fabs((double)pg.l_amp), fabs((double)pg.r_amp));
+        if (pg.flags & 2u) a *= fabs((double)pg.gain);
+        return a;
+    };
+    if (guard_on) {
+        down.assign(nv, PathGain{0.0, -1});
+        short_up.assign(nv, 0);
+        for (size_t vi : g->order) {   // inputs first
+            const Vertex& v = g->vertices[vi];
+            char su = (v.kind == K_SAMPLE_LOOP && v.sample_index < sb->samples.size() && sb->samples[v.sample_index].len < 2048) ? 1 : 0;
+            for (size_t u : g->edges[vi]) su = su || short_up[u];
+            short_up[vi] = su;
+        }
+        for (size_t k = g->order.size(); k-- > 0;) {   // consumers first
+            const size_t u = g->order[k];
+            if ((long)u == g->output_vertex) { down[u] = PathGain{1.0, -1}; continue; }
+            double sum = 0.0;
+            long nz = -1;
+            bool first = true;
+            for (size_t w : cons[u]) {   // (a duplicate edge is listed twice: the term is summed twice)
+                const Vertex& wv = g->vertices[w];
+                long through = down[w].norm;
+                if (through == -2) { nz = -2; break; }
+                double L = own_gain(wv);
+                if (wv.kind == K_ADSR && !(wv.wet < 0.0001f)) {   // |lerp(1, level x vel, wet)| <= max(1, |level| |vel|)
+                    const AdsrConfD& c = wv.conf;
+                    double lv = std::max(std::max(fabs((double)c.std_vel), fabs((double)c.attack_vel)),
+                                         std::max(std::max(fabs((double)c.decay_vel), fabs((double)c.sustain_vel)), fabs((double)c.release_vel)));
+                    double mv = 0.0;
+                    for (const td_event& e : floww_of(fb, wv.floww_index)) mv = std::max(mv, fabs((double)e.vel));
+                    L *= std::max(1.0, lv * mv);
+                }
+                if (wv.kind == K_NORMALIZE) {
+                    if (through != -1) { nz = -2; break; }
+                    through = (long)w;
+                }
+                if (first) { nz = through; first = false; }
+                else if (nz != through) { nz = -2; break; }
+                sum += L * down[w].g;
+            }
+            if (!(sum == sum) || std::isinf(sum)) nz = -2;
+            down[u] = PathGain{sum, nz};
+        }
+    }
+    auto guard_ok = [&](size_t vi, const ScanPlan& sp) {
+        return g->vertices[vi].pass && sp.Kw != 0u && down[vi].norm != -2 && !short_up[vi];
+    };
+    if (scan_on) {
         for (size_t vi : g->order) {
             const Vertex& v = g->vertices[vi];
             if (v.kind != K_BAND_PASS || v.wet < 0.0001f || (v.lgamma == 0.0f && v.hgamma == 0.0f)) continue;
+            if (g->band_mode == 2 && !guard_on) continue;   // (the redo of a guarded render, or chains switched off: exact kernels)
             ScanPlan sp;
-            if (plan_band_scan(g, v, M, &sp)) scan_plan[vi] = sp;
+            if (plan_band_scan(g, v, M, &sp) && (!guard_on || guard_ok(vi, sp))) scan_plan[vi] = sp;
         }
         std::map<size_t, size_t> prev_of, next_of;
         if (g->fuse_sources && g->band_chain)
@@ -1613,7 +1683,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     }
     // ---- a `pass` band-pass vertex that is in no chain takes the chain kernel too, as a chain of one: that kernel keeps a
     // non-finite state non-finite for the rest of the chunk (BandScanDesc::poison), and can take the vertices on either side in
-    if (g->band_mode == 1 && g->band_chain)
+    if (scan_on && g->band_chain)
         for (auto& kv : scan_plan)
             if (inlined[kv.first] != 5 && !chain_of.count(kv.first) && g->vertices[kv.first].pass && kv.second.Kw)
                 chain_of[kv.first] = std::vector<size_t>{kv.first};
@@ -1624,7 +1694,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     std::map<size_t, size_t> norm_of;                           // scan launch vertex -> the Normalize vertex it evaluates
     std::map<size_t, size_t> fused_norm;                        // ... and back
     std::map<size_t, std::vector<ChainLink>> links_after;       // scan launch vertex -> the links between it and that Normalize vertex
-    if (g->band_mode == 1 && g->band_chain && g->fuse_sources && g->fuse_normalize && g->spec_normalize && g->single_pass_normalize && !is_scan &&
+    if (scan_on && g->band_chain && g->fuse_sources && g->fuse_normalize && g->spec_normalize && g->single_pass_normalize && !is_scan &&
         bl == (size_t)kTileFrames && M < ((size_t)1 << 31)) {
         for (auto& kv : scan_plan) {
             const size_t L = kv.first;
@@ -1655,7 +1725,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     // that launch's input phase (its terms summed, its pan / gain applied: BandScanDesc::pre) instead of a launch of its own
     std::map<size_t, size_t> presum_of;   // first vertex of a chain launch -> that Sum vertex
     std::map<size_t, size_t> presum_stage;   // ... -> the gain / pan stage between the two, if any (only meaningful with presum_of)
-    if (g->band_mode == 1 && g->fuse_sources && g->band_chain && g->fuse_normalize)
+    if (scan_on && g->fuse_sources && g->band_chain && g->fuse_normalize)
         for (auto& kv : chain_of) {
             const size_t first = kv.second[0], last = kv.first;
             if (g->edges[first].size() != 1) continue;
@@ -1746,6 +1816,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     auto scratch_field = [&](size_t desc_off, size_t field_off, size_t s_off) { cb.scratch_fix.push_back({desc_off + field_off, s_off}); };
 
     const bool peaks_need_zero = !(bl == (size_t)kTileFrames);
+    // the guard's bookkeeping (band_mode 2): where every Normalize vertex of the chunk keeps its peak table and carried max,
+    // and what every guarded scan launch leaves for k_band_audit
+    std::map<size_t, std::pair<size_t, size_t>> audit_norm;   // Normalize vertex -> scratch offsets (peaks, init snapshot)
+    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; };   // from: the vertex whose output the estimate stands at
+    std::vector<AuditSrc> audit_src;
 
     for (int lv = 0; lv < g->n_levels; ++lv) {
         std::vector<size_t> fam_v[F_COUNT];
@@ -2114,6 +2189,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         if (g->vertices[vs[i]].kind == K_NORMALIZE) {
                             const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
                             norm_scratch[vs[i]] = {pk, ic};
+                            audit_norm[vs[i]] = {pk, ic};
                             sum_desc_of[vs[i]] = d[i];
                             if (d[i].mode >= 4u) {   // one granule per workgroup (at most one per block)
                                 cb.esync_fix.push_back({o + offsetof(SumDesc, sync), cb.esync_bytes});
@@ -2343,6 +2419,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 }
                                 sp.pk_off = ik->second;
                             }
+                            double link_gain = own_gain(v);
                             if (i + 1 < piece.size() || norm_of.count(vi)) {   // the links to the next vertex of the chain / to the Normalize vertex
                                 const std::vector<ChainLink>& links = i + 1 < piece.size() ? links_before[piece[i + 1]] : links_after[vi];
                                 x.n_post = (uint32_t)links.size();
@@ -2350,7 +2427,18 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                     const Vertex& lv2 = g->vertices[links[l].vertex];
                                     x.post[l].env = links[l].adsr ? env_of[links[l].vertex] : nullptr;
                                     x.post[l].pg = make_pg(lv2.gain, lv2.angle);
+                                    link_gain *= own_gain(lv2);
                                 }
+                            }
+                            if (guard_on) {   // (kernels.h BandStageDesc::nzv ..: DESIGN.md 3e "The guard")
+                                const double K0 = 2.53e-8 * 2.53e-8;   // variance of one rounding of a state of unit level: E[ulp^2] / 12 over a binade
+                                const float gm[2] = {v.lgamma, v.hgamma};
+                                for (int c = 0; c < 2; ++c) {
+                                    const double gmc = (double)gm[c];
+                                    x.nzv[c] = gm[c] == 0.0f ? 0.0f : (float)(0.25 * K0 / (gmc * (2.0 - gmc)));
+                                    x.nzs[c] = gm[c] == 0.0f ? 0.0f : (float)(0.5 * ldexp(1.0, -24) / gmc);
+                                }
+                                x.nzg = (float)link_gain;
                             }
                             sd.push_back(x);
                         }
@@ -2378,7 +2466,12 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         x.term_mode = term_mode[piece[0]];
                         x.n_tiles = sp0.n_tiles;
                         x.flags = (uint32_t)g->band_scan_debug;
+                        x.nz_end = norm_of.count(vi) ? (float)own_gain(g->vertices[norm_of[vi]]) : 1.0f;
                         d.push_back(x);
+                        if (guard_on) {
+                            const uint32_t n_wt = (uint32_t)((M + (size_t)kTileFrames - 1) / (size_t)kTileFrames);
+                            audit_src.push_back({scratch((size_t)n_wt * sizeof(float)), n_wt, norm_of.count(vi) ? norm_of[vi] : vi, norm_of.count(vi) != 0});
+                        }
                         if (norm_of.count(vi)) {   // the Normalize vertex behind the launch: its descriptor as k_norm1 would get it (mode 5)
                             const size_t ni = norm_of[vi];
                             Vertex& nv = g->vertices[ni];
@@ -2402,6 +2495,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             const size_t pk = scratch(nb * sizeof(float)), ic = scratch(2 * sizeof(float));
                             scratch_field(no, offsetof(SumDesc, peaks), pk);
                             scratch_field(no, offsetof(SumDesc, init_copy), ic);
+                            audit_norm[ni] = {pk, ic};
                             if (peaks_need_zero) cb.zero.push_back({pk, nb * sizeof(float)});
                             cb.sync_fix.push_back({no + offsetof(SumDesc, sync), cb.sync_bytes});   // one granule per tile
                             cb.sync_bytes += ((size_t)sp0.n_tiles * 8 + 63) & ~(size_t)63;
@@ -2415,6 +2509,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         ptr_field(o, offsetof(BandScanDesc, ins), ins_off[first_of(vs[i])]);
                         ptr_field(o, offsetof(BandScanDesc, stages), stages_off[i]);
                         if (norm_desc_off[i] != (size_t)-1) ptr_field(o, offsetof(BandScanDesc, norm), norm_desc_off[i]);
+                        if (guard_on) scratch_field(o, offsetof(BandScanDesc, noise), audit_src[audit_src.size() - vs.size() + i].noise_off);
                         cb.sync_fix.push_back({o + offsetof(BandScanDesc, ticket), cb.sync_bytes});   // {tile counter, "states read"}
                         cb.sync_bytes += 64;
                         {   // one granule per tile: the stage it went non-finite at; and the frame its right input did (k_band_chain)
@@ -2429,7 +2524,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         size_t e2 = b;
                         while (e2 < vs.size() && launch_key(vs[e2]) == launch_key(vs[b])) ++e2;
                         add_launch(fam, off + b * sizeof(BandScanDesc), (int)(e2 - b),
-                                   launch_key(vs[b]) | ((uint32_t)scan_plan[first_of(vs[b])].nf << 8), lv);
+                                   launch_key(vs[b]) | ((uint32_t)scan_plan[first_of(vs[b])].nf << 8) | (guard_on ? 0x20000u : 0u), lv);
                         b = e2;
                     }
                     continue;
@@ -2474,6 +2569,40 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         std::vector<QuantDesc> d{{g->vbuf[(size_t)g->output_vertex], pcm_dst, amplitude, (uint32_t)qmode}};
         add_launch(F_QUANT, st.put(d), 1, 0u, g->n_levels);
     }
+    // the guard's verdict on this chunk: one workgroup adds up what the guarded scan launches estimated (k_band_audit)
+    if (guard_on && !audit_src.empty()) {
+        std::vector<AuditDesc> ad;
+        for (const AuditSrc& a : audit_src) {
+            AuditDesc x{};
+            x.n_wt = a.n_wt;
+            x.nb = (uint32_t)nb;
+            x.bl = (uint32_t)bl;
+            x.gain = (float)down[a.from].g;
+            ad.push_back(x);
+        }
+        const size_t ao = st.put(ad);
+        for (size_t i = 0; i < audit_src.size(); ++i) {
+            const size_t o = ao + i * sizeof(AuditDesc);
+            scratch_field(o, offsetof(AuditDesc, noise), audit_src[i].noise_off);
+            const long nz = audit_src[i].fused ? -1 : down[audit_src[i].from].norm;   // (a fused Normalize vertex: 1 / max already applied by the launch)
+            if (nz >= 0) {
+                const auto it = audit_norm.find((size_t)nz);
+                if (it == audit_norm.end()) return fail("termdaw_amd: internal: the guard lost a Normalize vertex");
+                scratch_field(o, offsetof(AuditDesc, peaks), it->second.first);
+                // (a scan pass measures against scan_max, graph.rs:222-237: what matters there is the recorded peak's relative error)
+                scratch_field(o, offsetof(AuditDesc, init_copy), it->second.second + (is_scan ? sizeof(float) : 0));
+            }
+        }
+        AuditHead hd{};
+        hd.n = (uint32_t)audit_src.size();
+        hd.frames = (uint32_t)M;
+        const double thr = (double)g->band_guard_ppb * 1e-9;
+        hd.thr2 = (float)(thr * thr);
+        hd.host_word = g->guard.d_word;
+        const size_t ho = st.put(std::vector<AuditHead>{hd});
+        ptr_field(ho, offsetof(AuditHead, descs), ao);
+        add_launch(F_AUDIT, ho, 1, 0u, g->n_levels + 1);
+    }
     const auto tp2 = std::chrono::steady_clock::now();
     g->host_ms[0] += ms_between(tp0, tp1);   // event compile
     g->host_ms[1] += ms_between(tp1, tp2);   // descriptors
@@ -2500,6 +2629,7 @@ static size_t desc_size(int fam) {
         case F_BAND_FILL: return sizeof(BandSpecDesc);
         case F_BAND_SCAN: return sizeof(BandScanDesc);
         case F_QUANT: return sizeof(QuantDesc);
+        case F_AUDIT: return sizeof(AuditHead);
         default: return 0;
     }
 }
@@ -2778,10 +2908,11 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_BAND_FIX: launch_band_fix((const BandSpecDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_BAND_FILL: break;
                 case F_BAND_SCAN:
-                    if (L.aux & 0x10000u) launch_band_chain((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, s);
+                    if (L.aux & 0x10000u) launch_band_chain((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, (L.aux & 0x20000u) != 0u, s);
                     else launch_band_scan((const BandScanDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)((L.aux >> 8) & 0xFFu), s);
                     break;
                 case F_QUANT: launch_quantise((const QuantDesc*)d, L.n, L.M, s); break;
+                case F_AUDIT: launch_band_audit((const AuditHead*)d, L.n, s); break;
             }
         }
         if (fork) {
@@ -2908,16 +3039,90 @@ static void finish_render(td_graph* g, const RenderPlan& rp) {
 
 // Everything queued for the graph has completed AND a deferred k_norm_fix has run if one was called for (settle_arena): the
 // point from which results -- PCM, f32 frames, carried Normalize state -- may be read.
+static int guard_settle(td_graph* g);
+static int graph_set_time_impl(td_graph* g, size_t time);
 static int drain(td_graph* g) {
     if (!g->stream) return 1;
     if (!ensure_device(g->device)) return 0;
     if (!settle_arena(g->arena, g->stream)) return 0;
     if (g->batch && g->batch->stream && !settle_arena(g->batch->arena, g->batch->stream)) return 0;
-    return 1;
+    return guard_settle(g);
 }
 // A render whose output Normalize vertex continues from its carried max needs the previous render's deferred fix settled
 // first (a render that starts from reset_normalization does not read it: back-to-back fresh renders never wait here).
+// ---- the guard (band_mode 2): engine.h tde::Guard
+// Does the render about to start read any carried device state?  Not if every reachable vertex with a state slot starts
+// afresh: a Normalize vertex with reset_normalization pending, a band-pass vertex with set_time pending.
+static bool starts_afresh(const td_graph* g) {
+    for (size_t vi : g->order) {
+        const Vertex& v = g->vertices[vi];
+        if (v.kind == K_NORMALIZE && !v.has_init_override) return false;
+        if (v.kind == K_BAND_PASS && v.state_slot >= 0 && !v.first_pending) return false;
+    }
+    return true;
+}
+static bool has_reachable_band(const td_graph* g) {
+    for (size_t vi : g->order)
+        if (g->vertices[vi].kind == K_BAND_PASS) return true;
+    return false;
+}
+// In front of a render that may carry an audit: what it takes to do the render again (called once the plan and the state
+// slots are in place, before the first chunk compiles).
+static int guard_begin(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan, int bits,
+                       bool advance, size_t scan_t0, bool want_pcm) {
+    Guard& q = g->guard;
+    q.sb = sb; q.fb = fb; q.n_blocks = n_blocks; q.is_scan = is_scan; q.bits = bits; q.advance = advance; q.scan_t0 = scan_t0;
+    q.want_pcm = want_pcm;
+    q.post = 0;
+    q.snap.take(g, fb);
+    q.have_backup = false;
+    if (!starts_afresh(g) && g->dstate && !g->hstate.empty()) {
+        const size_t n = g->hstate.size();
+        if (n > q.backup_cap) {
+            if (q.d_backup) (void)hipFree(q.d_backup);
+            q.d_backup = nullptr;
+            q.backup_cap = 0;
+            TD_HIP(hipMalloc(&q.d_backup, n * 2 * sizeof(StateSlot)));
+            q.backup_cap = n * 2;
+        }
+        TD_HIP(hipMemcpyAsync(q.d_backup, g->dstate, n * sizeof(StateSlot), hipMemcpyDeviceToDevice, g->stream));
+        q.have_backup = true;
+    }
+    return 1;
+}
+// The stream has drained: look at the verdict of the last guarded render, and do that render again with the exact kernels
+// if its estimate was over the bound.
+static int guard_settle(td_graph* g) {
+    Guard& q = g->guard;
+    if (!q.armed || q.in_redo || !q.h_word) return 1;
+    q.armed = false;
+    const uint32_t raised = *(volatile uint32_t*)q.h_word;
+    const uint32_t bits = *(volatile uint32_t*)(q.h_word + 1);
+    memcpy(&q.last_est, &bits, 4);
+    if (q.last_est > q.max_est || !(q.last_est == q.last_est)) q.max_est = q.last_est;
+    if (!raised) return 1;
+    *(volatile uint32_t*)q.h_word = 0u;
+    q.in_redo = true;
+    const int mode = g->band_mode;
+    g->band_mode = 0;
+    q.snap.put(g, q.fb);
+    int ok = 1;
+    if (q.have_backup && hipMemcpyAsync(g->dstate, q.d_backup, g->hstate.size() * sizeof(StateSlot), hipMemcpyDeviceToDevice, g->stream) != hipSuccess)
+        ok = fail("HIP error: the guard could not restore the carried state");
+    g->state_dev_dirty = true;
+    if (ok) ok = graph_render_chunks(g, q.sb, q.fb, q.n_blocks, q.is_scan, q.bits, q.advance, q.scan_t0, q.want_pcm);
+    if (ok && q.post == 1) ok = graph_set_time_impl(g, 0);
+    if (ok && q.post == 2) { q.fb->frame = q.snap.fb_frame; q.fb->start_indices = q.snap.fb_start; }
+    g->band_mode = mode;
+    q.in_redo = false;
+    q.redos += 1;
+    if (!ok) return 0;
+    return settle_arena(g->arena, g->stream);   // (the second render's own deferred check, and its completion)
+}
+
 static int settle_before_render(td_graph* g) {
+    // (a guarded render's verdict is still out and this render continues from the state it left: settle it first)
+    if (g->guard.armed && !g->guard.in_redo && !(g->plan_dirty ? false : starts_afresh(g)) && !drain(g)) return 0;
     const bool pending = !g->arena.pending_fix.empty() || (g->batch && !g->batch->arena.pending_fix.empty());
     if (!pending || g->output_vertex < 0) return 1;
     const Vertex& ov = g->vertices[(size_t)g->output_vertex];
@@ -2967,6 +3172,9 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
     if (!settle_before_render(g)) return 0;
     if (!prepare_render(g, n_blocks, bits, want_pcm, &rp)) return 0;
     g->defer_fix = !rp.multi;   // (a later chunk reads the carried max; the f32 copy of a multi-chunk render reads the frames)
+    const bool guarded = g->band_mode == 2 && !g->guard.in_redo && has_reachable_band(g);
+    if (guarded && !guard_begin(g, sb, fb, n_blocks, is_scan, bits, advance_graph_time, scan_t0, want_pcm)) return 0;
+    bool audited = false;
     ChunkBuild& cb = g->build;
     cb.st = &g->staging;
     // (a graph that belongs to a batch may still render alone: it then uses its own arena on the shared stream)
@@ -2979,6 +3187,8 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
             g->snapshot.put(g, fb);
             return 0;
         }
+        if (guarded && !audited)
+            for (const Launch& L : cb.launches) audited = audited || L.fam == F_AUDIT;
         const uint8_t* scratch_base = nullptr;
         if (!submit_chunk(g->arena, cb, g->stream, g->prof, g, &scratch_base, &g->host_ms[2])) {
             g->snapshot.put(g, fb);
@@ -2989,6 +3199,7 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
         done += nb;
     }
     finish_render(g, rp);
+    if (audited) { g->guard.armed = true; g->guard.audits += 1; }
     return 1;
 }
 
@@ -3034,6 +3245,8 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
         if (!settle_before_render(g)) return 0;
         if (!prepare_render(g, n_blocks, bits, want_pcm, &rp[i])) return 0;
         g->defer_fix = allow_defer && !rp[i].multi;
+        if (g->band_mode == 2 && !g->guard.in_redo && has_reachable_band(g) &&
+            !guard_begin(g, b->sbs[lo + i], b->fbs[lo + i], n_blocks, is_scan, bits, advance_graph_time, 0, want_pcm)) return 0;
     }
     ChunkBuild& cb = b->build;
     cb.st = &b->staging;
@@ -3054,10 +3267,13 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
         for (size_t i = 0; i < P; ++i) {
             if (!nb[i]) continue;
             any = true;
+            const size_t l0 = cb.launches.size();
             if (!compile_next_chunk(b->graphs[lo + i], b->sbs[lo + i], b->fbs[lo + i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
                 roll_back();
                 return 0;
             }
+            for (size_t q = l0; q < cb.launches.size(); ++q)   // (this project's chunk carries an audit: its verdict is looked at when the batch is settled)
+                if (cb.launches[q].fam == F_AUDIT && !b->graphs[lo + i]->guard.armed) { b->graphs[lo + i]->guard.armed = true; b->graphs[lo + i]->guard.audits += 1; }
         }
         if (!any) break;
         const uint8_t* scratch_base = nullptr;
@@ -3236,6 +3452,7 @@ static void free_prof(ProfCtx& pc) {
 void td_graph_free(td_graph* g) {
     if (!g) return;
     // (a deferred k_norm_fix -- the graph's own arena's or its batch's -- holds pointers into this graph's state: settled first)
+    g->guard.armed = false;   // (nobody will read a render of this graph again: its verdict is dropped, not acted on)
     if (g->stream && hipSetDevice(g->device) == hipSuccess) (void)drain(g);
     if (g->batch) {   // leave the batch first: it must not keep a dangling handle
         td_batch* b = g->batch;
@@ -3261,6 +3478,8 @@ void td_graph_free(td_graph* g) {
         if (g->d_out_f32) (void)hipFree(g->d_out_f32);
         if (g->d_resampled) (void)hipFree(g->d_resampled);
         if (g->d_scalar) (void)hipFree(g->d_scalar);
+        if (g->guard.d_backup) (void)hipFree(g->guard.d_backup);
+        if (g->guard.h_word) (void)hipHostFree(g->guard.h_word);
         free_prof(g->prof);
         if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
         for (int a = 0; a < td_graph::kAuxStreams; ++a)
@@ -3274,6 +3493,7 @@ void td_graph_free(td_graph* g) {
     delete g;
 }
 void td_graph_reset(td_graph* g) {
+    g->guard.armed = false;   // (the vertices a pending verdict is about are going)
     if ((g->stream || !g->wavetables.empty()) && hipSetDevice(g->device) == hipSuccess) {
         if (g->stream) (void)drain(g);   // (a deferred k_norm_fix belongs to the vertices about to go)
         for (float* p : g->wavetables) (void)hipFree(p);
@@ -3521,6 +3741,7 @@ int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb
     const int ok = graph_render_chunks(g, sb, fb, 1, false, 16, true, 0, false);
     fb->frame = frame;
     fb->start_indices = starts;
+    g->guard.post = 2;   // (a guarded block that is done again leaves the cursor where this call found it, too)
     if (!ok) return -1;
     std::vector<float2> tmp(g->bl);
     if (!drain(g)) return -1;
@@ -3564,6 +3785,7 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
     if (g->output_vertex < 0) return 1;
     if (!scan_begin(g, fb)) return 0;
     if (!graph_render_chunks(g, sb, fb, chunks, true, 16, false, 0, false)) return 0;
+    if (g->guard.armed && !drain(g)) return 0;   // (band_mode 2: a dry run over the bound is done again BEFORE its peaks are applied)
     if (!scan_end(g, fb)) return 0;
     return drain(g);
 }
@@ -3571,6 +3793,7 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
 size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits) {
     if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, true)) return 0;
     if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
+    g->guard.post = 1;
     return n_blocks * g->bl;
 }
 int td_graph_sync(td_graph* g) { return drain(g); }
@@ -3591,6 +3814,7 @@ size_t td_graph_render_all_resampled(td_graph* g, const td_samplebank* sb, td_fl
     }
     if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, false)) return 0;
     if (!graph_set_time_impl(g, 0)) return 0;
+    g->guard.post = 1;
     if (!drain(g)) return 0;   // (the resampler reads the output vertex' frames)
     const size_t total = n_blocks * g->bl;
     float2* rs = nullptr;
@@ -3699,6 +3923,13 @@ size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float*
 }
 size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes + g->arena.device_bytes; }
 
+int td_graph_band_guard_stats(const td_graph* g, double out[4]) {
+    out[0] = (double)g->guard.audits;
+    out[1] = (double)g->guard.redos;
+    out[2] = (double)g->guard.last_est;
+    out[3] = (double)g->guard.max_est;
+    return 1;
+}
 int td_graph_band_stats(const td_graph* gc, uint32_t out[3]) {
     td_graph* g = const_cast<td_graph*>(gc);
     out[0] = out[1] = out[2] = 0;
@@ -3717,11 +3948,13 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
     if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
     if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
-    if (k == "band_mode") {   // 0: exact (default, the parity mode), 1: blocked affine scan (tolerance class)
-        if (value != 0 && value != 1) return fail("band_mode must be 0 (exact) or 1 (scan)");
+    if (k == "band_mode") {   // 0: exact (default, the parity mode), 1: blocked affine scan (tolerance class), 2: the scan under the guard
+        if (value != 0 && value != 1 && value != 2) return fail("band_mode must be 0 (exact), 1 (scan) or 2 (guarded scan)");
+        if (g->guard.armed && !drain(g)) return 0;   // (a verdict still out belongs to the mode it was rendered in)
         g->band_mode = (int)value;
         return 1;
     }
+    if (k == "band_guard_ppb") { g->band_guard_ppb = value > 0 ? (unsigned)std::min<long>(value, 1000000000L) : 0u; return 1; }
     if (k == "band_scan_nf") {
         if (value != 8 && value != 16) return fail("band_scan_nf must be 8 or 16");
         g->band_scan_nf = (int)value;
@@ -3826,14 +4059,19 @@ void td_batch_rewind(td_batch* b) {
 }
 size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits) {
     if (!batch_render_chunks(b, n_blocks, false, bits, true, true)) return 0;
-    for (td_graph* g : b->graphs)
+    for (td_graph* g : b->graphs) {
         if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
+        g->guard.post = 1;
+    }
     return b->graphs.empty() ? 0 : n_blocks * b->graphs[0]->bl;
 }
 int td_batch_sync(td_batch* b) {
     if (!b->stream) return 1;
     if (!ensure_device(b->device)) return 0;
-    return settle_arena(b->arena, b->stream);
+    if (!settle_arena(b->arena, b->stream)) return 0;
+    for (td_graph* g : b->graphs)   // (band_mode 2: a project whose estimate was over the bound renders again, alone, exact)
+        if (g->guard.armed && !guard_settle(g)) return 0;
+    return 1;
 }
 size_t td_batch_render_all(td_batch* b, size_t n_blocks, int bits) {
     const size_t n = td_batch_render_all_async(b, n_blocks, bits);
@@ -3959,7 +4197,18 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
     for (size_t gi = 0; gi < n_groups && ok; ++gi) {
         const size_t lo = gi * G, hi = std::min(P, lo + G);
         ok = batch_render_range(b, lo, hi, n_blocks, false, bits, true, true, false);
-        for (size_t i = lo; i < hi && ok; ++i) ok = graph_set_time_impl(b->graphs[i], 0);   // state.rs:575
+        for (size_t i = lo; i < hi && ok; ++i) {
+            ok = graph_set_time_impl(b->graphs[i], 0);   // state.rs:575
+            b->graphs[i]->guard.post = 1;
+        }
+        {   // (band_mode 2: a group with guarded projects is settled -- verdicts looked at, a project over the bound done again -- before its PCM leaves)
+            bool any_armed = false;
+            for (size_t i = lo; i < hi; ++i) any_armed = any_armed || b->graphs[i]->guard.armed;
+            if (ok && any_armed) {
+                ok = settle_arena(b->arena, b->stream);
+                for (size_t i = lo; i < hi && ok; ++i) ok = guard_settle(b->graphs[i]);
+            }
+        }
         if (!ok) break;
         const size_t bytes = b->host_pcm_off[hi - 1] + b->host_pcm_bytes[hi - 1] - b->host_pcm_off[lo];
         if (hipEventRecord(ev_group[gi], b->stream) != hipSuccess || hipStreamWaitEvent(b->copy_stream, ev_group[gi], 0) != hipSuccess ||
@@ -4014,6 +4263,11 @@ int td_batch_normalize_scan(td_batch* b, size_t chunks) {   // State::scan_exact
         if (!scan_begin(b->graphs[i], b->fbs[i])) return 0;
     }
     if (!batch_render_chunks(b, chunks, true, 16, false, false)) return 0;
+    {
+        bool any_armed = false;
+        for (td_graph* g : b->graphs) any_armed = any_armed || g->guard.armed;
+        if (any_armed && !td_batch_sync(b)) return 0;   // (a dry run over the bound is done again before its peaks are applied)
+    }
     for (size_t i = 0; i < b->graphs.size(); ++i)
         if (!scan_end(b->graphs[i], b->fbs[i])) return 0;
     return td_batch_sync(b);

@@ -287,6 +287,7 @@ struct ChunkBuild {
 struct td_batch;
 struct td_graph;
 
+
 namespace tde {
 // What compiling a chunk changes on the host side of a project (engine.cpp): taken before a step, put back if it fails.
 struct HostSnapshot {
@@ -296,6 +297,33 @@ struct HostSnapshot {
     std::vector<V> v;
     void take(const td_graph* g, const td_flowwbank* fb);
     void put(td_graph* g, td_flowwbank* fb) const;
+};
+// band_mode 2.  A render that holds guarded scan launches (k_band_chain<.., true>) ends in k_band_audit, which leaves its
+// estimate of the render's RMS deviation from the reference in word[1] and raises word[0] when it is over the bound.  The
+// words are looked at when the graph is drained (td_graph_sync, the read functions, td_batch_sync, or the next render that
+// continues from carried state): a raised word means the render is done again, from the state it started in, with the
+// exact kernels.  What "the state it started in" takes: the host side in `snap` (taken before the first chunk compiles);
+// the device side -- the carried Normalize / band-pass slots -- in `d_backup`, copied on the stream in front of the
+// render unless every reachable vertex with a slot starts afresh anyway (reset_normalization / set_time pending: the
+// pipelined fresh renders of the bench loops pay nothing).
+struct Guard {
+    uint32_t* h_word = nullptr;      // page-locked host memory: [0] over the bound, [1] estimate (f32 bits)
+    uint32_t* d_word = nullptr;      // ... its device address
+    bool armed = false;              // the last render carried an audit; its verdict has not been looked at
+    bool in_redo = false;
+    // the render to do again
+    const td_samplebank* sb = nullptr;
+    td_flowwbank* fb = nullptr;
+    size_t n_blocks = 0, scan_t0 = 0;
+    bool is_scan = false, advance = false, want_pcm = false;
+    int bits = 16;
+    int post = 0;                    // what the caller did behind the render: 1 set_time(0) (state.rs:575), 2 put the FlowwBank cursor back (block pull)
+    HostSnapshot snap;
+    bool have_backup = false;
+    void* d_backup = nullptr;        // StateSlot[backup_cap]
+    size_t backup_cap = 0;
+    size_t redos = 0, audits = 0;    // renders done again / renders that carried an audit
+    float last_est = 0.0f, max_est = 0.0f;
 };
 }  // namespace tde
 
@@ -367,7 +395,12 @@ struct td_graph {
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
     int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
-                                               //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex)
+                                               //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex),
+                                               // 2: the scan under the guard (tde::Guard below): every render estimates its own
+                                               //    deviation from the reference and is rendered again with the exact kernels when
+                                               //    the estimate is over `band_guard_ppb` -- the front-end's default
+    unsigned band_guard_ppb = 200;             // band_mode 2: bound on the estimated RMS deviation, in 1e-9 of full scale (0: every guarded render is redone)
+    tde::Guard guard;
     bool band_chain = true;                    // scan mode: a chain of band-pass vertices (linked by stages / Adsr vertices) is ONE launch
     int band_scan_nf = 16;                     // frames per lane of k_band_scan (8 | 16): tile = 256 x that
     int band_scan_debug = 0;                   // (tests) bit 0: every k_band_scan poll times out: predecessors are recomputed

@@ -382,6 +382,14 @@ struct BandStageDesc {          // one band-pass vertex
     float pn[16][2];            // (1 - gamma)^(n + 1), n = 0 .. NF - 1, {low, high} smoother: what an entry state still weighs after n + 1 frames
     const double* pk;           // [2][kScanMaxK]: (1 - gamma)^(NF * 256 * j): the weight of the tile j + 1 tiles back
     uint32_t Kw, pad3;          // (= K)
+    // k_band_chain, guarded form (engine option "band_mode" 2, BandScanDesc::noise): what this vertex adds to the launch's
+    // estimate of its own deviation from the reference's f32 trajectory (DESIGN.md 3e "The guard"), {low, high} smoother --
+    // nzv: 0.25 K0 / (gamma (2 - gamma)), the variance a unit-level state picks up from independent roundings of the
+    // recurrence's sum, seen through the 0.5 of `cut`; nzs: 0.5 * 2^-24 / gamma, the offset at which an f32 state of unit
+    // level parks short of a (nearly) constant input; nzg: the static gain between this vertex' recurrence and the next
+    // stage's input (its own pan / gain and the links', largest channel amplitude; envelope links multiply in per lane)
+    float nzv[2], nzs[2];
+    float nzg, pad4;
 };
 struct BandScanDesc {
     const InTerm* ins;          // the (first) vertex' input terms, in connect() order
@@ -410,10 +418,36 @@ struct BandScanDesc {
     // run, reach the output in exactly one way -- once non-finite (an infinite or NaN right input frame makes them so, for
     // good) they turn it NaN.  Every tile publishes this at its start and reads all earlier tiles' at its end.
     unsigned long long* rpoison;
+    // k_band_chain, guarded form: [ceil(frames / 1024)] -- per wave-tile the estimated ENERGY (sum over its frames of variance +
+    // offset^2) of the launch's deviation from the reference at the launch's output (behind the fused Normalize vertex where
+    // there is one); nullptr: not guarded (band_mode 1).  Read by k_band_audit at the end of the submission.
+    float* noise;
+    float nz_end, pad5;         // the static gain behind the last stage that the kernel applies itself (fused Normalize vertex' pan / gain)
 };
+// The guard's verdict (engine option "band_mode" 2): one workgroup per graph adds up what its scan launches estimated, carried to
+// the graph's output -- a static gain per launch (the host walks the graph: pan / gain of everything downstream) and, where the
+// path runs through ONE Normalize vertex that the launch has not evaluated itself, that vertex' running maximum per block
+// (its peak table and carried max, as k_scale / k_norm_fix read them) -- and raises a word in page-locked host memory when
+// the estimated RMS deviation exceeds the bound: the engine then renders the graph again with the exact kernels.
+struct AuditDesc {
+    const float* noise;         // a launch's per-wave-tile energies
+    const float* peaks;         // the Normalize vertex on the way to the output: [nb] block peaks (nullptr: none, or evaluated by the launch)
+    const float* init_copy;     // ... its carried max at the chunk start
+    uint32_t n_wt, nb, bl, pad;
+    float gain;                 // static gain from the launch's output to the graph's
+    uint32_t pad2[3];
+};
+struct AuditHead {              // one graph of the submission
+    const AuditDesc* descs;
+    uint32_t n, frames;
+    float thr2;                 // (bound on the RMS)^2
+    uint32_t pad;
+    uint32_t* host_word;        // page-locked host memory (device address): [0] raised when over the bound, [1] the estimate (f32 bits)
+};
+void launch_band_audit(const AuditHead* heads, int n_heads, hipStream_t s);
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
 int band_scan_resident_capacity(int nf);   // workgroups of k_band_scan resident at once (0: unknown)
-void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, hipStream_t s);   // n_stages >= 2, NF 16
+void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, bool guarded, hipStream_t s);   // NF 16; guarded: every descriptor has `noise`
 inline uint32_t band_scan_tile_frames(int nf) { return (uint32_t)nf * (uint32_t)kThreads; }
 
 // ---- build-defined sinc resampler (stands in for the un-vendored rubato crate; DESIGN.md "Resampler") ----

@@ -3224,9 +3224,19 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
 // (Tried and dropped, both bit-identical: every WAVE handing over for itself -- no barriers, but 2 816 pollers with a
 // four times deeper look-back: 0.71 ms for BASELINE config 4's 84 stages against 0.60; a wave owning two wave-tiles half
 // a timeline apart so that one's hand-off passes under the other's arithmetic -- 256 registers, two waves per SIMD: 1.22 ms.)
-template <int TMODE>
+// GUARD (engine option "band_mode" 2): the launch also estimates how far its output lies from the reference's f32 trajectory
+// -- the one thing this class gives up -- and leaves the estimate, per wave-tile, to k_band_audit (BandScanDesc::noise).  The
+// reference's smoother rounds its state once per frame; against exact arithmetic those roundings accumulate to (a) a random
+// walk held in check by the filter's own decay, variance ulp^2 / 12 per step over 1 / (gamma (2 - gamma)) steps, while the
+// state moves by more than its own ulp per frame, and (b) where it does not -- a held level, silence with an offset, a
+// very slow ramp: |gamma (x - y)| below a few ulp(y) -- a standing offset of up to ulp(y) / (2 gamma): the f32 state parks
+// short of its target and the exact-arithmetic one does not.  Both are functions of the state's LEVEL, which every lane has
+// in its entry state: one sample per 16 frames and smoother.  The estimate rides through the chain like the signal does
+// (static pan / gain of vertices and links, the envelope links' gain of the lane's first frame) as a variance and an offset.
+template <int TMODE, bool GUARD>
 __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M, uint32_t chains_in_x) {
     constexpr int NF = 16, NP = NF / 2;
+    constexpr float kSlowUlps = 4.0f * 1.1920929e-07f;   // |gamma (x - y)| < 4 ulp(y) (ulp <= 2^-23 |y|): the state is parked
     constexpr uint32_t WT = (uint32_t)NF * 64u;         // frames per wave-tile
     // Several chains in one launch (a batch of projects): the chain index is the FAST grid dimension, so the workgroups
     // the device holds at a time belong to all of them -- chains are independent of each other and each one's tiles move in
@@ -3362,6 +3372,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         return StageHead{q->lgamma, q->hgamma, q->pw, q->pk, q->n_post, q->post[0].env, q->post[1].env};
     };
     StageHead head = head_of(0u);
+    float nz_var = 0.0f, nz_off = 0.0f;   // (GUARD) the lane's estimate: variance and offset of the deviation at its frames
     for (uint32_t s = 0; s < n_stages; ++s) {
         const BandStageDesc TD_CONST* const sp = stages + s;
         stamp(s, 0u);
@@ -3509,6 +3520,17 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         const f32x2 c = {(float)__builtin_fma(pwl, __builtin_fma(awp0, carry_s[0], xw0), e0),
                          (float)__builtin_fma(pwh, __builtin_fma(awp2, carry_s[1], xw2), e2)};
         const f32x2 TD_CONST* const pn = (const f32x2 TD_CONST*)(const TD_CONST char*)sp->pn;
+        if (GUARD) {   // what this vertex' two smoothers add, from the level of the lane's entry state (host: nzv / nzs 0 for a constant chain)
+            const float x0 = x[0].x;
+            const float al = fabsf(c.x), ah = fabsf(c.y);
+            nz_var = __builtin_fmaf(sp->nzv[0], c.x * c.x, __builtin_fmaf(sp->nzv[1], c.y * c.y, nz_var));
+            const float pl = fabsf(lgam * (x0 - c.x)) < kSlowUlps * al ? sp->nzs[0] * al : 0.0f;
+            const float ph = fabsf(hgam * (x0 - c.y)) < kSlowUlps * ah ? sp->nzs[1] * ah : 0.0f;
+            nz_off += pl + ph;
+            const float gq = sp->nzg;   // ... and on through the vertex' own pan / gain and the static part of the links
+            nz_var *= gq * gq;
+            nz_off *= gq;
+        }
         // ---- output (extensions.rs:682-687 with cut_mul 0, pass_mul 1), then the vertex' pan / gain
         const bool lo_on = lgam != 0.0f, hi_on = hgam != 0.0f;
         if (fin_here) {   // the lane that holds the chunk's last frame carries the state over (one wave-tile of the chunk)
@@ -3577,6 +3599,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                         const float4 a = x[2 * q], b = x[2 * q + 1];
                         x[2 * q] = make_float4(a.x * e.x, a.y * e.x, a.z * e.y, a.w * e.y);
                         x[2 * q + 1] = make_float4(b.x * e.z, b.y * e.z, b.z * e.w, b.w * e.w);
+                    }
+                    if (GUARD) {   // (the envelope's gain at the lane's first frame; 0 beyond the chunk's end)
+                        const float e0 = fabsf(envv[0].x);
+                        nz_var *= e0 * e0;
+                        nz_off *= e0;
                     }
                 }
                 pan_gain(sp->post[p].pg.l_amp, sp->post[p].pg.r_amp, sp->post[p].pg.gain, sp->post[p].pg.flags);
@@ -3710,6 +3737,13 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         float run = fmaxf(pm, norm_init);                                   // max_(b-1) entering the tile's first block
         for (uint32_t w = 0; w <= wave; ++w) run = fmaxf(nwm[w], run);      // *max = buf_max.max(*max)
         const float r = 1.0f / run;
+        if (GUARD) {   // the estimate goes through the Normalize vertex like the frames do: 1 / max, its pan / gain (largest channel)
+            const float gq = fabsf(r) * dl->nz_end;
+            float e = mf_e < M ? (float)NF * __builtin_fmaf(nz_off * gq, nz_off * gq, nz_var * gq * gq) : 0.0f;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+            if (lane_e == 0u && wt0 < M) dl->noise[wt] = e;
+        }
         PanGain npg;
         npg.l_amp = ndl->pg.l_amp; npg.r_amp = ndl->pg.r_amp; npg.gain = ndl->pg.gain; npg.flags = ndl->pg.flags;
 #pragma unroll
@@ -3731,12 +3765,77 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         if (fin_here && lane_e == 0u) const_cast<NormState*>((const NormState*)ndl->state)->max = run;
         return;
     }
+    if (GUARD) {
+        float e = mf_e < M ? (float)NF * __builtin_fmaf(nz_off, nz_off, nz_var) : 0.0f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+        if (lane_e == 0u && wt0 < M) dl->noise[wt] = e;
+    }
     // the last vertex' output, back through the wave's staging for coalesced stores
 #pragma unroll
     for (int j = 0; j < NP; ++j) xw4_e[lane_e * (uint32_t)(NP + 1) + (uint32_t)j] = x[j];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
 #pragma unroll
     for (int q = 0; q < NP; ++q) store_pair(dl->out, wt0 + 2u * ((uint32_t)q * 64u + lane_e), M, xw4_e[slot((uint32_t)q * 64u + lane_e)]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_band_audit: the guard's verdict (AuditHead / AuditDesc, kernels.h) -- one workgroup per graph of the submission
+// ------------------------------------------------------------------------------------------------
+// Per scan launch: sum over its wave-tiles of  energy x (static gain to the output)^2 x (1 / running max of the Normalize
+// vertex on the way, at the tile's first frame)^2.  The running max of block b is max(carried max, peaks[0 .. b])
+// (extensions.rs:321-329): segment maxima of the peak table, their prefix, then a short walk inside the tile's segment.
+// Launches add up as amplitudes (the same rounding pattern may reach the output twice).  NaN energies (tiles the
+// reference turns NaN as well) count as 0, infinite ones trip the guard.
+__global__ __launch_bounds__(kThreads) void k_band_audit(const AuditHead* __restrict__ heads) {
+    const AuditHead h = heads[blockIdx.x];
+    __shared__ float seg_max[kThreads], seg_pre[kThreads + 1], part[kThreads];
+    const uint32_t tid = threadIdx.x;
+    float amp = 0.0f;   // (thread 0) sum over the launches of sqrt(energy at the output)
+    for (uint32_t i = 0; i < h.n; ++i) {
+        const AuditDesc d = h.descs[i];
+        const uint32_t seg = d.peaks ? (d.nb + (uint32_t)kThreads - 1u) / (uint32_t)kThreads : 0u;
+        if (d.peaks) {
+            float m = 0.0f;
+            for (uint32_t b = tid * seg; b < min(d.nb, (tid + 1u) * seg); ++b) m = fmaxf(m, gload1(d.peaks + b));
+            seg_max[tid] = m;
+            __syncthreads();
+            if (tid == 0u) {
+                float run = gload1(d.init_copy);
+                for (uint32_t q = 0; q < (uint32_t)kThreads; ++q) { seg_pre[q] = run; run = fmaxf(run, seg_max[q]); }
+            }
+            __syncthreads();
+        }
+        float e = 0.0f;
+        for (uint32_t w = tid; w < d.n_wt; w += (uint32_t)kThreads) {
+            float v = fmaxf(gload1(d.noise + w), 0.0f);   // (NaN -> 0)
+            if (d.peaks) {
+                const uint32_t b0 = min(d.nb - 1u, (uint32_t)(((uint64_t)w * (uint64_t)kTileFrames) / d.bl));
+                const uint32_t sg = b0 / seg;
+                float run = seg_pre[sg];
+                for (uint32_t b = sg * seg; b <= b0; ++b) run = fmaxf(run, gload1(d.peaks + b));
+                const float r = 1.0f / run;
+                v *= r * r;
+            }
+            e += v;
+        }
+        part[tid] = e;
+        __syncthreads();
+        for (uint32_t st = (uint32_t)kThreads / 2u; st > 0u; st >>= 1) {
+            if (tid < st) part[tid] += part[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0u) amp += sqrtf(part[0]) * fabsf(d.gain);
+        __syncthreads();
+    }
+    if (tid == 0u) {
+        const float ms = amp * amp / (float)max(h.frames, 1u);   // estimated mean square of the deviation over the chunk's frames
+        __hip_atomic_store((gu32)(TD_GLOBAL char*)(h.host_word + 1), __float_as_uint(sqrtf(ms)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (!(ms <= h.thr2)) __hip_atomic_store((gu32)(TD_GLOBAL char*)h.host_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+void launch_band_audit(const AuditHead* heads, int n_heads, hipStream_t s) {
+    if (n_heads > 0) hipLaunchKernelGGL(k_band_audit, dim3((uint32_t)n_heads), dim3(kThreads), 0, s, heads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -4146,16 +4245,16 @@ void launch_band_scan(const BandScanDesc* d, int n, uint32_t frames, uint32_t te
         default: launch_band_scan_mode<TERMS_MIXED>(d, n, frames, gx, nf, s); break;
     }
 }
-void launch_band_chain(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, hipStream_t s) {
+void launch_band_chain(const BandScanDesc* d, int n, uint32_t frames, uint32_t term_mode, bool guarded, hipStream_t s) {
     if (!n || !frames) return;
     const uint32_t tile = band_scan_tile_frames(16), gx = (frames + tile - 1u) / tile;
     void (*k)(const BandScanDesc*, uint32_t, uint32_t) = nullptr;
     switch (term_mode) {
-        case TERMS_EDGE_FEW: k = k_band_chain<TERMS_EDGE_FEW>; break;
-        case TERMS_ALL_EDGE: k = k_band_chain<TERMS_ALL_EDGE>; break;
-        case TERMS_ADSR1: k = k_band_chain<TERMS_ADSR1>; break;
-        case TERMS_WITH_ADSR: k = k_band_chain<TERMS_WITH_ADSR>; break;
-        default: k = k_band_chain<TERMS_MIXED>; break;
+        case TERMS_EDGE_FEW: k = guarded ? k_band_chain<TERMS_EDGE_FEW, true> : k_band_chain<TERMS_EDGE_FEW, false>; break;
+        case TERMS_ALL_EDGE: k = guarded ? k_band_chain<TERMS_ALL_EDGE, true> : k_band_chain<TERMS_ALL_EDGE, false>; break;
+        case TERMS_ADSR1: k = guarded ? k_band_chain<TERMS_ADSR1, true> : k_band_chain<TERMS_ADSR1, false>; break;
+        case TERMS_WITH_ADSR: k = guarded ? k_band_chain<TERMS_WITH_ADSR, true> : k_band_chain<TERMS_WITH_ADSR, false>; break;
+        default: k = guarded ? k_band_chain<TERMS_MIXED, true> : k_band_chain<TERMS_MIXED, false>; break;
     }
     if (gx <= (uint32_t)kMaxGridY) {   // chains along x (dispatched round-robin), tiles along y
         hipLaunchKernelGGL(k, dim3((uint32_t)n, gx), dim3(kThreads), 0, s, d, frames, 1u);

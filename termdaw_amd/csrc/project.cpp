@@ -485,10 +485,12 @@ td_state* td_state_new(const char* wdir, size_t project_samplerate, size_t buffe
     s->sb = td_samplebank_new(s->psr);
     s->fb = td_flowwbank_new(s->psr, s->bl);
     s->g = td_graph_new(s->bl, s->psr);
-    // The front-end's band-pass vertices run in scan mode (engine option "band_mode" 1: tolerance class, <= 1e-6 RMS and
-    // +-1 LSB against the reference's serial recurrence -- the bound BASELINE's north_star sets for filter paths; BASELINE
-    // config 4 renders in 0.43 ms instead of 12 ms).  td_state_set_option(s, "band_mode", 0) selects the exact kernels.
-    s->g->band_mode = 1;
+    // The front-end's band-pass vertices run the scan kernels UNDER THE GUARD (engine option "band_mode" 2): tolerance class,
+    // <= 1e-6 RMS and +-1 LSB against the reference's serial recurrence -- the bound BASELINE's north_star sets for filter
+    // paths -- with the bound checked per render: a render whose own estimate of its deviation is over 2e-7 is done again
+    // with the exact kernels (engine.h tde::Guard; BASELINE config 4 renders in 0.4 ms instead of 12 ms and is never
+    // redone).  td_state_set_option(s, "band_mode", 0) selects the exact kernels outright, 1 the scan without the guard.
+    s->g->band_mode = 2;
     return s;
 }
 

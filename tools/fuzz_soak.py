@@ -1,7 +1,10 @@
 """The random-project parity tests of tests/test_gpu_fuzz.py over any seed range:  python tools/fuzz_soak.py 1000 3000
 (bit-exact kinds), python tools/fuzz_soak.py 1000 3000 sinf (projects with debug_sine / synth: <= 1e-6 RMS),
 python tools/fuzz_soak.py 1000 3000 scan (the same random graphs with the tolerance-class band-pass, engine option band_mode 1:
-chains, the Sum vertex in front and the Normalize vertex behind a scan launch -- <= 1e-6 RMS of the output's scale)"""
+chains, the Sum vertex in front and the Normalize vertex behind a scan launch -- <= 1e-6 RMS of the output's scale),
+python tools/fuzz_soak.py 1000 3000 guard (the same in band_mode 2, the front-end's default: the scan under the guard -- renders
+whose own estimate is over the bound are done again with the exact kernels; the summary counts them).  `--jobs N` as a last
+argument pair splits the seed range over N processes (the CPU oracle is the slow side)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,9 +15,20 @@ from oracle import binding as oracle
 import test_gpu_fuzz as F
 
 lo_seed, hi_seed = int(sys.argv[1]), int(sys.argv[2])
-sinf = len(sys.argv) > 3 and sys.argv[3] in ("sinf", "scan")
-scan_mode = len(sys.argv) > 3 and sys.argv[3] == "scan"
+if "--jobs" in sys.argv:
+    import subprocess
+    jobs = int(sys.argv[sys.argv.index("--jobs") + 1])
+    rest = [a for a in sys.argv[3:] if a != "--jobs" and a != str(jobs)]
+    step = (hi_seed - lo_seed + jobs - 1) // jobs
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(a), str(min(a + step, hi_seed))] + rest)
+             for a in range(lo_seed, hi_seed, step)]
+    sys.exit(max(p.wait() for p in procs))
+sinf = len(sys.argv) > 3 and sys.argv[3] in ("sinf", "scan", "guard")
+scan_mode = len(sys.argv) > 3 and sys.argv[3] in ("scan", "guard")
+guard_mode = len(sys.argv) > 3 and sys.argv[3] == "guard"
 bad, rejected = [], 0
+audits = redos = renders = 0
+worst = (0.0, -1)
 for seed in range(lo_seed, hi_seed):
     p = F.random_project(seed, allow_sinf=sinf)
     try:
@@ -29,7 +43,7 @@ for seed in range(lo_seed, hi_seed):
         continue
     gb = p.build(api)
     if scan_mode:
-        gb[2].set_option("band_mode", 1)
+        gb[2].set_option("band_mode", 2 if guard_mode else 1)
     for scan in (False, True, False):
         gp, gf = p.render(api, built=gb, scan=scan)
         op, of = p.render(oracle, built=ob, scan=scan)
@@ -37,6 +51,9 @@ for seed in range(lo_seed, hi_seed):
             ok = np.isfinite(of)
             scale = max(1.0, float(np.abs(of[ok]).max()) if ok.any() else 1.0)
             rms = float(np.sqrt(np.mean(((gf[ok].astype(np.float64) - of[ok].astype(np.float64)) / scale) ** 2))) if ok.any() else 0.0
+            renders += 1
+            if rms > worst[0]:
+                worst = (rms, seed)
             if not np.array_equal(np.isfinite(gf), ok) or rms > 1e-6:
                 bad.append((seed, scan, rms))
                 break
@@ -45,5 +62,10 @@ for seed in range(lo_seed, hi_seed):
                 or not np.array_equal(gp, op)):
             bad.append((seed, scan))
             break
-print("seeds", lo_seed, hi_seed, "rejected by both:", rejected, "mismatching:", bad)
+    if guard_mode:
+        st = gb[2].band_guard_stats()
+        audits += st["audits"]
+        redos += st["redos"]
+print("seeds", lo_seed, hi_seed, "rejected by both:", rejected, "mismatching:", bad,
+      ("renders %d audited %d done again exact %d worst rms %.3g (seed %d)" % (renders, audits, redos, worst[0], worst[1])) if scan_mode else "")
 sys.exit(1 if bad else 0)
