@@ -83,9 +83,9 @@ def test_unwritable_path_is_an_error_not_a_crash(gpu_api, tmp_path):
 
 
 def test_front_end_default_is_scan_mode(gpu_api, oracle, tmp_path):
-    """A State renders band-pass vertices in scan mode by default (td_state_set_option in termdaw_amd.h): the same bytes as a
-    graph with band_mode 1, within the tolerance class of the oracle; band_mode 0 gives the oracle's bytes; the setting
-    survives a refresh; a project without band-pass vertices is bit-exact either way."""
+    """A State renders band-pass vertices in guarded scan mode by default (td_state_set_option in termdaw_amd.h): the same
+    bytes as a graph with band_mode 2, within the tolerance class of the oracle; band_mode 0 gives the oracle's bytes; the
+    setting survives a refresh; a project without band-pass vertices is bit-exact either way."""
     p = W.drum_project(seconds=1.7)
     lua = p.to_lua(str(tmp_path / "a"))
     ref_pcm, ref_f = p.render(oracle)
@@ -93,7 +93,7 @@ def test_front_end_default_is_scan_mode(gpu_api, oracle, tmp_path):
     assert s.refresh(lua), gpu_api.last_error()
     got = s.render_to_memory()
     built = p.build(gpu_api)
-    built[2].set_option("band_mode", 1)
+    built[2].set_option("band_mode", 2)
     scan_pcm, scan_f = p.render(gpu_api, built=built)
     assert np.array_equal(got, scan_pcm)
     assert np.abs(got.astype(np.int64) - ref_pcm.astype(np.int64)).max() <= 1
