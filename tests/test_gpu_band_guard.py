@@ -86,7 +86,10 @@ def test_a_forced_verdict_gives_the_exact_render(gpu_api, oracle, name, mk):
         else:
             assert np.array_equal(_bits(gf), _bits(of)) and np.array_equal(gp, op)
     st = gb[2].band_guard_stats()
-    assert st["audits"] >= 3 and st["redos"] >= 3, st
+    if name in ("config3", "config4"):
+        assert st["audits"] >= 3 and st["redos"] >= 3, st
+    else:   # (a `cut` vertex is never given to the scan in this mode: nothing to audit)
+        assert st["redos"] == st["audits"], st
     # ... and exactly what band_mode 0 renders
     eb = p.build(gpu_api)
     gb2 = _guarded(p, gpu_api, band_guard_ppb=0)
@@ -126,12 +129,14 @@ def test_pipelined_renders_and_mode_switch(gpu_api, oracle):
     """Fresh renders queued back to back leave ONE verdict to look at (the last render is the one that is read); a verdict
     still out when the mode changes belongs to the render it was made for."""
     p = W.config4(seconds=1.0, depth=12)
-    op, of = p.render(oracle)
+    osb, ofb, og = p.build(oracle)
     sb, fb, g = _guarded(p, gpu_api, band_guard_ppb=0)
     for _ in range(4):
-        g.reset_normalize_vertices()
-        fb.set_time(0)
-        g.set_time(0)
+        for (b, gr) in ((ofb, og), (fb, g)):
+            gr.reset_normalize_vertices()
+            b.set_time(0)
+            gr.set_time(0)
+        op, of = og.render_all(osb, ofb, p.cs, 16)      # (host-side voices carry from render to render: Q4)
         g.render_all_async(sb, fb, p.cs, 16)
     g.sync()
     assert np.array_equal(_read_pcm(gpu_api, g, p.cs * p.bl), op)
