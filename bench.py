@@ -49,7 +49,8 @@ SECONDS = 60.0
 N_SRC = 64
 PROF_EVERY = 8
 PREWARM_S = 0.25           # untimed, before the W warm-up steps: steady device clocks (see time_batch)
-PROFILE_TAG = "r04"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
+PROFILE_TAG = "r05"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
+PROFILE_TAG_PREV = "r04"   # ... or, until this round's passes are committed, the previous round's (the entry says which file)
 
 
 def algorithmic_bytes_per_frame(k, fused, packed):
@@ -234,13 +235,17 @@ def launch_ranks(n):
     return rc
 
 
-def profiled(name):
-    """A committed rocprofv3 summary of THIS round (profiles/<tag>_<name>.json), or None."""
-    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (PROFILE_TAG, name))
-    try:
-        return json.load(open(path))
-    except Exception:   # noqa: BLE001
-        return None
+def profiled(name, with_tag=False):
+    """A committed rocprofv3 summary of THIS round (profiles/<tag>_<name>.json; the previous round's while this round's has
+    not been made yet), or None."""
+    for tag in (PROFILE_TAG, PROFILE_TAG_PREV):
+        path = os.path.join(ROOT, "profiles", "%s_%s.json" % (tag, name))
+        try:
+            d = json.load(open(path))
+            return (d, tag) if with_tag else d
+        except Exception:   # noqa: BLE001
+            continue
+    return (None, PROFILE_TAG) if with_tag else None
 
 
 def build_batch(api, workloads, rank, world, n_per_gpu, seconds, no_fuse, no_pack):
@@ -291,11 +296,14 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     every = 0 if by_marks else (PROF_EVERY if steps >= 64 else max(PROF_EVERY, steps))
     batch.set_profiling(every)
     barrier()
+    start_wall = time.time()                 # (right behind the opening barrier: max - min over the ranks = start skew)
     t0 = time.perf_counter()
     batch.mark(0)
     for _ in range(steps):
         step()
     batch.mark(1)
+    batch.sync()                             # this rank's K steps are done (the exchange below waits for the stream anyway)
+    t_done = time.perf_counter()
     # The closing barrier.  With more than one rank it IS the path's only exchange -- one all-reduce(max) of the peak table on
     # device memory, which no rank leaves before every rank has contributed, i.e. has finished its K steps (each contributes
     # only after synchronising its engine stream) -- followed by torch.cuda.synchronize(): a second collective (dist.barrier)
@@ -306,7 +314,9 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
         torch.cuda.synchronize()
     else:
         barrier()
-    dt = time.perf_counter() - t0
+    t_end = time.perf_counter()
+    dt = t_end - t0
+    time_batch.last_ranks = {"render_ms": (t_done - t0) * 1e3, "exchange_ms": (t_end - t_done) * 1e3, "dt_ms": dt * 1e3, "start_wall": start_wall}
     peaks = exchange.host()                  # (the report's copy of the table: outside the timed region, like the PCM it stays in HBM)
     ktimes = batch.kernel_times()
     batch.set_profiling(0)
@@ -391,11 +401,13 @@ def other_configs(api, workloads, ub, chain_ns):
     issue_ns = float(ub.td_ubench_fma_issue_ns(SIMDS // 4)) if ub is not None else -1.0
     plan = (("config1", workloads.config1, None, 50, ()),
             ("config3", workloads.config3, "exact", 10, (8, 32)), ("config3", workloads.config3, "scan", 10, (8, 32)),
-            ("config4", workloads.config4, "exact", 4, (8, 32)), ("config4", workloads.config4, "scan", 10, (8, 32)))
+            ("config3", workloads.config3, "guard", 10, ()),
+            ("config4", workloads.config4, "exact", 4, (8, 32)), ("config4", workloads.config4, "scan", 10, (8, 32)),
+            ("config4", workloads.config4, "guard", 10, (32,)))
     for name, mk, mode, reps, batches in plan:
         p = mk()
         frames = p.cs * p.bl
-        opts = {} if mode is None else {"band_mode": 1 if mode == "scan" else 0}
+        opts = {} if mode is None else {"band_mode": {"scan": 1, "guard": 2}.get(mode, 0)}
         ms, kernels, hosts, built = time_project(p, api, opts, reps)
         g = built[2]
         dom = kernels[0]
@@ -406,13 +418,17 @@ def other_configs(api, workloads, ub, chain_ns):
                  "host_ms_per_render": {k: round(v / max(hosts["chunks"], 1), 4) for k, v in hosts.items() if k != "chunks"},
                  "kernels": [{"kernel": k[0], "ms_per_render": round(k[1], 4), "launches": int(k[2]), "avg_ms": round(k[3], 5)} for k in kernels],
                  "dominant": dom[0]}
+        if mode == "guard":   # (the front-end's default: the scan under the guard -- what the guard saw of the timed renders)
+            entry["guard"] = g.band_guard_stats()
         if mode is not None:
             entry["band_mode"] = mode
             entry["band_mode_note"] = ("exact: speculative-segment kernels, bit-identical to the reference's serial recurrence (default, parity mode)"
                                        if mode == "exact" else
+                                       "guard: the scan kernels under the guard (band_mode 2, the front-end's default): every render estimates its own "
+                                       "deviation and is redone with the exact kernels when over 2e-7 RMS (tests/test_gpu_band_guard.py)" if mode == "guard" else
                                        "scan: blocked affine scan (k_band_scan / k_band_chain), tolerance class: <= 1e-6 RMS and +-1 LSB against the "
                                        "oracle (tests/test_gpu_band_scan.py; measured RMS per chain depth: profiles/%s_scan_rms.txt)" % PROFILE_TAG)
-        vkey = name if mode in (None, "exact") else name + "_scan"
+        vkey = name if mode in (None, "exact") else name + "_scan"   # (the guarded launches are priced with the scan entry's counters)
         insts = (valu.get(vkey, {}).get(dom[0]) or {}).get("SQ_INSTS_VALU")
         if name == "config1":
             floor = launches * 1.45e-3    # MI355X_MICROARCH.md price list, row "boundary": dependent kernel boundary 1.45 us
@@ -458,7 +474,38 @@ def other_configs(api, workloads, ub, chain_ns):
     return out
 
 
-def edge_buffer_mode(api, workloads, seconds, frames, copy_gbs, reps=5):
+def cold_tables(api, workloads, seconds, n_projects=16, reps=8):
+    """The headline region over DISTINCT projects: n_projects config-2 projects (seeds offset by 64 per project: 16 x 20 MB of
+    packed tables, more than the 256 MB Infinity Cache holds beside everything else) on ONE stream, each step renders the next
+    one -- the same one launch per render as the headline, whose single project's tables never leave the cache."""
+    from termdaw_amd import batch as tb
+    opts = {"fuse_sources": 1, "packed_samples": 1, "output_f32": 0}
+    b, first = tb.build_shard(api, lambda pid: workloads.config2(seconds=seconds, n_src=N_SRC, seed_offset=64 * (pid + 1)), list(range(n_projects)), opts)
+    cs = first.cs
+
+    def one(i):
+        sb, fb, g = b.projects[i % n_projects]
+        g.reset_normalize_vertices()
+        fb.set_time(0)
+        g.render_all_async(sb, fb, cs, 16)
+    t_pre = time.perf_counter()
+    i = 0
+    while i < 2 * n_projects or time.perf_counter() - t_pre < PREWARM_S:
+        one(i)
+        i += 1
+    b.sync()
+    n = reps * n_projects
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(i)
+    b.sync()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    frames = cs * first.bl
+    del b
+    return {"projects": n_projects, "renders": n, "ms_per_render": round(ms, 5), "Msamples_per_s": round(frames / ms / 1e3, 1)}
+
+
+def edge_buffer_mode(api, workloads, seconds, frames, copy_gbs, reps=5, copy_detail=None):
     """SURVEY 8(d)'s sum+normalize check on the SAME project with the edge-buffer model (engine option fuse_sources 0: one
     HBM buffer per source vertex, the Normalize reads 64 of them): k_sum + k_scale move 8k+8 + 8+8 = 536 B per frame
     (+ the 4 B PCM), which IS HBM traffic there (L2 hit 2 %, profiles/*_pmc_summary.json "nofuse")."""
@@ -473,7 +520,7 @@ def edge_buffer_mode(api, workloads, seconds, frames, copy_gbs, reps=5):
     return {"k_sum_ms": round(kd["k_sum"], 5), "k_scale_ms": round(kd["k_scale"], 5), "k_sample_loop_ms": round(kd.get("k_sample_loop", 0.0), 5),
             "ms_per_render": round(ms, 4), "bytes": int(nbytes), "bytes_per_frame": 536, "GB/s": round(gbs, 1),
             "frac_hbm_peak": round(gbs / HBM_PEAK_GBS, 4), "frac_measured_copy": round(gbs / copy_gbs, 4),
-            "measured_copy_GBs": round(copy_gbs, 1), "renders": reps,
+            "measured_copy_GBs": round(copy_gbs, 1), "copy_GBs": copy_detail, "renders": reps,
             "k_sum_alone_GBs": round(520 * frames / (kd["k_sum"] * 1e-3) / 1e9, 1),
             "note": "run after the timed region, outside it: the headline project rebuilt with engine options fuse_sources 0 "
                     "(SURVEY 8(d)'s edge-buffer model) and output_f32 1 (pass B writes the f32 frames back, as the 8+8 of the model "
@@ -569,7 +616,7 @@ NOTES = "profiles/NOTES.md"   # the prose that used to ride in the line, by note
 def compact(o):
     """The ONE line the driver stores: every headline number, no prose (notes live in profiles/NOTES.md under the ids
     given here); `--full` prints the long form instead."""
-    c = {k: o[k] for k in ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "exchange_backend", "steps", "warmup", "ms_per_step",
+    c = {k: o[k] for k in ("metric", "value", "unit", "n_gpus", "n_ranks_seen", "ranks", "exchange_backend", "steps", "warmup", "ms_per_step",
                            "higher_is_better", "scaling", "vs_baseline", "dtype", "data") if k in o}
     cfg = o["config"]
     c["config"] = {"workload": cfg["workload"], "frames_per_project": cfg["frames_per_project"], "projects_per_gpu": cfg["projects_per_gpu"],
@@ -577,17 +624,18 @@ def compact(o):
                    "parallelism": cfg["parallelism_id"]}
     r = o.get("roofline")
     if r:
-        rr = {"bound": "hbm", "ceiling": r.get("bound"), "kernel": r.get("rocprof_kernel"), "avg_ms": r.get("avg_ms"), "achieved": r.get("achieved"),
+        rr = {"bound": r.get("bound"), "kernel": r.get("rocprof_kernel"), "avg_ms": r.get("avg_ms"), "achieved": r.get("achieved"),
               "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic")}
         tp = r.get("traffic_profiled") or {}
         if tp:
             rr["traffic_profiled"] = {"bytes": tp.get("bytes_per_launch"), "l2_hit": tp.get("l2_hit_rate"), "avg_us_rocprof": tp.get("avg_us_rocprof"),
                                       "file": tp.get("profile")}
-        for k in ("bytes_per_frame", "ceiling_ms", "hbm_compulsory_bytes", "hbm_compulsory_frac", "frac_of_l2_peak", "frac_of_measured_copy", "measured_copy_GBs"):
+        for k in ("bytes_per_frame", "ceiling_ms", "frac_of_ubench_ceiling", "ubench_ceiling_GBs", "hbm_compulsory_bytes", "hbm_compulsory_frac",
+                  "frac_of_l2_peak", "frac_of_measured_copy", "measured_copy_GBs", "copy_GBs", "cold_tables"):
             if k in r:
                 rr[k] = r[k]
         if "l2_mall_split" in r:
-            rr["l2_mall_split"] = {"floor_ms": r["l2_mall_split"]["floor_ms"], "frac": r["l2_mall_split"]["frac"]}
+            rr["l2_mall_split"] = {"floor_ms": r["l2_mall_split"]["floor_ms"], "l2_hit": r["l2_mall_split"]["l2_hit_rate_profiled"]}
         if "valu_profiled" in r:
             rr["SQ_INSTS_VALU_profiled"] = round(r["valu_profiled"].get("SQ_INSTS_VALU", 0))
         rr["note"] = NOTES + "#roofline"
@@ -598,11 +646,11 @@ def compact(o):
     e = o.get("edge_buffer_mode")
     if e:
         c["edge_buffer_mode"] = e if "error" in e else {k: e[k] for k in ("k_sum_ms", "k_scale_ms", "bytes_per_frame", "GB/s", "frac_hbm_peak", "frac_measured_copy",
-                                                                           "measured_copy_GBs", "ms_per_render") if k in e}
+                                                                           "measured_copy_GBs", "copy_GBs", "ms_per_render") if k in e}
         c["edge_buffer_mode"]["note"] = NOTES + "#edge_buffer_mode"
     c5 = o.get("config5")
     if c5:
-        c["config5"] = {k: c5[k] for k in ("value", "unit", "projects_per_gpu", "projects", "steps", "ms_per_step", "ms_per_project") if k in c5}
+        c["config5"] = {k: c5[k] for k in ("value", "unit", "projects_per_gpu", "projects", "steps", "ms_per_step", "ms_per_project", "ranks") if k in c5}
     sc = o.get("scanned")
     if sc:
         c["scanned"] = {k: sc[k] for k in ("ms_per_render", "Msamples_per_s", "scan_ms", "ms_per_render_with_f32_copy") if k in sc}
@@ -622,6 +670,8 @@ def compact(o):
             row = {"config": x["config"], "ms": x["ms_per_render"], "Msps": x["Msamples_per_s"], "launches": x["launches_per_render"]}
             if "band_mode" in x:
                 row["band_mode"] = x["band_mode"]
+            if "guard" in x:
+                row["guard"] = {"redos": x["guard"]["redos"], "est": float("%.3g" % x["guard"]["max_est"])}
             ks = x.get("kernels") or []
             row["kernels"] = {k["kernel"]: k["ms_per_render"] for k in ks[:3]}
             b = x.get("bound") or {}
@@ -709,6 +759,23 @@ def main():
         from termdaw_amd import batch as tb
         return tb.PeakExchange(batch, n_per_gpu, rank, world, dist if use_dist else None, on_device=(backend == "nccl"))
 
+    def gather_ranks(mine):
+        """Every rank's own view of the timed region (outside it): what explains a scaling curve -- per-rank region and
+        render times, the time each spent in the closing exchange (the wait for the slowest rank included), start skew."""
+        vals = [mine["dt_ms"], mine["render_ms"], mine["exchange_ms"], mine["start_wall"]]
+        rows = [vals]
+        if use_dist:
+            t = torch.tensor(vals, dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            outs = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(outs, t)
+            rows = [[float(x) for x in o.cpu().tolist()] for o in outs]
+        a = np.array(rows, dtype=np.float64)
+        return {"n": int(a.shape[0]),
+                "dt_ms_min": round(float(a[:, 0].min()), 4), "dt_ms_max": round(float(a[:, 0].max()), 4),
+                "render_ms_min": round(float(a[:, 1].min()), 4), "render_ms_max": round(float(a[:, 1].max()), 4),
+                "exchange_ms": round(float(a[0, 2]), 4), "exchange_ms_min": round(float(a[:, 2].min()), 4),
+                "start_skew_us": round(float((a[:, 3].max() - a[:, 3].min()) * 1e6), 1)}
+
     def reduce_max(dt):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         if use_dist:
@@ -721,6 +788,7 @@ def main():
     cs, bl = project.cs, project.bl
     frames = cs * bl
     dt, ktimes, peaks, prof_every, marked_ms = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
+    ranks = gather_ranks(time_batch.last_ranks)
     dt = reduce_max(dt)
     device_bytes = sum(g.device_bytes() for _, _, g in batch.projects)
     host = batch.host_times()
@@ -739,6 +807,7 @@ def main():
         c5_steps = max(2, min(10, args.steps))
         b64, _ = build_batch(api, workloads, rank, world, 64, args.seconds, False, False)
         dt5, kt5, pk5, _, _ = time_batch(b64, cs, c5_steps, 2, barrier, make_exchange(b64, 64))
+        ranks5 = gather_ranks(time_batch.last_ranks)
         dt5 = reduce_max(dt5)
         c5 = {"projects_per_gpu": 64, "projects": 64 * world, "steps": c5_steps, "ms_per_step": round(dt5 / c5_steps * 1e3, 4),
               "ms_per_project": round(dt5 / c5_steps / 64 * 1e3, 5),
@@ -746,6 +815,7 @@ def main():
               "kernels": {k: round(v[0] / max(v[1], 1), 5) for k, v in kt5.items()},
               "host_ms_per_step": {k: round(v / max(b64.host_times(reset=False)["steps"], 1), 4) for k, v in b64.host_times(reset=False).items() if k != "steps"},
               "peak_table_entries": int(len(pk5)), "peak_table_min_max": [round(float(np.min(pk5)), 6), round(float(np.max(pk5)), 6)],
+              "ranks": ranks5,
               "note": "BASELINE config 5's per-GPU share: 64 independent config-2 projects (seed offset 64 x project id) resident per GPU, "
                       "one batch submission per step (launches of the 64 projects merged into one grid per kernel family), ONE "
                       "all-reduce(max) of the %d-entry peak table in the timed region" % (64 * world)}
@@ -776,7 +846,17 @@ def main():
         except Exception as e:   # noqa: BLE001
             sys.stderr.write("bench.py: no ubench library (%s): ceilings omitted\n" % e)
 
-        # the HBM denominator measured on this box (1 GiB each way: beyond the Infinity Cache)
+        # the HBM denominator measured on this box (1 GiB each way: beyond the Infinity Cache) -- the repo's own
+        # float4 copy kernel (tools/ubench/ceilings.hip k_stream: 16 B per lane in, 16 B out) and, beside it, torch's copy_
+        own_copy_gbs = None
+        if ub is not None:
+            try:
+                fr = (1 << 30) // 8
+                ms_c = float(ub.td_ubench_stream(fr, 1, 1, 10))
+                if ms_c > 0:
+                    own_copy_gbs = 2.0 * fr * 8 / (ms_c * 1e-3) / 1e9
+            except Exception:   # noqa: BLE001
+                own_copy_gbs = None
         copy_gbs = HBM_COPY_GBS
         try:
             n = 256 << 20
@@ -794,6 +874,9 @@ def main():
             del src, dst
         except Exception:   # noqa: BLE001
             copy_gbs = HBM_COPY_GBS
+        torch_copy_gbs = copy_gbs
+        if own_copy_gbs and own_copy_gbs > copy_gbs:
+            copy_gbs = own_copy_gbs      # the denominator is the faster of the two copies this box shows
 
         # ---- measured ceilings for the kernels of the timed region ----
         lens = np.array([project.assets["s%02d" % k].pcm.shape[0] for k in range(N_SRC)], dtype=np.uint32)
@@ -810,7 +893,8 @@ def main():
             gather_l2_ms = min(float(ub.td_ubench_gather(sp, N_SRC, frames, nq, it, P, per)), float(ub.td_ubench_gather(sp, N_SRC, frames, nq, it, P, 0)))
         if ub is not None:
             stream_ms = float(ub.td_ubench_stream(frames, 1, 1, 20))
-        tp = profiled("pmc_summary") or {}
+        tp, tp_tag = profiled("pmc_summary", with_tag=True)
+        tp = tp or {}
         mode_key = "nofuse" if args.no_fuse else ("fused_f32" if args.no_pack else "fused")
 
         kernels = []
@@ -825,7 +909,7 @@ def main():
                    "traffic_profiled": None if "hbm_side_bytes_per_launch" not in prof else {
                        "bytes_per_launch": prof["hbm_side_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate"),
                        "avg_us_rocprof": prof.get("avg_us"),
-                       "profile": "profiles/%s_pmc_summary.json" % PROFILE_TAG,
+                       "profile": "profiles/%s_pmc_summary.json" % tp_tag,
                        "note": "separate rocprofv3 --pmc passes of this command (FETCH_SIZE x 2 per the gfx950 half-count rule + "
                                "WRITE_SIZE); fabric-side bytes: Infinity-Cache hits are included, so HBM bytes are at most this"}}
             if name == "k_sum" and fused and packed and gather_ms and gather_ms > 0:
@@ -870,6 +954,8 @@ def main():
                                         "frac": round(hb / HBM_PEAK_GBS, 4), "bytes": dom["hbm_compulsory_bytes"],
                                         "note": "compulsory HBM bytes only: the launch is bound by its cache-served gathers (`bound` above), not by HBM"}
             roofline["measured_copy_GBs"] = round(copy_gbs, 1)
+            roofline["copy_GBs"] = {"own_float4_kernel": None if not own_copy_gbs else round(own_copy_gbs, 1), "torch_copy_": round(torch_copy_gbs, 1),
+                                    "guide_float4": HBM_COPY_GBS, "bytes_each_way": 1 << 30}
             vp = ((profiled("valu") or {}).get("config2") or {}).get(dom["kernel"])
             if vp:
                 roofline["valu_profiled"] = dict(vp, profile="profiles/%s_valu.json" % PROFILE_TAG)
@@ -887,7 +973,16 @@ def main():
                     roofline["l2_mall_split"] = {"l2_hit_rate_profiled": hit, "l2_gather_GBs": L2_GATHER_GBS, "mall_gather_GBs": MALL_GATHER_GBS,
                                                  "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / dom["avg_ms"], 4),
                                                  "note": "bytes x hit rate / 17.8 TB/s + bytes x (1 - hit rate) / 8.6 TB/s (MI355X_MICROARCH.md, "
-                                                         "'Indexed rows: gather'), hit rate from profiles/%s_pmc_summary.json" % PROFILE_TAG}
+                                                         "'Indexed rows: gather'), hit rate from profiles/%s_pmc_summary.json" % tp_tag}
+                    # The primary reading: `peak` is that guide-priced gather rate for THIS launch's split, `bound` says so, `frac`
+                    # is floor / measured -- no dependency on this repo's own ceiling kernel, which stays beside it
+                    roofline["frac_of_ubench_ceiling"] = roofline.get("frac")
+                    roofline["ubench_ceiling_GBs"] = roofline.get("peak")
+                    roofline["bound"] = "l2+infinity-cache gather"
+                    roofline["peak"] = round(gathered / (floor_ms * 1e-3) / 1e9, 1)
+                    roofline["frac"] = round(floor_ms / dom["avg_ms"], 4)
+                else:
+                    roofline["bound"] = "l2+infinity-cache gather (ceiling measured in-process: tools/ubench)"
             if fused and dom["kernel"] == "k_sum":
                 roofline["survey_model"] = {
                     "bytes_per_frame": survey_abf["k_sum"],
@@ -900,6 +995,7 @@ def main():
             "unit": "Msamples/s",
             "n_gpus": world,
             "n_ranks_seen": dist.get_world_size() if use_dist else 1,   # what the process group itself reports
+            "ranks": ranks,   # per-rank view of the timed region: dt / render min-max, exchange_ms (rank 0), start skew (profiles/NOTES.md#ranks)
             "exchange_backend": (backend if use_dist else "none"),      # "nccl" = RCCL: the peak table is all-reduced on device memory
             "steps": args.steps,
             "warmup": args.warmup,
@@ -997,9 +1093,16 @@ def main():
             ts.sort()
             out["pcie_inclusive"] = {"ms_per_render": round(ts[2] * 1e3, 4), "Msamples_per_s": round(frames / ts[2] / 1e6, 1),
                                      "note": "render + D2H of the PCM into pageable host memory; not part of `value`"}
+            if roofline is not None and not args.no_fuse and not args.no_pack:
+                try:
+                    ct = cold_tables(api, workloads, args.seconds)
+                    ct["warm_ms_per_render"] = out["ms_per_step"] / P
+                    roofline["cold_tables"] = ct
+                except Exception as e:   # noqa: BLE001
+                    roofline["cold_tables"] = {"error": str(e)[:120]}
             chain_ns = float(ub.td_ubench_valu_chain_ns()) if ub is not None else None
             try:
-                out["edge_buffer_mode"] = edge_buffer_mode(api, workloads, args.seconds, frames, copy_gbs)
+                out["edge_buffer_mode"] = edge_buffer_mode(api, workloads, args.seconds, frames, copy_gbs, copy_detail=(roofline or {}).get("copy_GBs"))
             except Exception as e:   # noqa: BLE001
                 out["edge_buffer_mode"] = {"error": str(e)}
             try:

@@ -147,7 +147,10 @@ size_t td_graph_render_all(td_graph* g, const td_samplebank* sb, td_flowwbank* f
  * parameter set (DESIGN.md "Resampler") -- parity with the reference is unpinned.  Returns output frames. */
 size_t td_graph_render_all_resampled(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits,
                                      size_t psr, size_t render_sr);
-/* Device-resident results of the last td_graph_render_all (valid until the next render on g). */
+/* Device-resident results of the last td_graph_render_all (valid until the next render on g).  After the ASYNC forms the
+ * contents are final only once td_graph_sync / td_batch_sync has returned: those settle what a render may have left
+ * pending -- the single-pass Normalize's deferred check, the guard's verdict of "band_mode" 2 -- which a plain stream or
+ * device synchronisation of the caller's own does not. */
 const void* td_graph_output_pcm_device(const td_graph* g);    /* int16|int32 interleaved, frames*2 words */
 const float* td_graph_output_f32_device(const td_graph* g);   /* float2 per frame, un-quantised output vertex */
 /* D2H copies of the above (pcm: frames*2 words of 2 or 4 bytes; f32: frames*2 floats). */

@@ -2838,7 +2838,13 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
 
     // ---- 4. launch, level by level
     const auto tp3 = std::chrono::steady_clock::now();
-    ar.pending_fix.clear();   // (what an un-settled earlier submission left: prepare_render has settled it where its result is still needed)
+    // (what an un-settled earlier submission left: prepare_render has settled it where its result is still needed.  If its
+    // host-visible word is already up, the word is cleared ON THE STREAM -- behind that submission's launches, in front of this
+    // one's -- so that it does not count against this submission at the next settle; the normal case is one host load.  A word
+    // raised after this look costs one unnecessary k_norm_fix later, never a wrong result.)
+    if (!ar.pending_fix.empty() && ar.h_flag && *(volatile uint32_t*)ar.h_flag)
+        TD_HIP(hipMemsetD32Async((hipDeviceptr_t)ar.d_flag, 0, 1, stream));
+    ar.pending_fix.clear();
     size_t li = 0;
     while (li < launches.size()) {
         size_t lj = li;
@@ -3244,7 +3250,14 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
         td_graph* g = b->graphs[lo + i];
         if (!settle_before_render(g)) return 0;
         if (!prepare_render(g, n_blocks, bits, want_pcm, &rp[i])) return 0;
-        g->defer_fix = allow_defer && !rp[i].multi;
+    }
+    // A deferred k_norm_fix lives in the arena's LAST submission only: where any project of the range takes several chunks --
+    // several submissions through this arena -- no project's check may be deferred (the later submissions would drop it).
+    bool any_multi = false;
+    for (size_t i = 0; i < P; ++i) any_multi = any_multi || rp[i].multi;
+    for (size_t i = 0; i < P; ++i) {
+        td_graph* g = b->graphs[lo + i];
+        g->defer_fix = allow_defer && !any_multi;
         if (g->band_mode == 2 && !g->guard.in_redo && has_reachable_band(g) &&
             !guard_begin(g, b->sbs[lo + i], b->fbs[lo + i], n_blocks, is_scan, bits, advance_graph_time, 0, want_pcm)) return 0;
     }
@@ -4155,7 +4168,7 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
     // writer threads: project i is theirs once its group's copy has completed
     std::atomic<size_t> next{0};
     std::atomic<int> failed{0};
-    const size_t nw = paths ? (size_t)std::max(writers, 0) : 0;
+    const size_t nw = paths ? (size_t)std::max(writers, 1) : 0;   // (files asked for: at least one writer, whatever `writers` says)
     std::vector<std::string> errs(nw);
     std::vector<double> first_write(nw, -1.0), last_write(nw, 0.0);
     std::atomic<size_t> queued{0};   // groups whose copy has been enqueued (their events are recorded)

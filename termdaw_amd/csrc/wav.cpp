@@ -212,7 +212,10 @@ bool write_wav_int_part(const char* path, const void* words, size_t frames, int 
     const size_t lo = std::min(data_bytes, per * (size_t)part), hi = std::min(data_bytes, lo + per);
     put((const uint8_t*)words + lo, hi - lo, h.size() + lo);
     ok = (close(fd) == 0) && ok;
-    if (!ok) *err = std::string("short write to \"") + path + "\"";
+    if (!ok) {
+        *err = std::string("short write to \"") + path + "\"";
+        (void)unlink(path);   // (no file rather than a valid header over a mix of old and new words)
+    }
     return ok;
 }
 

@@ -26,6 +26,15 @@ def test_bench_gpus_2_invoked_plainly_starts_its_own_ranks(gpu_api):
     assert out["n_gpus"] == 2 and out["n_ranks_seen"] == 2 and out["steps"] == 5
     assert out["scaling"] == "weak" and out["value"] > 0
     assert out["peak_table_entries"] == 2
+    # what explains a scaling curve: every rank's own view of the timed region
+    rk = out["ranks"]
+    assert rk["n"] == 2
+    for k in ("dt_ms_min", "dt_ms_max", "render_ms_min", "render_ms_max", "exchange_ms", "exchange_ms_min", "start_skew_us"):
+        assert k in rk and rk[k] >= 0.0, (k, rk)
+    assert rk["dt_ms_min"] <= rk["dt_ms_max"] and rk["render_ms_min"] <= rk["render_ms_max"] <= rk["dt_ms_max"]
+    # ms_per_step x steps is the slowest rank's region (max over ranks), within rounding
+    assert abs(out["ms_per_step"] * out["steps"] - rk["dt_ms_max"]) <= 0.02 * rk["dt_ms_max"] + 0.01
+    assert rk["start_skew_us"] < 1e6
 
 
 def test_bench_world_size_mismatch_is_an_error():

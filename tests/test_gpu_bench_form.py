@@ -171,6 +171,7 @@ def test_bench_one_rank_over_rccl():
     assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and out["value"] > 0
     assert out["exchange_backend"] == "nccl"
     assert out["peak_table_entries"] == 3 and all(v > 0 for v in out["peak_table"])
+    assert out["ranks"]["n"] == 1 and out["ranks"]["exchange_ms"] >= 0.0 and out["ranks"]["start_skew_us"] == 0.0
 
 
 def test_forced_give_up_under_graph_replay(gpu_api, oracle):
