@@ -1394,6 +1394,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
 
     g->band_stats_off.clear();
     g->band_stats_base = nullptr;
+    g->guard.chunk_audited = false;
     // ---- 1. host compile: sequential bookkeeping -> tables
     const auto tp0 = std::chrono::steady_clock::now();
     Staging& st = *cb.st;   // capacity kept from render to render
@@ -1544,6 +1545,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     // (event tables, conf, wet, flags) of the chunk -- the 84 envelope stages of a deep chain share one -- filled by
     // k_adsr_env at the vertex' own level, held until the chunk has been compiled
     std::map<std::string, float*> env_of_key;
+    const size_t env_tile_off = (M + 4 + 63) & ~(size_t)63;   // (floats; the edge buffer behind it is 2 x cap_frames >= 2 M floats long)
     std::vector<float*> env_of(nv, nullptr);
     std::vector<float2*> env_bufs;
     auto add_launch = [&](int fam, size_t off, int n, uint32_t aux, int level) {
@@ -1785,6 +1787,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 x.conf = v.conf;
                 adsr_fill_run_consts(&x);
                 x.env = env_of[vi];
+                x.env_tile = env_of[vi] + env_tile_off;   // (the buffer holds 2 x cap_frames floats: gains, then the mean squares per 512 frames)
                 d.push_back(x);
             }
             const size_t off = st.put(d);
@@ -1819,7 +1822,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     // the guard's bookkeeping (band_mode 2): where every Normalize vertex of the chunk keeps its peak table and carried max,
     // and what every guarded scan launch leaves for k_band_audit
     std::map<size_t, std::pair<size_t, size_t>> audit_norm;   // Normalize vertex -> scratch offsets (peaks, init snapshot)
-    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; };   // from: the vertex whose output the estimate stands at
+    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; size_t desc_off; };   // from: the vertex whose output the estimate stands at
     std::vector<AuditSrc> audit_src;
 
     for (int lv = 0; lv < g->n_levels; ++lv) {
@@ -2376,6 +2379,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         const std::vector<size_t> piece = chain_of.count(vi) ? chain_of[vi] : std::vector<size_t>{vi};
                         const ScanPlan& sp0 = scan_plan[piece[0]];
                         std::vector<BandStageDesc> sd;
+                        std::vector<double> stage_gain;   // (guard) per stage: its own pan / gain and the static part of the links behind it
                         for (size_t i = 0; i < piece.size(); ++i) {
                             const Vertex& v = g->vertices[piece[i]];
                             ScanPlan& sp = scan_plan[piece[i]];
@@ -2428,6 +2432,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                     x.post[l].env = links[l].adsr ? env_of[links[l].vertex] : nullptr;
                                     x.post[l].pg = make_pg(lv2.gain, lv2.angle);
                                     link_gain *= own_gain(lv2);
+                                    if (links[l].adsr && guard_on) x.envt = env_of[links[l].vertex] + env_tile_off;   // (at most one Adsr vertex per hop)
                                 }
                             }
                             if (guard_on) {   // (kernels.h BandStageDesc::nzv ..: DESIGN.md 3e "The guard")
@@ -2437,10 +2442,54 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                     const double gmc = (double)gm[c];
                                     x.nzv[c] = gm[c] == 0.0f ? 0.0f : (float)(0.25 * K0 / (gmc * (2.0 - gmc)));
                                     x.nzs[c] = gm[c] == 0.0f ? 0.0f : (float)(0.5 * ldexp(1.0, -24) / gmc);
+                                    x.nzk[c] = gm[c] == 0.0f ? 0.0f : (float)(4.0 * ldexp(1.0, -23) / gmc);
                                 }
-                                x.nzg = (float)link_gain;
+                                // both smoothers see the same input: when the slower one is parked so is the faster, at the same level
+                                // and an offset smaller by gamma_low / gamma_high -- below 5 % the faster one's test is not run
+                                if (v.lgamma != 0.0f && v.hgamma != 0.0f && (double)v.lgamma < 0.05 * (double)v.hgamma) { x.nzk[1] = 0.0f; x.nzs[1] = 0.0f; }
+                                stage_gain.push_back(link_gain);
                             }
                             sd.push_back(x);
+                        }
+                        if (guard_on) {   // the static gain from every stage to the launch's last one, folded into its coefficients
+                            std::vector<double> G(piece.size(), 1.0);
+                            double acc = 1.0;
+                            for (size_t i = piece.size(); i-- > 0;) { acc *= stage_gain[i]; G[i] = acc; }
+                            // Runs of identical filters (the 84 stages of BASELINE config 4) are evaluated at their FIRST stage only,
+                            // for the whole run: a later member's state level is the first one's times the gains in between, and
+                            // those times its own gain to the end are the first one's gain to the end -- so every member adds what
+                            // the first adds (the envelope gains in between reach the estimate in the kernel either way; they are
+                            // at most 1 here, so a later member's true level is lower, never higher).  Up to 8 stages per run: every
+                            // VALU instruction of the stage loop costs it ~0.2 % (kernels.hip).
+                            size_t f = 0;
+                            for (size_t i = 0; i < piece.size(); ++i) {
+                                const Vertex& vf = g->vertices[piece[f]];
+                                const Vertex& vi2 = g->vertices[piece[i]];
+                                bool same = i > f && i - f < 8 && vi2.lgamma == vf.lgamma && vi2.hgamma == vf.hgamma;
+                                if (same)   // (an envelope link in between that may exceed 1 ends the run)
+                                    for (const ChainLink& L : links_before[piece[i]])
+                                        if (L.adsr) {
+                                            const Vertex& av = g->vertices[L.vertex];
+                                            const AdsrConfD& c = av.conf;
+                                            double lv = std::max(std::max(fabs((double)c.std_vel), fabs((double)c.attack_vel)),
+                                                                 std::max(std::max(fabs((double)c.decay_vel), fabs((double)c.sustain_vel)), fabs((double)c.release_vel)));
+                                            double mv = 0.0;
+                                            for (const td_event& e : floww_of(fb, av.floww_index)) mv = std::max(mv, fabs((double)e.vel));
+                                            if (!(lv * mv <= 1.0)) same = false;
+                                        }
+                                if (!same) f = i;
+                                const double n_run = 1.0;   // (this member's own share; the run's first stage collects it)
+                                const double wv = (double)sd[i].nzv[0], wv1 = (double)sd[i].nzv[1], ws = (double)sd[i].nzs[0], ws1 = (double)sd[i].nzs[1];
+                                if (i == f) {
+                                    sd[i].nzv[0] = (float)(wv * G[i] * G[i]); sd[i].nzv[1] = (float)(wv1 * G[i] * G[i]);
+                                    sd[i].nzs[0] = (float)(ws * G[i]); sd[i].nzs[1] = (float)(ws1 * G[i]);
+                                } else {
+                                    sd[f].nzv[0] += (float)(n_run * wv * G[f] * G[f]); sd[f].nzv[1] += (float)(n_run * wv1 * G[f] * G[f]);
+                                    sd[f].nzs[0] += (float)(n_run * ws * G[f]); sd[f].nzs[1] += (float)(n_run * ws1 * G[f]);
+                                    sd[i].nzv[0] = sd[i].nzv[1] = sd[i].nzs[0] = sd[i].nzs[1] = 0.0f;
+                                    sd[i].nzk[0] = sd[i].nzk[1] = 0.0f;
+                                }
+                            }
                         }
                         const size_t so = st.put(sd);
                         stages_off.push_back(so);
@@ -2470,7 +2519,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         d.push_back(x);
                         if (guard_on) {
                             const uint32_t n_wt = (uint32_t)((M + (size_t)kTileFrames - 1) / (size_t)kTileFrames);
-                            audit_src.push_back({scratch((size_t)n_wt * sizeof(float)), n_wt, norm_of.count(vi) ? norm_of[vi] : vi, norm_of.count(vi) != 0});
+                            audit_src.push_back({scratch((size_t)n_wt * sizeof(float)), n_wt, norm_of.count(vi) ? norm_of[vi] : vi, norm_of.count(vi) != 0, 0});
                         }
                         if (norm_of.count(vi)) {   // the Normalize vertex behind the launch: its descriptor as k_norm1 would get it (mode 5)
                             const size_t ni = norm_of[vi];
@@ -2509,7 +2558,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         ptr_field(o, offsetof(BandScanDesc, ins), ins_off[first_of(vs[i])]);
                         ptr_field(o, offsetof(BandScanDesc, stages), stages_off[i]);
                         if (norm_desc_off[i] != (size_t)-1) ptr_field(o, offsetof(BandScanDesc, norm), norm_desc_off[i]);
-                        if (guard_on) scratch_field(o, offsetof(BandScanDesc, noise), audit_src[audit_src.size() - vs.size() + i].noise_off);
+                        if (guard_on) {
+                            AuditSrc& as = audit_src[audit_src.size() - vs.size() + i];
+                            as.desc_off = o;
+                            scratch_field(o, offsetof(BandScanDesc, noise), as.noise_off);
+                        }
                         cb.sync_fix.push_back({o + offsetof(BandScanDesc, ticket), cb.sync_bytes});   // {tile counter, "states read"}
                         cb.sync_bytes += 64;
                         {   // one granule per tile: the stage it went non-finite at; and the frame its right input did (k_band_chain)
@@ -2570,7 +2623,22 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         add_launch(F_QUANT, st.put(d), 1, 0u, g->n_levels);
     }
     // the guard's verdict on this chunk: one workgroup adds up what the guarded scan launches estimated (k_band_audit)
-    if (guard_on && !audit_src.empty()) {
+    const double guard_thr = (double)g->band_guard_ppb * 1e-9;
+    if (guard_on && audit_src.size() == 1 && audit_src[0].fused) {
+        // ONE guarded launch and it ends in the Normalize vertex: the launch gives the verdict itself (BandScanDesc::nz_acc)
+        const size_t o = audit_src[0].desc_off;
+        const double gout = down[audit_src[0].from].g;
+        const float scale = (float)(gout * gout / (double)M), thr2 = (float)(guard_thr * guard_thr);
+        const uint64_t hw = (uint64_t)(uintptr_t)g->guard.d_word;
+        memcpy(&st.b[o + offsetof(BandScanDesc, nz_scale)], &scale, 4);
+        memcpy(&st.b[o + offsetof(BandScanDesc, nz_thr2)], &thr2, 4);
+        memcpy(&st.b[o + offsetof(BandScanDesc, nz_host)], &hw, 8);
+        const uint32_t n_tiles4 = (uint32_t)((M + 4 * (size_t)kTileFrames - 1) / (4 * (size_t)kTileFrames));
+        cb.sync_fix.push_back({o + offsetof(BandScanDesc, nz_sync), cb.sync_bytes});   // one granule per tile, zeroed before the launch
+        cb.sync_bytes += ((size_t)n_tiles4 * 8 + 63) & ~(size_t)63;
+        g->guard.chunk_audited = true;
+    } else if (guard_on && !audit_src.empty()) {
+        g->guard.chunk_audited = true;
         std::vector<AuditDesc> ad;
         for (const AuditSrc& a : audit_src) {
             AuditDesc x{};
@@ -2596,8 +2664,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
         AuditHead hd{};
         hd.n = (uint32_t)audit_src.size();
         hd.frames = (uint32_t)M;
-        const double thr = (double)g->band_guard_ppb * 1e-9;
-        hd.thr2 = (float)(thr * thr);
+        hd.thr2 = (float)(guard_thr * guard_thr);
         hd.host_word = g->guard.d_word;
         const size_t ho = st.put(std::vector<AuditHead>{hd});
         ptr_field(ho, offsetof(AuditHead, descs), ao);
@@ -3193,8 +3260,7 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
             g->snapshot.put(g, fb);
             return 0;
         }
-        if (guarded && !audited)
-            for (const Launch& L : cb.launches) audited = audited || L.fam == F_AUDIT;
+        audited = audited || (guarded && g->guard.chunk_audited);
         const uint8_t* scratch_base = nullptr;
         if (!submit_chunk(g->arena, cb, g->stream, g->prof, g, &scratch_base, &g->host_ms[2])) {
             g->snapshot.put(g, fb);
@@ -3280,13 +3346,12 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
         for (size_t i = 0; i < P; ++i) {
             if (!nb[i]) continue;
             any = true;
-            const size_t l0 = cb.launches.size();
             if (!compile_next_chunk(b->graphs[lo + i], b->sbs[lo + i], b->fbs[lo + i], rp[i], done[i], nb[i], is_scan, advance_graph_time, 0, cb)) {
                 roll_back();
                 return 0;
             }
-            for (size_t q = l0; q < cb.launches.size(); ++q)   // (this project's chunk carries an audit: its verdict is looked at when the batch is settled)
-                if (cb.launches[q].fam == F_AUDIT && !b->graphs[lo + i]->guard.armed) { b->graphs[lo + i]->guard.armed = true; b->graphs[lo + i]->guard.audits += 1; }
+            // (this project's chunk carries an audit: its verdict is looked at when the batch is settled)
+            if (b->graphs[lo + i]->guard.chunk_audited && !b->graphs[lo + i]->guard.armed) { b->graphs[lo + i]->guard.armed = true; b->graphs[lo + i]->guard.audits += 1; }
         }
         if (!any) break;
         const uint8_t* scratch_base = nullptr;

@@ -311,6 +311,7 @@ struct Guard {
     uint32_t* d_word = nullptr;      // ... its device address
     bool armed = false;              // the last render carried an audit; its verdict has not been looked at
     bool in_redo = false;
+    bool chunk_audited = false;      // the chunk compiled last holds guarded launches (an audit launch, or the in-launch verdict)
     // the render to do again
     const td_samplebank* sb = nullptr;
     td_flowwbank* fb = nullptr;

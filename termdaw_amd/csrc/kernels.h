@@ -270,6 +270,9 @@ struct AdsrVDesc {
     uint32_t tame, pad2;
     // the vertex' gain per frame of the chunk (>= frames + 1 floats): written by k_adsr_env, read by consumers of a kind-5 term
     float* env;
+    // ... and its mean square over every 512 frames ([ceil(frames / 512)], behind the gains in the same buffer): what the
+    // guarded chain launch multiplies its estimate by where the vertex is a link (two scalar loads per stage)
+    float* env_tile;
 };
 void adsr_fill_run_consts(AdsrVDesc* d);   // host: rcp[], tame from conf / sr
 void launch_adsr_env(const AdsrVDesc* d, int n_desc, uint32_t frames, hipStream_t s);
@@ -383,13 +386,17 @@ struct BandStageDesc {          // one band-pass vertex
     const double* pk;           // [2][kScanMaxK]: (1 - gamma)^(NF * 256 * j): the weight of the tile j + 1 tiles back
     uint32_t Kw, pad3;          // (= K)
     // k_band_chain, guarded form (engine option "band_mode" 2, BandScanDesc::noise): what this vertex adds to the launch's
-    // estimate of its own deviation from the reference's f32 trajectory (DESIGN.md 3e "The guard"), {low, high} smoother --
-    // nzv: 0.25 K0 / (gamma (2 - gamma)), the variance a unit-level state picks up from independent roundings of the
-    // recurrence's sum, seen through the 0.5 of `cut`; nzs: 0.5 * 2^-24 / gamma, the offset at which an f32 state of unit
-    // level parks short of a (nearly) constant input; nzg: the static gain between this vertex' recurrence and the next
-    // stage's input (its own pan / gain and the links', largest channel amplitude; envelope links multiply in per lane)
+    // estimate of its own deviation from the reference's f32 trajectory (DESIGN.md 3e "The guard"), {low, high} smoother, every
+    // coefficient already multiplied by the STATIC gain G between this vertex' recurrence and the launch's last stage (own pan /
+    // gain, the links', every later vertex' -- largest channel amplitude; envelope links multiply in per lane in the kernel) --
+    // nzv: G^2 0.25 K0 / (gamma (2 - gamma)), the variance a unit-level state picks up from independent roundings of the
+    // recurrence's sum, seen through the 0.5 of `cut`; nzs: G 0.5 2^-24 / gamma, the offset at which an f32 state of unit
+    // level parks short of a (nearly) constant input; nzk: 4 * 2^-23 / gamma -- the state counts as parked while
+    // |x - y| < nzk |y| (|gamma (x - y)| below 4 ulp(y)); nzk[1] = 0: the faster smoother's test is skipped (both see the same
+    // input: when the slower one is parked so is the faster, at a level equal and an offset smaller by gamma_low / gamma_high)
     float nzv[2], nzs[2];
-    float nzg, pad4;
+    float nzk[2];
+    const float* envt;          // the envelope link behind this vertex, if any: AdsrVDesc::env_tile (at most one Adsr vertex per hop)
 };
 struct BandScanDesc {
     const InTerm* ins;          // the (first) vertex' input terms, in connect() order
@@ -422,7 +429,14 @@ struct BandScanDesc {
     // offset^2) of the launch's deviation from the reference at the launch's output (behind the fused Normalize vertex where
     // there is one); nullptr: not guarded (band_mode 1).  Read by k_band_audit at the end of the submission.
     float* noise;
-    float nz_end, pad5;         // the static gain behind the last stage that the kernel applies itself (fused Normalize vertex' pan / gain)
+    float nz_end;               // the static gain behind the last stage that the kernel applies itself (fused Normalize vertex' pan / gain)
+    // ... or, where this launch is the graph's ONLY guarded one and carries the Normalize vertex itself, the verdict right
+    // here, without k_band_audit: every tile leaves its energy as one granule, the tile with the last ticket gathers them,
+    // compares  sum x nz_scale (= (static gain to the output)^2 / frames)  with nz_thr2 and writes the host words
+    float nz_scale;
+    unsigned long long* nz_sync;   // [n_tiles] granules, zeroed before the launch; nullptr: leave the wave-tiles' energies in `noise`
+    uint32_t* nz_host;          // AuditHead::host_word
+    float nz_thr2, pad5;
 };
 // The guard's verdict (engine option "band_mode" 2): one workgroup per graph adds up what its scan launches estimated, carried to
 // the graph's output -- a static gain per launch (the host walks the graph: pan / gain of everything downstream) and, where the

@@ -1837,7 +1837,8 @@ TD_DEV void adsr_env_block(const AdsrVDesc& d, uint32_t bx, uint32_t M) {
     if (threadIdx.x == 0u) adsr_piece_table(adsr_run_consts(d), ptab);
     __syncthreads();
     const uint32_t m0 = (bx * kThreads + threadIdx.x) * (uint32_t)kEnvRun;
-    if (m0 >= M) return;
+    float sq = 0.0f;   // sum of the squared gains of the lane's frames (-> AdsrVDesc::env_tile)
+    if (m0 < M) {
     float* const out = d.env;
     const uint32_t mlast = min(m0 + (uint32_t)kEnvRun - 1u, M - 1u);
     const uint32_t it = find_interval(d.tab, m0);
@@ -1866,12 +1867,25 @@ TD_DEV void adsr_env_block(const AdsrVDesc& d, uint32_t bx, uint32_t M) {
                 const float av = fmaxf(pvel, gvel) * maxmul + fminf(pvel, gvel) * minmul;
                 v[e] = lerpf(1.0f, av, d.wet);
             }
+            sq += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             gstore4(out + m0 + q, make_float4(v[0], v[1], v[2], v[3]));
         }
     } else {
 #pragma unroll 1
-        for (uint32_t m = m0; m <= mlast; ++m) out[m] = adsr_vel(d, m);
+        for (uint32_t m = m0; m <= mlast; ++m) {
+            const float v = adsr_vel(d, m);
+            sq += v * v;
+            out[m] = v;
+        }
     }
+    }
+    // one wave = 512 consecutive frames = half a wave-tile of k_band_chain: the table holds the MEAN SQUARE of every half
+    static_assert(kEnvRun * 64 * 2 == kTileFrames, "two waves of k_adsr_env cover one wave-tile");
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sq += __shfl_xor(sq, off, 64);
+    const uint32_t w0 = (bx * kThreads + (threadIdx.x & ~63u)) * (uint32_t)kEnvRun;   // the wave's first frame
+    if ((threadIdx.x & 63u) == 0u && w0 < M && d.env_tile)
+        d.env_tile[w0 / (uint32_t)(kEnvRun * 64)] = sq / (float)min((uint32_t)(kEnvRun * 64), M - w0);
 }
 __global__ __launch_bounds__(kThreads) void k_adsr_env(const AdsrVDesc* __restrict__ descs, uint32_t M) {
     adsr_env_block(descs[blockIdx.y], blockIdx.x, M);
@@ -3236,7 +3250,6 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
 template <int TMODE, bool GUARD>
 __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* __restrict__ descs, uint32_t M, uint32_t chains_in_x) {
     constexpr int NF = 16, NP = NF / 2;
-    constexpr float kSlowUlps = 4.0f * 1.1920929e-07f;   // |gamma (x - y)| < 4 ulp(y) (ulp <= 2^-23 |y|): the state is parked
     constexpr uint32_t WT = (uint32_t)NF * 64u;         // frames per wave-tile
     // Several chains in one launch (a batch of projects): the chain index is the FAST grid dimension, so the workgroups
     // the device holds at a time belong to all of them -- chains are independent of each other and each one's tiles move in
@@ -3366,13 +3379,27 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     // What a stage needs before its first instruction -- the two gammas, the table pointers, the first envelope link -- is
     // read ONE STAGE AHEAD, in one batch of scalar loads: read where it is used, behind `&&` and `if`, it was five dependent
     // scalar-cache round trips in front of every stage's recurrence.
-    struct StageHead { float lgam, hgam; const double* pw; const double* pk; uint32_t n_post; const float* env0; const float* env1; };
+    // (GUARD: the estimate's seven coefficients too -- they sit on a cache line of their own at the descriptor's end, and read
+    // where they are used they were a scalar-cache MISS in front of every stage's output phase: 0.3 us per stage)
+    struct StageHead { float lgam, hgam; const double* pw; const double* pk; uint32_t n_post; const float* env0; const float* env1;
+                       float nzv0, nzv1, nzs0, nzs1, nzk0, nzk1; const float* envt; };
     auto head_of = [&](uint32_t s) {
         const BandStageDesc TD_CONST* const q = stages + s;
-        return StageHead{q->lgamma, q->hgamma, q->pw, q->pk, q->n_post, q->post[0].env, q->post[1].env};
+        if (GUARD) return StageHead{q->lgamma, q->hgamma, q->pw, q->pk, q->n_post, q->post[0].env, q->post[1].env,
+                                    q->nzv[0], q->nzv[1], q->nzs[0], q->nzs[1], q->nzk[0], q->nzk[1], q->envt};
+        return StageHead{q->lgamma, q->hgamma, q->pw, q->pk, q->n_post, q->post[0].env, q->post[1].env, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr};
     };
     StageHead head = head_of(0u);
-    float nz_var = 0.0f, nz_off = 0.0f;   // (GUARD) the lane's estimate: variance and offset of the deviation at its frames
+    // (GUARD) the lane's estimate: variance (one accumulator per smoother, added up at the end) and offset of the deviation at
+    // its frames.  Every VALU instruction of this loop costs ~12 ticks of a stage's ~6 900 (three waves of a SIMD move in
+    // lockstep), so the estimate is pared down: the static gains between a vertex and the chain's end are folded into its
+    // coefficients by the host (only the envelope links' gain is applied here, in the stages that have one), the pair of
+    // smoothers is one packed operand, and the parked test of the faster smoother is dropped where the slower one's
+    // offset dwarfs it (host: nzk[1] 0).
+    f32x2 nz_v2 = {0.0f, 0.0f};
+    float nz_off = 0.0f;
+    const float* nz_envt = nullptr;   // the envelope link whose gain over this wave-tile nz_e2 (mean square) / nz_e1 (RMS) hold
+    float nz_e2 = 1.0f, nz_e1 = 1.0f;
     for (uint32_t s = 0; s < n_stages; ++s) {
         const BandStageDesc TD_CONST* const sp = stages + s;
         stamp(s, 0u);
@@ -3520,16 +3547,19 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         const f32x2 c = {(float)__builtin_fma(pwl, __builtin_fma(awp0, carry_s[0], xw0), e0),
                          (float)__builtin_fma(pwh, __builtin_fma(awp2, carry_s[1], xw2), e2)};
         const f32x2 TD_CONST* const pn = (const f32x2 TD_CONST*)(const TD_CONST char*)sp->pn;
-        if (GUARD) {   // what this vertex' two smoothers add, from the level of the lane's entry state (host: nzv / nzs 0 for a constant chain)
+        // what this vertex' two smoothers add, from the level of the lane's entry state (host: all 0 for a constant chain, and
+        // for every stage but the first of a run of identical filters, which stands for the run)
+        if (GUARD && (head.nzk0 != 0.0f || head.nzv0 != 0.0f || head.nzv1 != 0.0f)) {   // (uniform)
+            asm volatile("");
             const float x0 = x[0].x;
-            const float al = fabsf(c.x), ah = fabsf(c.y);
-            nz_var = __builtin_fmaf(sp->nzv[0], c.x * c.x, __builtin_fmaf(sp->nzv[1], c.y * c.y, nz_var));
-            const float pl = fabsf(lgam * (x0 - c.x)) < kSlowUlps * al ? sp->nzs[0] * al : 0.0f;
-            const float ph = fabsf(hgam * (x0 - c.y)) < kSlowUlps * ah ? sp->nzs[1] * ah : 0.0f;
-            nz_off += pl + ph;
-            const float gq = sp->nzg;   // ... and on through the vertex' own pan / gain and the static part of the links
-            nz_var *= gq * gq;
-            nz_off *= gq;
+            nz_v2 = __builtin_elementwise_fma(f32x2{head.nzv0, head.nzv1}, c * c, nz_v2);
+            const float al = fabsf(c.x);
+            nz_off = __builtin_fmaf(fabsf(x0 - c.x) < head.nzk0 * al ? head.nzs0 : 0.0f, al, nz_off);   // parked: |gamma (x - y)| below 4 ulp(y)
+            if (head.nzk1 != 0.0f) {   // (uniform)
+                asm volatile("");
+                const float ah = fabsf(c.y);
+                nz_off = __builtin_fmaf(fabsf(x0 - c.y) < head.nzk1 * ah ? head.nzs1 : 0.0f, ah, nz_off);
+            }
         }
         // ---- output (extensions.rs:682-687 with cut_mul 0, pass_mul 1), then the vertex' pan / gain
         const bool lo_on = lgam != 0.0f, hi_on = hgam != 0.0f;
@@ -3600,17 +3630,26 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                         x[2 * q] = make_float4(a.x * e.x, a.y * e.x, a.z * e.y, a.w * e.y);
                         x[2 * q + 1] = make_float4(b.x * e.z, b.y * e.z, b.z * e.w, b.w * e.w);
                     }
-                    if (GUARD) {   // (the envelope's gain at the lane's first frame; 0 beyond the chunk's end)
-                        const float e0 = fabsf(envv[0].x);
-                        nz_var *= e0 * e0;
-                        nz_off *= e0;
-                    }
                 }
                 pan_gain(sp->post[p].pg.l_amp, sp->post[p].pg.r_amp, sp->post[p].pg.gain, sp->post[p].pg.flags);
             }
             if (tail) {
 #pragma unroll
                 for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
+            }
+            // (GUARD) the estimate goes through the envelope link like the frames do -- by the link's RMS gain over this wave's
+            // 1 024 frames, ONE scalar load (AdsrVDesc::env_tile).  (Taken from the per-frame gains the link loop above holds in
+            // registers, the three instructions cost the loop 0.25 us per stage, wherever they were put.)
+            if (GUARD && head.envt) {
+                if (head.envt != nz_envt) {   // (uniform; the links of a chain mostly share ONE envelope: read once, like the power tables)
+                    nz_envt = head.envt;
+                    const float TD_CONST* const et = (const float TD_CONST*)(const TD_CONST char*)head.envt;
+                    const uint32_t h0 = 2u * (uint32_t)__builtin_amdgcn_readfirstlane((int)wt);   // (the table holds mean squares per 512 frames)
+                    nz_e2 = wt0 + WT / 2u < M ? 0.5f * (et[h0] + et[h0 + 1u]) : et[h0];
+                    nz_e1 = __builtin_sqrtf(nz_e2);
+                }
+                nz_v2 *= f32x2{nz_e2, nz_e2};
+                nz_off *= nz_e1;
             }
         }
         head = next_head;
@@ -3624,6 +3663,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     // quantiser when it is the output) the tile's maximum goes out beside that granule and ONE gather brings both in.
     __shared__ uint32_t pz[kThreads / 64], pt[kThreads / 64];
     __shared__ float nwm[kThreads / 64], npm[kThreads / 64];
+    __shared__ float nz_w[kThreads / 64], nz_p[kThreads / 64];   // (GUARD) the waves' energies; the gather's partial sums
     const float qnan = __uint_as_float(0x7FC00000u);
     // (the end phase computes its frame indices and addresses afresh, from a lane number and descriptor pointers the compiler
     // cannot see through: shared with the input phase's identical expressions they were kept -- i.e. spilled to scratch, the
@@ -3739,10 +3779,35 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         const float r = 1.0f / run;
         if (GUARD) {   // the estimate goes through the Normalize vertex like the frames do: 1 / max, its pan / gain (largest channel)
             const float gq = fabsf(r) * dl->nz_end;
+            const float nz_var = nz_v2.x + nz_v2.y;
             float e = mf_e < M ? (float)NF * __builtin_fmaf(nz_off * gq, nz_off * gq, nz_var * gq * gq) : 0.0f;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
-            if (lane_e == 0u && wt0 < M) dl->noise[wt] = e;
+            unsigned long long* const nzs = dl->nz_sync;
+            if (nzs) {
+                // The graph's only guarded launch: the verdict right here (kernels.h BandScanDesc::nz_sync).  Every tile leaves its
+                // energy as ONE granule -- a plain tagged store: 2 813 atomic adds to one word took 60 us of the launch -- and the
+                // tile with the last ticket, which every other ticket holder is running ahead of or beside, gathers them.
+                if (lane_e == 0u) nz_w[wave] = (wt0 < M && e == e) ? e : 0.0f;   // (NaN: a tile the reference turns NaN as well)
+                __syncthreads();
+                const float mine = (nz_w[0] + nz_w[1]) + (nz_w[2] + nz_w[3]);
+                if (threadIdx.x == 0u) granule_store(nzs + tile, __float_as_uint(mine));
+                if (tile + 1u == dl->n_tiles) {
+                    float sum = 0.0f;
+                    (void)for_lower_granules(nzs, tile, 0xFFFFFFFFu, [&sum](uint32_t, uint32_t v) { sum += __uint_as_float(v); });
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                    if (lane_e == 0u) nz_p[wave] = sum;
+                    __syncthreads();
+                    if (threadIdx.x == 0u) {
+                        const float ms = (((nz_p[0] + nz_p[1]) + (nz_p[2] + nz_p[3])) + mine) * dl->nz_scale;
+                        __hip_atomic_store((gu32)(TD_GLOBAL char*)(dl->nz_host + 1), __float_as_uint(sqrtf(ms)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (!(ms <= dl->nz_thr2)) __hip_atomic_store((gu32)(TD_GLOBAL char*)dl->nz_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    }
+                }
+            } else if (lane_e == 0u && wt0 < M) {
+                dl->noise[wt] = e;
+            }
         }
         PanGain npg;
         npg.l_amp = ndl->pg.l_amp; npg.r_amp = ndl->pg.r_amp; npg.gain = ndl->pg.gain; npg.flags = ndl->pg.flags;
@@ -3766,7 +3831,7 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         return;
     }
     if (GUARD) {
-        float e = mf_e < M ? (float)NF * __builtin_fmaf(nz_off, nz_off, nz_var) : 0.0f;
+        float e = mf_e < M ? (float)NF * __builtin_fmaf(nz_off, nz_off, nz_v2.x + nz_v2.y) : 0.0f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
         if (lane_e == 0u && wt0 < M) dl->noise[wt] = e;

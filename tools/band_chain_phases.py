@@ -26,7 +26,7 @@ def project(seconds=60.0):
 if __name__ == "__main__":
     p = project(float(os.environ.get("SECONDS_", "60")))
     sb, fb, g = p.build(api)
-    g.set_option("band_mode", 1)
+    g.set_option("band_mode", int(os.environ.get("MODE", "1")))   # (2: the guarded instantiation)
     def render():
         g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
         return g.render_all(sb, fb, p.cs, 16)
