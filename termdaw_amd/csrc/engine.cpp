@@ -1545,7 +1545,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
     // (event tables, conf, wet, flags) of the chunk -- the 84 envelope stages of a deep chain share one -- filled by
     // k_adsr_env at the vertex' own level, held until the chunk has been compiled
     std::map<std::string, float*> env_of_key;
-    const size_t env_tile_off = (M + 4 + 63) & ~(size_t)63;   // (floats; the edge buffer behind it is 2 x cap_frames >= 2 M floats long)
+    std::map<const float*, size_t> env_tile_at;   // envelope buffer -> scratch offset of its mean squares per 512 frames (AdsrVDesc::env_tile)
     std::vector<float*> env_of(nv, nullptr);
     std::vector<float2*> env_bufs;
     auto add_launch = [&](int fam, size_t off, int n, uint32_t aux, int level) {
@@ -1787,11 +1787,16 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                 x.conf = v.conf;
                 adsr_fill_run_consts(&x);
                 x.env = env_of[vi];
-                x.env_tile = env_of[vi] + env_tile_off;   // (the buffer holds 2 x cap_frames floats: gains, then the mean squares per 512 frames)
                 d.push_back(x);
             }
             const size_t off = st.put(d);
             for (size_t i = 0; i < envs.size(); ++i) {
+                if (guard_on) {   // (the guarded chain launches multiply their estimate by the link's gain: kernels.h AdsrVDesc::env_tile)
+                    const size_t so = cb.scratch_bytes;
+                    cb.scratch_bytes += (((M + 511) / 512 + 1) * sizeof(float) + 255) & ~(size_t)255;
+                    env_tile_at[env_of[envs[i]]] = so;
+                    cb.scratch_fix.push_back({off + i * sizeof(AdsrVDesc) + offsetof(AdsrVDesc, env_tile), so});
+                }
                 const size_t t = off + i * sizeof(AdsrVDesc) + offsetof(AdsrVDesc, tab);
                 const auto tf = [&](size_t field_off, size_t o2) {
                     const uint64_t p = (uint64_t)(uintptr_t)(vt[envs[i]].dev + o2);
@@ -2380,6 +2385,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                         const ScanPlan& sp0 = scan_plan[piece[0]];
                         std::vector<BandStageDesc> sd;
                         std::vector<double> stage_gain;   // (guard) per stage: its own pan / gain and the static part of the links behind it
+                        std::vector<const float*> stage_env;   // ... and the envelope link behind it, if any
                         for (size_t i = 0; i < piece.size(); ++i) {
                             const Vertex& v = g->vertices[piece[i]];
                             ScanPlan& sp = scan_plan[piece[i]];
@@ -2424,6 +2430,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 sp.pk_off = ik->second;
                             }
                             double link_gain = own_gain(v);
+                            const float* stage_env_link = nullptr;
                             if (i + 1 < piece.size() || norm_of.count(vi)) {   // the links to the next vertex of the chain / to the Normalize vertex
                                 const std::vector<ChainLink>& links = i + 1 < piece.size() ? links_before[piece[i + 1]] : links_after[vi];
                                 x.n_post = (uint32_t)links.size();
@@ -2432,7 +2439,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                     x.post[l].env = links[l].adsr ? env_of[links[l].vertex] : nullptr;
                                     x.post[l].pg = make_pg(lv2.gain, lv2.angle);
                                     link_gain *= own_gain(lv2);
-                                    if (links[l].adsr && guard_on) x.envt = env_of[links[l].vertex] + env_tile_off;   // (at most one Adsr vertex per hop)
+                                    if (links[l].adsr && guard_on) stage_env_link = env_of[links[l].vertex];   // (at most one Adsr vertex per hop)
                                 }
                             }
                             if (guard_on) {   // (kernels.h BandStageDesc::nzv ..: DESIGN.md 3e "The guard")
@@ -2448,6 +2455,7 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                                 // and an offset smaller by gamma_low / gamma_high -- below 5 % the faster one's test is not run
                                 if (v.lgamma != 0.0f && v.hgamma != 0.0f && (double)v.lgamma < 0.05 * (double)v.hgamma) { x.nzk[1] = 0.0f; x.nzs[1] = 0.0f; }
                                 stage_gain.push_back(link_gain);
+                                stage_env.push_back(stage_env_link);
                             }
                             sd.push_back(x);
                         }
@@ -2499,6 +2507,11 @@ static int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwban
                             if (chain_of.count(vi)) ptr_field(o, offsetof(BandStageDesc, pk), scan_plan[piece[i]].pk_off);
                             cb.sync_fix.push_back({o + offsetof(BandStageDesc, sync), cb.sync_bytes});
                             cb.sync_bytes += (size_t)sp0.n_tiles * 128;   // 8 granules per tile, or 4 per wave-tile (chain)
+                            if (guard_on && stage_env[i]) {
+                                const auto et = env_tile_at.find(stage_env[i]);
+                                if (et == env_tile_at.end()) return fail("termdaw_amd: internal: the guard lost an envelope buffer");
+                                cb.scratch_fix.push_back({o + offsetof(BandStageDesc, envt), et->second});
+                            }
                         }
                         BandScanDesc x{};
                         x.out = g->vbuf[vi];

@@ -20,9 +20,15 @@ if "--jobs" in sys.argv:
     jobs = int(sys.argv[sys.argv.index("--jobs") + 1])
     rest = [a for a in sys.argv[3:] if a != "--jobs" and a != str(jobs)]
     step = (hi_seed - lo_seed + jobs - 1) // jobs
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(a), str(min(a + step, hi_seed))] + rest)
+    logdir = os.environ.get("TD_SOAK_LOGDIR")   # (per-job stderr files: with TD_SOAK_VERBOSE=1 the last line is the seed a job died on)
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), str(a), str(min(a + step, hi_seed))] + rest,
+                              stderr=open(os.path.join(logdir, "job_%d.err" % a), "w") if logdir else None)
              for a in range(lo_seed, hi_seed, step)]
-    sys.exit(max(p.wait() for p in procs))
+    rcs = [p.wait() for p in procs]
+    for a, rc in zip(range(lo_seed, hi_seed, step), rcs):
+        if rc not in (0, 1):
+            print("seeds", a, min(a + step, hi_seed), "DIED with exit code", rc, flush=True)
+    sys.exit(max(abs(rc) for rc in rcs))
 sinf = len(sys.argv) > 3 and sys.argv[3] in ("sinf", "scan", "guard")
 scan_mode = len(sys.argv) > 3 and sys.argv[3] in ("scan", "guard")
 guard_mode = len(sys.argv) > 3 and sys.argv[3] == "guard"
@@ -30,6 +36,8 @@ bad, rejected = [], 0
 audits = redos = renders = 0
 worst = (0.0, -1)
 for seed in range(lo_seed, hi_seed):
+    if os.environ.get("TD_SOAK_VERBOSE"):
+        print("seed", seed, file=sys.stderr, flush=True)
     p = F.random_project(seed, allow_sinf=sinf)
     try:
         ob = p.build(oracle)
@@ -44,6 +52,8 @@ for seed in range(lo_seed, hi_seed):
     gb = p.build(api)
     if scan_mode:
         gb[2].set_option("band_mode", 2 if guard_mode else 1)
+    for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=norm_debug=1
+        gb[2].set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for scan in (False, True, False):
         gp, gf = p.render(api, built=gb, scan=scan)
         op, of = p.render(oracle, built=ob, scan=scan)
