@@ -583,7 +583,7 @@ class State:
         return bool(ok)
 
     def set_option(self, key, value):
-        """Engine option of the State's graph; a State defaults to band_mode 1 (scan), set_option("band_mode", 0) = exact."""
+        """Engine option of the State's graph; a State defaults to band_mode 2 (the scan under the guard), set_option("band_mode", 0) = exact."""
         _check(lib().td_state_set_option(self.h, key.encode(), int(value)))
 
     def scan_exact(self):
