@@ -248,3 +248,17 @@ def test_the_complete_rust_binding_follows_the_header():
     declared = set(re.findall(r"\b(td_[a-z0-9_]+)\s*\(", header))
     bound = set(re.findall(r"pub fn (td_[a-z0-9_]+)\(", out))
     assert declared == bound and len(bound) > 90
+
+
+def test_headline_block_is_the_generated_one():
+    """README.md and DESIGN.md quote ONE end-of-round headline: the block tools/headline.py makes of the committed driver-form
+    bench line (profiles/r05_bench_k20.json).  A hand-edited or stale figure fails here."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("headline", os.path.join(ROOT, "tools", "headline.py"))
+    h = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(h)
+    if not os.path.exists(h.SRC):
+        pytest.skip("no committed r05 driver-form bench line yet")
+    want = h.block()
+    for name in ("README.md", "DESIGN.md"):
+        assert h.current(os.path.join(ROOT, name)) == want, name

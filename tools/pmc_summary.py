@@ -73,6 +73,7 @@ if __name__ == "__main__":
     for cfg, d in (("config2", "gpurun_out/pmc_%s_fused_VALU" % tag), ("config2_nofuse", "gpurun_out/pmc_%s_nofuse_VALU" % tag),
                    ("config3", "gpurun_out/pmc_%s_c3_VALU" % tag), ("config4", "gpurun_out/pmc_%s_c4_VALU" % tag),
                    ("config3_scan", "gpurun_out/pmc_%s_c3scan_VALU" % tag), ("config4_scan", "gpurun_out/pmc_%s_c4scan_VALU" % tag),
+                   ("config3_guard", "gpurun_out/pmc_%s_c3guard_VALU" % tag), ("config4_guard", "gpurun_out/pmc_%s_c4guard_VALU" % tag),
                    # engine option one_grid_sources 0: every source family its own launch (k_synth / k_sampsyn / k_adsr_env by themselves)
                    ("config3_separate", "gpurun_out/pmc_%s_c3sep_VALU" % tag), ("config4_separate", "gpurun_out/pmc_%s_c4sep_VALU" % tag)):
         rows = {}

@@ -28,6 +28,12 @@ for c in c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}scan -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}scan.log 2>&1
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}scan_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
 done
+# ... under the guard (band_mode 2, the front-end's default: k_band_chain<.., true>, the verdict in the launch)
+export TD_OPTS=band_mode=2
+for c in c3 c4; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}guard -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}guard.log 2>&1
+  rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}guard_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
+done
 # ... and with every source family launched on its own (engine option one_grid_sources 0): k_synth / k_sampsyn / k_adsr_env by themselves
 export TD_OPTS=one_grid_sources=0
 for c in c3 c4; do
