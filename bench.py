@@ -302,8 +302,6 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     for _ in range(steps):
         step()
     batch.mark(1)
-    batch.sync()                             # this rank's K steps are done (the exchange below waits for the stream anyway)
-    t_done = time.perf_counter()
     # The closing barrier.  With more than one rank it IS the path's only exchange -- one all-reduce(max) of the peak table on
     # device memory, which no rank leaves before every rank has contributed, i.e. has finished its K steps (each contributes
     # only after synchronising its engine stream) -- followed by torch.cuda.synchronize(): a second collective (dist.barrier)
@@ -316,11 +314,15 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
         barrier()
     t_end = time.perf_counter()
     dt = t_end - t0
-    time_batch.last_ranks = {"render_ms": (t_done - t0) * 1e3, "exchange_ms": (t_end - t_done) * 1e3, "dt_ms": dt * 1e3, "start_wall": start_wall}
+    time_batch.last_ranks = {"dt_ms": dt * 1e3, "start_wall": start_wall}
     peaks = exchange.host()                  # (the report's copy of the table: outside the timed region, like the PCM it stays in HBM)
     ktimes = batch.kernel_times()
     batch.set_profiling(0)
     marked = batch.marked_ms()
+    # this rank's own K steps: the time between the two marks on the engine's stream (HIP events: no host synchronisation of its
+    # own inside the region); what is left of the region is the closing exchange -- the collective plus the wait for the slowest rank
+    time_batch.last_ranks["render_ms"] = marked if marked > 0 else dt * 1e3
+    time_batch.last_ranks["exchange_ms"] = max(0.0, dt * 1e3 - time_batch.last_ranks["render_ms"])
     if by_marks and marked > 0:
         (fam, (_, per_step)), = fam0.items()
         ktimes = {fam: (marked, steps * per_step)}
@@ -636,8 +638,6 @@ def compact(o):
                 rr[k] = r[k]
         if "l2_mall_split" in r:
             rr["l2_mall_split"] = {"floor_ms": r["l2_mall_split"]["floor_ms"], "l2_hit": r["l2_mall_split"]["l2_hit_rate_profiled"]}
-        if "valu_profiled" in r:
-            rr["SQ_INSTS_VALU_profiled"] = round(r["valu_profiled"].get("SQ_INSTS_VALU", 0))
         rr["note"] = NOTES + "#roofline"
         c["roofline"] = rr
     if "cpu_baseline" in o:
@@ -659,7 +659,12 @@ def compact(o):
     if "pcie_inclusive" in o:
         c["pcie_inclusive"] = {k: o["pcie_inclusive"][k] for k in ("ms_per_render", "Msamples_per_s")}
     if "e2e" in o:
-        c["e2e"] = o["e2e"]
+        e = o["e2e"]
+        c["e2e"] = {k: e[k] for k in ("projects", "render_only_ms_per_project", "pinned_d2h_GBs_measured", "file_bytes_each", "error") if k in e}
+        if "render_d2h" in e:
+            c["e2e"]["render_d2h"] = {k: e["render_d2h"][k] for k in ("ms_per_project", "d2h_GBs", "d2h_frac_of_pinned_rate") if k in e["render_d2h"]}
+        if "render_d2h_wav" in e:
+            c["e2e"]["render_d2h_wav"] = {k: e["render_d2h_wav"][k] for k in ("ms_per_project", "writers", "files", "dir", "ms_per_project_by_form") if k in e["render_d2h_wav"]}
     if "cpu_baseline_all_cores" in o:
         a = o["cpu_baseline_all_cores"]
         c["cpu_all_cores"] = {"value": a["value"], "cores": a["cores"], "gpu_over": o.get("gpu_over_cpu_all_cores")}
@@ -673,12 +678,10 @@ def compact(o):
             if "guard" in x:
                 row["guard"] = {"redos": x["guard"]["redos"], "est": float("%.3g" % x["guard"]["max_est"])}
             ks = x.get("kernels") or []
-            row["kernels"] = {k["kernel"]: k["ms_per_render"] for k in ks[:3]}
+            row["kernels"] = {k["kernel"]: k["ms_per_render"] for k in ks[:2]}
             b = x.get("bound") or {}
             if b:
                 row["bound"] = {"kind": b.get("kind"), "floor_ms": b.get("floor_ms"), "frac": b.get("frac")}
-                if b.get("SQ_INSTS_VALU_profiled"):
-                    row["bound"]["insts"] = round(b["SQ_INSTS_VALU_profiled"])
             if x.get("batch"):
                 row["batch_ms_per_project"] = {str(e2["projects"]): e2.get("ms_per_project", e2.get("error")) for e2 in x["batch"]}
             rows.append(row)
@@ -686,7 +689,8 @@ def compact(o):
         c["configs_note"] = NOTES + "#configs"
     elif cf:
         c["configs"] = cf
-    c["rooflines"] = [{k: r2.get(k) for k in ("kernel", "avg_ms", "launches", "achieved", "peak", "frac", "bytes_per_frame") if k in r2} for r2 in o.get("rooflines", [])]
+    if len(o.get("rooflines", [])) > 1:   # (one family per step: `roofline` is all there is to say)
+        c["rooflines"] = [{k: r2.get(k) for k in ("kernel", "avg_ms", "launches", "achieved", "peak", "frac", "bytes_per_frame") if k in r2} for r2 in o.get("rooflines", [])]
     for k in ("kernel_timing_every", "marked_ms", "host_ms_per_step", "peak_table_entries", "device_bytes", "vertex_frames_per_s"):
         if k in o:
             c[k] = o[k]

@@ -216,7 +216,7 @@ def test_bench_line_compact_form_fits_the_drivers_tail():
     compacts to well under the 6 KB the driver's stored tail holds, with the derived-mode entries ahead of `configs`."""
     import json
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_full.json")))
     full["config"]["normalize_id"] = "one launch"
     full["config"]["parallelism_id"] = "project p on rank p mod N; one RCCL all-reduce(max) of the 1-entry peak table"
     c = bench.compact(full)
