@@ -440,7 +440,17 @@ def other_configs(api, workloads, ub, chain_ns):
         elif dom[0] in ("k_synth", "k_sources", "k_band_scan"):
             if insts and issue_ns > 0:
                 floor = insts * issue_ns / SIMDS * 1e-6
+                # ... priced by instruction class instead of at the fastest one: the average issue time of the kernel's loop
+                # instructions from its ISA (tools/isa_mix.py -> profiles/<tag>_isa_mix.json: packed f32, compares / selects /
+                # min / max / conversions 1.75 ns, f64 1.85, transcendentals 3.4 against 1.06 for plain f32 add / mul / fma)
+                mix = (profiled("isa_mix") or {}).get(((valu.get(vkey, {}).get(dom[0]) or {}).get("rocprof_kernel") or "").replace("tdk::", ""))
+                fastest = {"floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4)}
+                if mix:
+                    floor = insts * mix["avg_ns_per_valu"] / SIMDS * 1e-6
                 entry["bound"] = {"kind": "f32 VALU issue", "floor_ms": round(floor, 4), "frac": round(floor / dom[3], 4),
+                                  "priced": ("by instruction class: %.3f ns per VALU instruction (profiles/%s_isa_mix.json)" % (mix["avg_ns_per_valu"], PROFILE_TAG)) if mix
+                                            else "every instruction at the fastest class",
+                                  "at_fastest_class": fastest,
                                   "SQ_INSTS_VALU_profiled": insts, "profile": "profiles/%s_valu.json" % PROFILE_TAG,
                                   "ns_per_fma_per_simd_measured": round(issue_ns, 3),
                                   "note": "wave-level VALU instructions per launch (PMC, committed profile) x the issue time of the FASTEST class "

@@ -3389,6 +3389,8 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
                                     q->nzv[0], q->nzv[1], q->nzs[0], q->nzs[1], q->nzk[0], q->nzk[1], q->envt};
         return StageHead{q->lgamma, q->hgamma, q->pw, q->pk, q->n_post, q->post[0].env, q->post[1].env, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, nullptr};
     };
+    const float* env_kept = nullptr;                                  // the envelope whose gains for this lane's frames sit in env_row
+    float4* const env_row = xt + tid * (uint32_t)(NP + 1);           // (the lane's own row of the staging: one pad word per row, conflict-free)
     StageHead head = head_of(0u);
     // (GUARD) the lane's estimate: variance (one accumulator per smoother, added up at the end) and offset of the deviation at
     // its frames.  Every VALU instruction of this loop costs ~12 ticks of a stage's ~6 900 (three waves of a SIMD move in
@@ -3449,10 +3451,24 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
         float4 envv[NP / 2];
         // (wave 0 issues them BEHIND its serial section: in front of it they are four more loads the hand-off's own loads queue
         // behind -- vmcnt counts in order: 0.331 -> 0.321 ms)
+        // The links of a chain mostly share ONE envelope (BASELINE config 4: all 84): the lane's sixteen gains are read from
+        // global memory when the buffer changes and kept in the lane's own row of the staging area -- idle between the input
+        // phase and the end phase -- from where every later stage takes them with four LDS reads: no vector-memory loads (and
+        // none of the in-order waits they put in front of the hand-off's own loads) in the stage loop.
         auto load_env = [&]() {
+            if (env_pre && env_pre == env_kept) {   // (uniform)
 #pragma unroll
-            for (int q = 0; q < NP / 2; ++q)
-                envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < NP / 2; ++q) envv[q] = env_row[q];
+            } else {
+#pragma unroll
+                for (int q = 0; q < NP / 2; ++q)
+                    envv[q] = (env_pre && mf + 4u * (uint32_t)q < M) ? gload4(env_pre + mf + 4u * (uint32_t)q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (env_pre) {
+#pragma unroll
+                    for (int q = 0; q < NP / 2; ++q) env_row[q] = envv[q];
+                    env_kept = env_pre;
+                }
+            }
         };
         if (wave != 0u) load_env();
         double xw0 = 0.0, xw2 = 0.0, awp0 = 1.0, awp2 = 1.0;   // the tile's response up to this wave; a_wave^wave
