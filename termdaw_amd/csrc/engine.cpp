@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <condition_variable>
 #include <atomic>
 #include <thread>
 #include <limits>
@@ -2205,6 +2206,8 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
     std::vector<std::string> errs(nw);
     std::vector<double> first_write(nw, -1.0), last_write(nw, 0.0);
     std::atomic<size_t> queued{0};   // groups whose copy has been enqueued (their events are recorded)
+    std::mutex q_mu;                 // (writers sleep on q_cv until their group is queued: up to 96 of them spinning on `queued` took
+    std::condition_variable q_cv;    //  host cores from the thread that enqueues the renders)
     const int dev = b->device;
     // a file is written in `parts` slices by as many threads (pwrite at their own offsets): the last group's files -- nothing
     // renders or copies under them any more -- are then finished by all the writers, not by one thread per file
@@ -2216,9 +2219,10 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
             if (task >= P * parts) return;
             const size_t i = task / parts, part = task % parts;
             const size_t gi = i / G;
-            while (queued.load(std::memory_order_acquire) <= gi) {
-                if (failed.load()) return;
-                std::this_thread::yield();
+            {
+                std::unique_lock<std::mutex> lk(q_mu);
+                q_cv.wait(lk, [&] { return queued.load(std::memory_order_acquire) > gi || failed.load() != 0; });
+                if (queued.load(std::memory_order_acquire) <= gi) return;   // (failed)
             }
             if (hipEventSynchronize(ev_c1[gi]) != hipSuccess) { failed = 1; errs[w] = "copy event failed"; return; }
             const double t_a = ms_between(w0, std::chrono::steady_clock::now());
@@ -2261,10 +2265,18 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
             hipEventRecord(ev_c0[gi], b->copy_stream) != hipSuccess ||
             hipMemcpyAsync(b->host_pcm + b->host_pcm_off[lo], b->d_pcm_arena + b->host_pcm_off[lo], bytes, hipMemcpyDeviceToHost, b->copy_stream) != hipSuccess ||
             hipEventRecord(ev_c1[gi], b->copy_stream) != hipSuccess) { ok = fail("HIP error: PCM copy to the host"); break; }
-        queued.store(gi + 1, std::memory_order_release);
+        {
+            std::lock_guard<std::mutex> lk(q_mu);
+            queued.store(gi + 1, std::memory_order_release);
+        }
+        q_cv.notify_all();
     }
     if (ok && hipEventRecord(ev_r1, b->stream) != hipSuccess) ok = fail("HIP error: event");
-    if (!ok) failed = 1;
+    if (!ok) {
+        std::lock_guard<std::mutex> lk(q_mu);
+        failed = 1;
+    }
+    q_cv.notify_all();
     const auto w2 = std::chrono::steady_clock::now();
     for (auto& t : pool) t.join();
     if (hipStreamSynchronize(b->copy_stream) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) ok = ok && fail("HIP error: stream");
