@@ -1147,14 +1147,19 @@ static int guard_settle(td_graph* g) {
     q.in_redo = true;
     const int mode = g->band_mode;
     g->band_mode = 0;
+    // The host side of the project as it stands NOW -- behind the render, behind whatever its caller did next (set_time(0) of
+    // State::render, a FlowwBank cursor put back, reset_normalize_vertices for the next render): none of it depends on the
+    // band-pass arithmetic, so the second render leaves the host side exactly where the first left it, and what stands now is
+    // what has to stand afterwards.  Only the device side -- filter states, running peaks, the frames -- differs.
+    HostSnapshot now;
+    now.take(g, q.fb);
     q.snap.put(g, q.fb);
     int ok = 1;
     if (q.have_backup && hipMemcpyAsync(g->dstate, q.d_backup, g->hstate.size() * sizeof(StateSlot), hipMemcpyDeviceToDevice, g->stream) != hipSuccess)
         ok = fail("HIP error: the guard could not restore the carried state");
     g->state_dev_dirty = true;
     if (ok) ok = graph_render_chunks(g, q.sb, q.fb, q.n_blocks, q.is_scan, q.bits, q.advance, q.scan_t0, q.want_pcm);
-    if (ok && q.post == 1) ok = graph_set_time_impl(g, 0);
-    if (ok && q.post == 2) { q.fb->frame = q.snap.fb_frame; q.fb->start_indices = q.snap.fb_start; }
+    now.put(g, q.fb);
     g->band_mode = mode;
     q.in_redo = false;
     q.redos += 1;
@@ -1558,7 +1563,13 @@ void td_graph_reset(td_graph* g) {
     g->plan_dirty = true;
 }
 
+// A guarded render whose verdict is still out is settled before the graph it was rendered from changes shape (band_mode 2:
+// the render is done again from a snapshot of THIS graph's vertices).
+static void settle_guard_before_edit(td_graph* g) {
+    if (g->guard.armed && !g->guard.in_redo) (void)drain(g);
+}
 static Vertex& add_vertex(td_graph* g, const char* name, float gain, float angle, float wet, Kind kind) {
+    settle_guard_before_edit(g);
     Vertex v;
     v.kind = kind;
     v.name = name;
@@ -1728,6 +1739,7 @@ static bool has_loop(size_t x, size_t b, const std::vector<std::vector<size_t>>&
     return false;
 }
 int td_graph_connect(td_graph* g, const char* a, const char* b) {   // graph.rs:58-96
+    settle_guard_before_edit(g);
     auto ia = g->name_map.find(a), ib = g->name_map.find(b);
     if (ia == g->name_map.end()) return fail(std::string("TermDaw: warning: vertex \"") + a + "\" cannot be found and thus can't be connected.");
     if (ib == g->name_map.end()) return fail(std::string("TermDaw: warning: vertex \"") + b + "\" cannot be found and thus can't be connected to.");
@@ -1742,6 +1754,7 @@ int td_graph_connect(td_graph* g, const char* a, const char* b) {   // graph.rs:
 int td_graph_set_output(td_graph* g, const char* vertex) {
     auto it = g->name_map.find(vertex);
     if (it == g->name_map.end()) return fail("set_output: vertex not found");
+    settle_guard_before_edit(g);
     g->output_vertex = (long)it->second;
     g->plan_dirty = true;
     return 1;
@@ -1788,7 +1801,6 @@ int td_graph_render_block(td_graph* g, const td_samplebank* sb, td_flowwbank* fb
     const int ok = graph_render_chunks(g, sb, fb, 1, false, 16, true, 0, false);
     fb->frame = frame;
     fb->start_indices = starts;
-    g->guard.post = 2;   // (a guarded block that is done again leaves the cursor where this call found it, too)
     if (!ok) return -1;
     std::vector<float2> tmp(g->bl);
     if (!drain(g)) return -1;
@@ -1840,7 +1852,6 @@ int td_graph_normalize_scan(td_graph* g, const td_samplebank* sb, td_flowwbank* 
 size_t td_graph_render_all_async(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, int bits) {
     if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, true)) return 0;
     if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
-    g->guard.post = 1;
     return n_blocks * g->bl;
 }
 int td_graph_sync(td_graph* g) { return drain(g); }
@@ -1861,7 +1872,6 @@ size_t td_graph_render_all_resampled(td_graph* g, const td_samplebank* sb, td_fl
     }
     if (!graph_render_chunks(g, sb, fb, n_blocks, false, bits, true, 0, false)) return 0;
     if (!graph_set_time_impl(g, 0)) return 0;
-    g->guard.post = 1;
     if (!drain(g)) return 0;   // (the resampler reads the output vertex' frames)
     const size_t total = n_blocks * g->bl;
     float2* rs = nullptr;
@@ -2108,8 +2118,7 @@ size_t td_batch_render_all_async(td_batch* b, size_t n_blocks, int bits) {
     if (!batch_render_chunks(b, n_blocks, false, bits, true, true)) return 0;
     for (td_graph* g : b->graphs) {
         if (!graph_set_time_impl(g, 0)) return 0;   // state.rs:575
-        g->guard.post = 1;
-    }
+        }
     return b->graphs.empty() ? 0 : n_blocks * b->graphs[0]->bl;
 }
 int td_batch_sync(td_batch* b) {
@@ -2249,7 +2258,6 @@ int td_batch_render_to_files(td_batch* b, size_t n_blocks, int bits, size_t rend
         ok = batch_render_range(b, lo, hi, n_blocks, false, bits, true, true, false);
         for (size_t i = lo; i < hi && ok; ++i) {
             ok = graph_set_time_impl(b->graphs[i], 0);   // state.rs:575
-            b->graphs[i]->guard.post = 1;
         }
         {   // (band_mode 2: a group with guarded projects is settled -- verdicts looked at, a project over the bound done again -- before its PCM leaves)
             bool any_armed = false;

@@ -302,7 +302,9 @@ struct HostSnapshot {
 // estimate of the render's RMS deviation from the reference in word[1] and raises word[0] when it is over the bound.  The
 // words are looked at when the graph is drained (td_graph_sync, the read functions, td_batch_sync, or the next render that
 // continues from carried state): a raised word means the render is done again, from the state it started in, with the
-// exact kernels.  What "the state it started in" takes: the host side in `snap` (taken before the first chunk compiles);
+// exact kernels; afterwards the host side is put back to what stood when the verdict was looked at (what the caller did
+// between the render and the drain -- a reset_normalization, a set_time, a FlowwBank rewind for the next render -- does not
+// depend on the band-pass arithmetic and must survive).  What "the state it started in" takes: the host side in `snap` (taken before the first chunk compiles);
 // the device side -- the carried Normalize / band-pass slots -- in `d_backup`, copied on the stream in front of the
 // render unless every reachable vertex with a slot starts afresh anyway (reset_normalization / set_time pending: the
 // pipelined fresh renders of the bench loops pay nothing).
@@ -318,7 +320,7 @@ struct Guard {
     size_t n_blocks = 0, scan_t0 = 0;
     bool is_scan = false, advance = false, want_pcm = false;
     int bits = 16;
-    int post = 0;                    // what the caller did behind the render: 1 set_time(0) (state.rs:575), 2 put the FlowwBank cursor back (block pull)
+    int post = 0;                    // (unused: the redo puts the host side back to what stood when the verdict was looked at)
     HostSnapshot snap;
     bool have_backup = false;
     void* d_backup = nullptr;        // StateSlot[backup_cap]

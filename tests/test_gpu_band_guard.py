@@ -150,6 +150,32 @@ def test_pipelined_renders_and_mode_switch(gpu_api, oracle):
     assert g.band_guard_stats()["redos"] == 2
 
 
+def test_what_the_caller_did_behind_the_render_survives_the_redo(gpu_api, oracle):
+    """An asynchronous render whose verdict is still out, then reset_normalize_vertices + set_time + a FlowwBank rewind for the
+    NEXT render, and only then the sync that does the first render again: the host side stands where the caller left it (none
+    of it depends on the band-pass arithmetic), so the next render is the oracle's next render."""
+    p = W.config4(seconds=1.0, depth=9)
+    osb, ofb, og = p.build(oracle)
+    sb, fb, g = _guarded(p, gpu_api, band_guard_ppb=0)
+    op1, _ = og.render_all(osb, ofb, p.cs, 16)
+    g.render_all_async(sb, fb, p.cs, 16)
+    for (b, gr) in ((ofb, og), (fb, g)):        # the caller's preparations for the next render, verdict still out
+        gr.reset_normalize_vertices()
+        b.set_time(0)
+        gr.set_time(0)
+    g.sync()                                    # (the redo happens here)
+    assert g.band_guard_stats()["redos"] == 1
+    assert np.array_equal(_read_pcm(gpu_api, g, p.cs * p.bl), op1)
+    op2, of2 = og.render_all(osb, ofb, p.cs, 16)
+    gp2, gf2 = g.render_all(sb, fb, p.cs, 16)
+    assert np.array_equal(gp2, op2) and np.array_equal(_bits(gf2), _bits(of2))
+    # ... and a graph that changes shape settles a verdict still out before it does
+    g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
+    g.render_all_async(sb, fb, p.cs, 16)
+    g.add_sum("late", 1.0, 0.0)
+    assert g.band_guard_stats()["redos"] == 3
+
+
 def test_forced_verdict_in_a_batch_and_to_files(gpu_api, oracle, tmp_path):
     """Projects of a batch are audited one by one; the ones over the bound render again alone.  td_batch_render_to_files
     settles a group before its PCM leaves for the host."""
