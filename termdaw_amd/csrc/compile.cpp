@@ -974,8 +974,9 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
             down[u] = PathGain{sum, nz};
         }
     }
-    auto guard_ok = [&](size_t vi, const ScanPlan& sp) {
-        return g->vertices[vi].pass && sp.Kw != 0u && down[vi].norm != -2 && !short_up[vi];
+    auto guard_ok = [&](size_t vi, const ScanPlan& sp) {   // (`pass` vertices: the chain launch; `cut` vertices: k_band_scan, one vertex per launch)
+        (void)sp;
+        return down[vi].norm != -2 && !short_up[vi];
     };
     if (scan_on) {
         for (size_t vi : g->order) {
@@ -1175,7 +1176,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     // the guard's bookkeeping (band_mode 2): where every Normalize vertex of the chunk keeps its peak table and carried max,
     // and what every guarded scan launch leaves for k_band_audit
     std::map<size_t, std::pair<size_t, size_t>> audit_norm;   // Normalize vertex -> scratch offsets (peaks, init snapshot)
-    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; size_t desc_off; };   // from: the vertex whose output the estimate stands at
+    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; size_t desc_off; uint32_t tile_frames; };   // from: the vertex whose output the estimate stands at
     std::vector<AuditSrc> audit_src;
 
     for (int lv = 0; lv < g->n_levels; ++lv) {
@@ -1878,9 +1879,11 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                         x.flags = (uint32_t)g->band_scan_debug;
                         x.nz_end = norm_of.count(vi) ? (float)own_gain(g->vertices[norm_of[vi]]) : 1.0f;
                         d.push_back(x);
-                        if (guard_on) {
-                            const uint32_t n_wt = (uint32_t)((M + (size_t)kTileFrames - 1) / (size_t)kTileFrames);
-                            audit_src.push_back({scratch((size_t)n_wt * sizeof(float)), n_wt, norm_of.count(vi) ? norm_of[vi] : vi, norm_of.count(vi) != 0, 0});
+                        if (guard_on) {   // one entry per wave-tile (the chain launch) or per workgroup tile (k_band_scan: a single vertex)
+                            const bool is_chain = chain_of.count(vi) != 0;
+                            const uint32_t tf = is_chain ? (uint32_t)kTileFrames : band_scan_tile_frames(sp0.nf);
+                            const uint32_t n_wt = is_chain ? (uint32_t)((M + (size_t)kTileFrames - 1) / (size_t)kTileFrames) : sp0.n_tiles;
+                            audit_src.push_back({scratch((size_t)n_wt * sizeof(float)), n_wt, norm_of.count(vi) ? norm_of[vi] : vi, norm_of.count(vi) != 0, 0, tf});
                         }
                         if (norm_of.count(vi)) {   // the Normalize vertex behind the launch: its descriptor as k_norm1 would get it (mode 5)
                             const size_t ni = norm_of[vi];
@@ -2004,6 +2007,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
         for (const AuditSrc& a : audit_src) {
             AuditDesc x{};
             x.n_wt = a.n_wt;
+            x.tile_frames = a.tile_frames;
             x.nb = (uint32_t)nb;
             x.bl = (uint32_t)bl;
             x.gain = (float)down[a.from].g;

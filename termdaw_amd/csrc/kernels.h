@@ -425,9 +425,10 @@ struct BandScanDesc {
     // run, reach the output in exactly one way -- once non-finite (an infinite or NaN right input frame makes them so, for
     // good) they turn it NaN.  Every tile publishes this at its start and reads all earlier tiles' at its end.
     unsigned long long* rpoison;
-    // k_band_chain, guarded form: [ceil(frames / 1024)] -- per wave-tile the estimated ENERGY (sum over its frames of variance +
-    // offset^2) of the launch's deviation from the reference at the launch's output (behind the fused Normalize vertex where
-    // there is one); nullptr: not guarded (band_mode 1).  Read by k_band_audit at the end of the submission.
+    // Guarded form (band_mode 2) -- k_band_chain: [ceil(frames / 1024)], per wave-tile; k_band_scan (a single vertex, `cut`
+    // vertices included): [n_tiles], per workgroup tile -- the estimated ENERGY (sum over its frames of variance + offset^2) of
+    // the launch's deviation from the reference at the launch's output (behind the fused Normalize vertex where there is
+    // one); nullptr: not guarded (band_mode 1).  Read by k_band_audit at the end of the submission.
     float* noise;
     float nz_end;               // the static gain behind the last stage that the kernel applies itself (fused Normalize vertex' pan / gain)
     // ... or, where this launch is the graph's ONLY guarded one and carries the Normalize vertex itself, the verdict right
@@ -447,7 +448,8 @@ struct AuditDesc {
     const float* noise;         // a launch's per-wave-tile energies
     const float* peaks;         // the Normalize vertex on the way to the output: [nb] block peaks (nullptr: none, or evaluated by the launch)
     const float* init_copy;     // ... its carried max at the chunk start
-    uint32_t n_wt, nb, bl, pad;
+    uint32_t n_wt, nb, bl;      // entries of `noise`; the Normalize vertex' blocks and block length
+    uint32_t tile_frames;       // frames per entry of `noise`: 1 024 (k_band_chain: a wave-tile) or NF x 256 (k_band_scan: a workgroup tile)
     float gain;                 // static gain from the launch's output to the graph's
     uint32_t pad2[3];
 };

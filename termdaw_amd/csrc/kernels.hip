@@ -2816,6 +2816,7 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
     const uint32_t tile0 = tile * TILE, mlast = M - 1u, mf = tile0 + (uint32_t)NF * tid;
 
     float4 x[NP];             // the lane's NF consecutive frames: a stage's input, then its output
+    float nz_e = 0.0f;        // (band_mode 2) the lane's share of the launch's estimated deviation energy (BandScanDesc::noise)
     double excl[4], xw[4], B[4];
     // ---- the first vertex' input terms for tile tt -> lane-consecutive frames
     auto load_tile = [&](uint32_t tt) {
@@ -3078,6 +3079,17 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
         float y1 = (float)__builtin_fma(pwl, __builtin_fma(awpl, carry_s[1], xw[1]), excl[1]);
         float y2 = (float)__builtin_fma(pwh, __builtin_fma(awph, carry_s[2], xw[2]), excl[2]);
         float y3 = (float)__builtin_fma(pwh, __builtin_fma(awph, carry_s[3], xw[3]), excl[3]);
+        if (d.noise) {   // (uniform; band_mode 2, single vertices: the estimate of k_band_chain<.., true>, both channels' smoothers)
+            const float x0l = x[0].x, x0r = x[0].y;
+            const float a0 = fabsf(y0), a1 = fabsf(y1), a2 = fabsf(y2), a3 = fabsf(y3);
+            const float vl = __builtin_fmaf(sp->nzv[0], y0 * y0, sp->nzv[1] * (y2 * y2));
+            const float vr = __builtin_fmaf(sp->nzv[0], y1 * y1, sp->nzv[1] * (y3 * y3));
+            const float ol = (fabsf(x0l - y0) < sp->nzk[0] * a0 ? sp->nzs[0] * a0 : 0.0f) + (fabsf(x0l - y2) < sp->nzk[1] * a2 ? sp->nzs[1] * a2 : 0.0f);
+            const float orr = (fabsf(x0r - y1) < sp->nzk[0] * a1 ? sp->nzs[0] * a1 : 0.0f) + (fabsf(x0r - y3) < sp->nzk[1] * a3 ? sp->nzs[1] * a3 : 0.0f);
+            const float el = __builtin_fmaf(ol, ol, vl), er = __builtin_fmaf(orr, orr, vr);
+            // a `pass` vertex' two outputs both carry the LEFT cut (extensions.rs:685); a `cut` vertex' right output its own
+            nz_e += mf < M ? (float)NF * (sp->pass ? el : 0.5f * (el + er)) : 0.0f;
+        }
         // the lane's frames in the reference's own arithmetic (extensions.rs:671-688); x becomes the vertex' output.
         // Pan / gain steps a vertex skips (flags) are skipped by uniform branches, not computed and masked.
         const BandCoef kf = band_coef(lgam, hgam, sp->pass);
@@ -3167,6 +3179,15 @@ __global__ __launch_bounds__(kThreads, NF == 16 ? 3 : 4) void k_band_scan(const 
                 for (int j = 0; j < NP; ++j) x[j] = zero_tail(x[j], mf + 2u * (uint32_t)j, M);
             }
         }
+    }
+    if (d.noise) {   // (band_mode 2) the tile's share of the launch's estimate, for k_band_audit
+        __shared__ float nzw[kThreads / 64];
+        float e = (nz_e == nz_e) ? nz_e : 0.0f;   // (NaN: a tile the reference turns NaN as well)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
+        if (lane == 0u) nzw[wave] = e;
+        __syncthreads();
+        if (tid == 0u) d.noise[tile] = (nzw[0] + nzw[1]) + (nzw[2] + nzw[3]);
     }
     if (d.poison) {
         // ---- once NaN, always NaN (the reference's smoother state never recovers; the look-back forgets a tile after K tiles):
@@ -3891,7 +3912,7 @@ __global__ __launch_bounds__(kThreads) void k_band_audit(const AuditHead* __rest
         for (uint32_t w = tid; w < d.n_wt; w += (uint32_t)kThreads) {
             float v = fmaxf(gload1(d.noise + w), 0.0f);   // (NaN -> 0)
             if (d.peaks) {
-                const uint32_t b0 = min(d.nb - 1u, (uint32_t)(((uint64_t)w * (uint64_t)kTileFrames) / d.bl));
+                const uint32_t b0 = min(d.nb - 1u, (uint32_t)(((uint64_t)w * (uint64_t)d.tile_frames) / d.bl));
                 const uint32_t sg = b0 / seg;
                 float run = seg_pre[sg];
                 for (uint32_t b = sg * seg; b <= b0; ++b) run = fmaxf(run, gload1(d.peaks + b));

@@ -155,8 +155,8 @@ static void touch_scan(const BandScanDesc* d, int n, uint32_t frames, bool chain
             if (x.norm->out) touch_w(x.norm->out, (size_t)frames * sizeof(float2));
             if (x.norm->qmode) touch_w(x.norm->pcm, (size_t)frames * 2 * (x.norm->qmode == 1u ? 2 : 4));
         }
-        if (guarded) {
-            touch_w(x.noise, (size_t)((frames + kTileFrames - 1) / kTileFrames) * 4);
+        if (x.noise) {   // (per wave-tile in the chain launch, per workgroup tile in k_band_scan)
+            touch_w(x.noise, (size_t)(chain ? (frames + kTileFrames - 1) / kTileFrames : x.n_tiles) * 4);
             if (x.nz_sync) { touch_w(x.nz_sync, (size_t)x.n_tiles * 8); touch_w(x.nz_host, 8); }
         }
     }
