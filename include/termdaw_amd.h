@@ -180,6 +180,12 @@ size_t td_graph_last_kernel_times(const td_graph* g, const char** names, float* 
 size_t td_graph_host_times(td_graph* g, double* ms4, int reset);
 /* HBM bytes allocated for edge buffers / tables by this graph handle. */
 size_t td_graph_device_bytes(const td_graph* g);
+/* Device and page-locked memory given back by freed handles stays with the process and is handed out again to the next handle
+ * that asks for a block of that size (no reference counterpart; budget: environment TD_ALLOC_CACHE_MB, default 2048, 0 = off;
+ * DESIGN.md 3 "Memory").  td_trim_memory gives everything on the free lists back to the driver now; td_cached_memory_bytes
+ * says how much is there. */
+void td_trim_memory(void);
+size_t td_cached_memory_bytes(void);
 /* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
  * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);
  * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders);

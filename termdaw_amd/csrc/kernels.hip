@@ -4197,6 +4197,40 @@ void launch_norm_fix(const SumDesc* d, int n, uint32_t frames, uint32_t bl, hipS
     if (!n || !frames) return;
     TD_BATCHED(k_norm_fix, std::min(tiles(frames), 512u), kThreads, d, n, frames, bl, frames / bl);
 }
+// (debugging aid, TD_DEBUG_SYNC & 16: does every workgroup of a wide grid -- every XCD, every L2 -- see the bytes an upload
+// just put there?  Each workgroup sums the whole region with position weights and compares with the host's sum; a workgroup
+// that disagrees leaves {1 + count, XCC_ID, first differing 256-byte segment by a second array of per-segment sums}.)
+__global__ __launch_bounds__(kThreads) void k_debug_verify(const uint32_t* __restrict__ p, uint32_t n_words, const uint32_t* __restrict__ seg_sums,
+                                                           uint32_t* __restrict__ report) {
+    __shared__ uint32_t bad_seg;
+    if (threadIdx.x == 0) bad_seg = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t n_seg = (n_words + 63u) / 64u;
+    const uint32_t wave = threadIdx.x / 64u, lane = threadIdx.x % 64u;
+    for (uint32_t sg = wave; sg < n_seg; sg += kThreads / 64u) {
+        const uint32_t i = sg * 64u + lane;
+        uint32_t v = i < n_words ? p[i] * (2u * lane + 1u) : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0u && v != seg_sums[sg]) atomicMin(&bad_seg, sg);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && bad_seg != 0xFFFFFFFFu) {
+        uint32_t xcc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        const uint32_t k = atomicAdd(report, 1u);
+        if (k < 15u) {
+            report[4 + 4 * k] = blockIdx.x;
+            report[5 + 4 * k] = xcc;
+            report[6 + 4 * k] = bad_seg;
+            report[7 + 4 * k] = p[bad_seg * 64u];
+        }
+    }
+}
+void launch_debug_verify(const uint32_t* p, uint32_t n_words, const uint32_t* seg_sums, uint32_t* report, hipStream_t s) {
+    if (!n_words) return;
+    hipLaunchKernelGGL(k_debug_verify, dim3(512), dim3(kThreads), 0, s, p, n_words, seg_sums, report);
+}
 void launch_quantise(const QuantDesc* d, int n, uint32_t frames, hipStream_t s) {
     if (!n || !frames) return;
     TD_BATCHED(k_quantise, tiles(frames), kThreads, d, n, frames);

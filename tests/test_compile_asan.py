@@ -56,7 +56,9 @@ def test_event_compiler_and_descriptor_builder_under_sanitizers(tmp_path):
     exe = _build(str(tmp_path))
     n = int(os.environ.get("TD_ASAN_SEEDS", "600"))
     workers = max(1, min(8, os.cpu_count() or 1))
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    # (TD_ALLOC_CACHE_MB=0: every "device" block is its own malloc of exactly the size asked for, so that one byte past it is a report)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=0", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               TD_ALLOC_CACHE_MB="0")
     renders = 0
     with multiprocessing.Pool(workers) as pool:
         for lo in range(0, n, 200):      # (a few hundred projects on disk at a time)
