@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "engine.h"
+#include "devmem.h"
 #include "lua_subset.h"
 #include "wav.h"
 #include "midi.h"

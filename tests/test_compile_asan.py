@@ -18,7 +18,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "termdaw_amd", "csrc")
-SOURCES = ["engine.cpp", "compile.cpp", "project.cpp", "lua_subset.cpp", "wav.cpp", "midi.cpp"]
+SOURCES = ["engine.cpp", "compile.cpp", "devmem.cpp", "project.cpp", "lua_subset.cpp", "wav.cpp", "midi.cpp"]
 
 
 def _build(out_dir):

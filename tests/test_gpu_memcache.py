@@ -1,4 +1,4 @@
-"""The per-process memory cache (include/termdaw_amd.h td_trim_memory / td_cached_memory_bytes; engine.cpp MemCache): blocks of
+"""The per-process memory cache (include/termdaw_amd.h td_trim_memory / td_cached_memory_bytes; csrc/devmem.cpp): blocks of
 freed handles are handed out again -- with whatever the last owner left in them -- and a project set up in such blocks renders
 the oracle's bytes; trimming gives everything back.  (Why the cache exists: DESIGN.md 7 "One process of 40".)"""
 import gc
