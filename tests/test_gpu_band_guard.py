@@ -64,6 +64,23 @@ def test_baseline_configs_pass_the_guard(gpu_api, oracle, name, mk):
     assert st["last_est"] >= 0.1 * _rms(f, ref_f), (st, _rms(f, ref_f))
 
 
+@pytest.mark.parametrize("name,mk", [("config3", W.config3), ("config4", W.config4)])
+def test_baseline_configs_at_the_full_60_s_through_the_guard(gpu_api, oracle, name, mk):
+    """BASELINE configs 3 and 4 at the size the bench times them (2 813 blocks) in the front-end's default mode: audited,
+    not rendered twice, <= 1e-6 RMS on the f32 output and +-1 LSB on the PCM; scanned (the dry run is audited too) likewise."""
+    p = mk()
+    assert p.cs == 2813
+    ob = p.build(oracle)
+    built = _guarded(p, gpu_api)
+    for scan in (False, True):
+        ref_pcm, ref_f = p.render(oracle, built=ob, scan=scan)
+        pcm, f = p.render(gpu_api, built=built, scan=scan)
+        assert _rms(f, ref_f) <= 1e-6
+        assert np.abs(pcm.astype(np.int64) - ref_pcm.astype(np.int64)).max() <= 1
+    st = built[2].band_guard_stats()
+    assert st["audits"] == 3 and st["redos"] == 0 and st["max_est"] < 1e-7, st
+
+
 def test_a_cut_vertex_is_audited_too(gpu_api, oracle):
     """`cut` vertices (band_pass_gen with pass = false: its own left AND right smoothers, extensions.rs:671-688) are not part
     of a chain launch; k_band_scan carries the same estimate per workgroup tile and k_band_audit adds it up."""
