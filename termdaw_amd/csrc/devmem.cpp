@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -32,7 +33,7 @@ struct MemCache {
     std::map<void*, Block> live;
     std::multimap<std::tuple<int, unsigned, size_t>, void*> free_list;
     std::map<void*, size_t> free_size;
-    size_t cached_bytes = 0;
+    std::atomic<size_t> cached_bytes{0};
     size_t budget() {
         static const size_t b = (size_t)(getenv("TD_ALLOC_CACHE_MB") ? atoll(getenv("TD_ALLOC_CACHE_MB")) : 2048) << 20;
         return b;
