@@ -33,6 +33,7 @@ sinf = len(sys.argv) > 3 and sys.argv[3] in ("sinf", "scan", "guard")
 scan_mode = len(sys.argv) > 3 and sys.argv[3] in ("scan", "guard")
 guard_mode = len(sys.argv) > 3 and sys.argv[3] == "guard"
 bad, rejected = [], 0
+sine_class = []   # (scan / guard modes) renders over 1e-6 that are as far off with the exact band-pass kernels
 audits = redos = renders = 0
 worst = (0.0, -1)
 only = os.environ.get("TD_SOAK_ONLY", "")
@@ -57,7 +58,7 @@ for seed in range(lo_seed, hi_seed):
         gb[2].set_option("band_mode", 2 if guard_mode else 1)
     for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=norm_debug=1
         gb[2].set_option(kv.split("=")[0], int(kv.split("=")[1]))
-    for scan in (False, True, False):
+    for ki, scan in enumerate((False, True, False)):
         gp, gf = p.render(api, built=gb, scan=scan)
         op, of = p.render(oracle, built=ob, scan=scan)
         if sinf:
@@ -68,6 +69,24 @@ for seed in range(lo_seed, hi_seed):
             if rms > worst[0]:
                 worst = (rms, seed)
             if not np.array_equal(np.isfinite(gf), ok) or rms > 1e-6:
+                if scan_mode and np.array_equal(np.isfinite(gf), ok) and rms <= 1e-5 and (p.calls["add_synth"] or p.calls["add_debug_sine"]):
+                    # Is it the band-pass arithmetic at all?  The same renders with the EXACT band-pass kernels: when they are as far
+                    # from the oracle, what is seen is the sine class' own tolerance (device sine vs glibc's, <= 3.3e-7 per
+                    # oscillator) made larger by the graph -- a filter that cancels most of the signal, a Normalize vertex behind
+                    # it -- and is listed apart (DESIGN.md 5 "Sine class").
+                    eb = p.build(api)
+                    eo = p.build(oracle)
+                    same = False
+                    for kj, sc2 in enumerate((False, True, False)[:ki + 1]):   # (the same sequence of renders: state carries)
+                        ef = p.render(api, built=eb, scan=sc2)[1]
+                        rf = p.render(oracle, built=eo, scan=sc2)[1]
+                        if kj == ki:
+                            k2 = np.isfinite(rf)
+                            r0 = float(np.sqrt(np.mean(((ef[k2].astype(np.float64) - rf[k2].astype(np.float64)) / scale) ** 2))) if k2.any() else 0.0
+                            same = r0 >= 0.7 * rms
+                    if same:
+                        sine_class.append((seed, scan, rms))
+                        break
                 bad.append((seed, scan, rms))
                 if os.environ.get("TD_SOAK_VERBOSE") and rms > 1e-4:   # (a gross one: where, and what stands there)
                     d = np.abs(gf.astype(np.float64) - of.astype(np.float64)).max(axis=1)
@@ -93,6 +112,8 @@ for seed in range(lo_seed, hi_seed):
         st = gb[2].band_guard_stats()
         audits += st["audits"]
         redos += st["redos"]
+if sine_class:
+    print("seeds", lo_seed, hi_seed, "sine class, the same distance in band_mode 0:", sine_class, flush=True)
 print("seeds", lo_seed, hi_seed, "rejected by both:", rejected, "mismatching:", bad,
       ("renders %d audited %d done again exact %d worst rms %.3g (seed %d)" % (renders, audits, redos, worst[0], worst[1])) if scan_mode else "")
 sys.exit(1 if bad else 0)
