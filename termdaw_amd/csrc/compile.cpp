@@ -282,6 +282,7 @@ static float synth_release_sec(const Vertex& v) {   // extensions.rs:469-478
 // Only for confs whose pieces cannot reach the `res <= -1.0` escape of adsr.rs:62-69 and whose times are finite, the attack
 // longer than zero (quirk Q6's NaN frame) -- anything else keeps the generic per-frame evaluation.
 static bool synth_affine_ok(const Vertex& v) {
+    if (v.exact_sin) return false;   // (sine_mode 1: the generic per-frame form carries sin_glibc)
     float amp = 0.0f;
     for (const tdk::OscConfD* o : {&v.square, &v.topflat, &v.triangle}) {
         if (!(o->volume > 0.0f)) {
@@ -585,7 +586,7 @@ static void table_key(const Vertex& v, const td_flowwbank* fb, const std::vector
     switch (v.kind) {
         case K_SAMPLE_MULTI: put_pod(key, (uint64_t)sample_len); break;
         case K_SAMPLE_LERP: put_pod(key, (uint64_t)v.lerp_len); break;
-        case K_SYNTH: put_pod(key, v.square); put_pod(key, v.topflat); put_pod(key, v.triangle); break;   // (retain rule: release times)
+        case K_SYNTH: put_pod(key, v.square); put_pod(key, v.topflat); put_pod(key, v.triangle); put_pod(key, (uint8_t)v.exact_sin); break;   // (retain rule: release times; the table's form)
         case K_SAMPSYN: put_pod(key, v.conf); break;
         case K_ADSR: put_pod(key, (uint8_t)v.use_off); put_pod(key, v.conf); break;
         default: break;
@@ -1410,6 +1411,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                         x.out = g->vbuf[vi];
                         x.t0 = t0;
                         x.sr = (uint32_t)sr;
+                        x.exact_sin = v.exact_sin ? 1u : 0u;
                         x.pg = make_pg(v.gain, v.angle);
                         d.push_back(x);
                     }
@@ -1443,6 +1445,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                                     v.triangle.volume * adsr_max_vel(v.triangle.adsr));
                         x.pg = make_pg(v.gain, v.angle);
                         x.affine = synth_affine_ok(v) ? 1u : 0u;   // (the tables then hold affine records: compile_synth)
+                        x.exact_sin = v.exact_sin ? 1u : 0u;
                         {
                             auto same = [](const AdsrConfD& a, const AdsrConfD& b) { return memcmp(&a, &b, sizeof(AdsrConfD)) == 0; };
                             const bool sq = v.square.volume > 0.0f, tf = v.topflat.volume > 0.0f;

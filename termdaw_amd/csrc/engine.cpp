@@ -1652,6 +1652,7 @@ int td_graph_add_sample_lerp(td_graph* g, const char* name, float gain, float an
 }
 int td_graph_add_debug_sine(td_graph* g, const char* name, float gain, float angle, size_t floww_index) {
     Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_DEBUG_SINE);
+    v.exact_sin = g->sine_mode != 0;
     v.floww_index = floww_index;
     return 1;
 }
@@ -1664,6 +1665,7 @@ int td_graph_add_synth(td_graph* g, const char* name, float gain, float angle, s
         !conf_from(triangle_adsr, triangle_adsr_len, &tr))
         return fail("ADSR config must have 6 or 9 elements");   // state.rs:393 panics
     Vertex& v = add_vertex(g, name, gain, angle, 0.0f, K_SYNTH);
+    v.exact_sin = g->sine_mode != 0;
     v.floww_index = floww_index;
     v.square = {square_vel, fmaxf(square_z, 0.0001f), sq};   // state.rs:400
     v.topflat = {topflat_vel, topflat_z, tf};
@@ -2057,6 +2059,13 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "norm_debug") { g->norm_debug = (int)value; return 1; }
     if (k == "fuse_normalize") { g->fuse_normalize = value != 0; return 1; }
     if (k == "one_grid_sources") { g->one_grid_sources = value != 0; return 1; }
+    if (k == "sine_mode") {   // 0: the tolerance-class device sine (default), 1: glibc's sinf operation for operation (kernels.hip sin_glibc)
+        if (value != 0 && value != 1) return fail("td_graph_set_option: sine_mode is 0 or 1");
+        g->sine_mode = (int)value;
+        for (auto& v : g->vertices)
+            if (v.kind == K_DEBUG_SINE || v.kind == K_SYNTH) v.exact_sin = value != 0;
+        return 1;
+    }
     if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
     if (k == "table_cache") { g->table_cache = value != 0; return 1; }
     if (k == "graph_replay") { g->graph_replay = value != 0; return 1; }

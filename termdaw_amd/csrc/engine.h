@@ -111,6 +111,7 @@ struct Vertex {
     tdk::OscConfD square{}, topflat{}, triangle{};
     tdk::AdsrConfD conf{};
     bool use_off = false, use_max = false, pass = true;
+    bool exact_sin = false;   // (debug_sine, synth) the graph's "sine_mode" option at the last set_option / add: glibc's sinf on the device
     float lgamma = 0, hgamma = 0;
     tdk::WaveTableD wavetable{};   // K_SAMPSYN: table in HBM (owned by the graph)
     // carried host state (what the reference keeps inside VertexExt, extensions.rs:15-80)
@@ -397,6 +398,7 @@ struct td_graph {
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
+    int sine_mode = 0;                         // 0: the device sine of the tolerance class (<= 3.3e-7 from glibc's sinf), 1: glibc's sinf operation for operation (bit-exact; ~6 x the cost per oscillator)
     int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
                                                //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex),
                                                // 2: the scan under the guard (tde::Guard below): every render estimates its own

@@ -209,7 +209,8 @@ struct SineDesc {
     IntervalTab tab;
     float2* out;
     uint64_t t0;   // graph time of the chunk's first frame
-    uint32_t sr, pad;
+    uint32_t sr;
+    uint32_t exact_sin;   // 1: glibc's sinf, operation for operation (SynthDesc::exact_sin)
     PanGain pg;
 };
 
@@ -229,7 +230,8 @@ struct SynthDesc {
     // oscillator (square, top-flat, triangle), (s1, s2, A, B): envelope x velocity x volume x osc_amp_multiplier x shape scale
     // = A + B ((t - s1) - s2), t = env_t + in-block offset (engine.cpp synth_refine_affine); 0: one float4 (hz, vel, env_t,
     // rel_t) per voice, envelopes evaluated per frame (confs that can reach the `res <= -1.0` escape, zero-length pieces)
-    uint32_t affine, pad2;
+    uint32_t affine;
+    uint32_t exact_sin;   // 1: the oscillators' sine is glibc's sinf, operation for operation (kernels.hip sin_glibc; engine option "sine_mode"); affine is 0 then
 };
 
 // sampsyn_gen (extensions.rs:532-578) with this engine's own wavetable oscillator (the sampsyn crate is

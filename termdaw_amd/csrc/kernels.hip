@@ -1216,6 +1216,69 @@ TD_DEV f2 sin_any2(f2 arg) {
     return __builtin_bit_cast(f2, __builtin_bit_cast(u2, q) ^ sg);
 }
 TD_DEV float sin_any(float arg) { return sin_any2((f2)(arg)).x; }
+
+// sin of an f32 argument EXACTLY as glibc's sinf returns it (engine option "sine_mode" 1).  The reference's `f32::sin`
+// (extensions.rs:450,501) is libm's sinf; glibc's (2.28 and later: sysdeps/ieee754/flt-32/s_sinf.c + sincosf.h, the ARM
+// optimized-routines algorithm) is a short computation in IEEE double -- |y| < pi/4: an odd polynomial; |y| < 120: n =
+// round(y 2/pi) by a 2^24-scaled multiply, x = y - n pi/2; beyond: 2/pi from a 24-word table times the mantissa in 64-bit
+// integers, the top two bits n, the rest x pi / 2^63 -- then sin or cos polynomial by n & 1, sign by n & 2.  Restated here
+// operation for operation, with a fused multiply-add exactly where the x86-64 build of glibc has one (its FMA variant, what
+// an EPYC runs; every `a + b * c` of the source): tools/sinf_restate.c compares the same sequence with the host's sinf over ALL
+// 4 278 190 080 finite floats -- 0 differ (without the fusing: 12).  Double arithmetic on the device is IEEE, the conversions
+// round to nearest even: the kernels' oscillators then carry the oracle's bits.  ~45 instructions, half of them f64 or 64-bit
+// integer -- six times sin_any2's cost per frame: the mode is for byte parity, not for the bench.
+__device__ const uint32_t kInvPio4[24] = {0xa2u, 0xa2f9u, 0xa2f983u, 0xa2f9836eu, 0xf9836e4eu, 0x836e4e44u, 0x6e4e4415u, 0x4e441529u,
+                                          0x441529fcu, 0x1529fc27u, 0x29fc2757u, 0xfc2757d1u, 0x2757d1f5u, 0x57d1f534u, 0xd1f534ddu, 0xf534ddc0u,
+                                          0x34ddc0dbu, 0xddc0db62u, 0xc0db6295u, 0xdb629599u, 0x6295993cu, 0x95993c43u, 0x993c4390u, 0x3c439041u};
+TD_DEV float sin_glibc_poly(double x, double x2, double csign, int n) {
+    if ((n & 1) == 0) {
+        const double x3 = x * x2;
+        const double s1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7);
+        const double x7 = x3 * x2;
+        const double s = __builtin_fma(x3, -0x1.555545995a603p-3, x);
+        return (float)__builtin_fma(x7, s1, s);
+    }
+    // (the second row of glibc's table is the first with the cosine coefficients negated: csign = -1)
+    const double x4 = x2 * x2;
+    const double c2 = __builtin_fma(x2, csign * 0x1.99343027bf8c3p-16, csign * -0x1.6c087e89a359dp-10);
+    const double c1 = __builtin_fma(x2, csign * -0x1.ffffffd0c621cp-2, csign * 0x1p0);
+    const double x6 = x4 * x2;
+    const double c = __builtin_fma(x4, csign * 0x1.55553e1068f19p-5, c1);
+    return (float)__builtin_fma(x6, c2, c);
+}
+TD_DEV float sin_glibc(float y) {
+    const uint32_t yi = __float_as_uint(y);
+    const uint32_t top = (yi >> 20) & 0x7ffu;   // abstop12
+    double x = (double)y;
+    if (top < 0x3f4u) {                          // |y| < pi/4  (abstop12(0x1.921FB6p-1f))
+        if (top < 0x398u) return y;              // |y| < 2^-12
+        return sin_glibc_poly(x, x * x, 1.0, 0);
+    }
+    if (top < 0x42fu) {                          // |y| < 120
+        const double r = x * 0x1.45F306DC9C883p+23;
+        const int n = ((int)r + 0x800000) >> 24;
+        x = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+        const double s = ((n + 1) & 2) ? -1.0 : 1.0;   // sign[n & 3] = {1, -1, -1, 1}
+        return sin_glibc_poly(x * s, x * x, (n & 2) ? -1.0 : 1.0, n);
+    }
+    if (top < 0x7f8u) {                          // finite
+        const uint32_t sign = yi >> 31;
+        const uint32_t* arr = kInvPio4 + ((yi >> 26) & 15u);
+        const uint32_t shift = (yi >> 23) & 7u;
+        uint32_t xi = ((yi & 0xffffffu) | 0x800000u) << shift;
+        uint64_t res0 = (uint64_t)(uint32_t)(xi * arr[0]);
+        const uint64_t res1 = (uint64_t)xi * arr[4], res2 = (uint64_t)xi * arr[8];
+        res0 = (res2 >> 32) | (res0 << 32);
+        res0 += res1;
+        const uint64_t nn = (res0 + (1ull << 61)) >> 62;
+        res0 -= nn << 62;
+        x = (double)(int64_t)res0 * 0x1.921FB54442D18p-62;
+        const int n = (int)nn, ns = n + (int)sign;
+        const double s = ((ns + 1) & 2) ? -1.0 : 1.0;
+        return sin_glibc_poly(x * s, x * x, (ns & 2) ? -1.0 : 1.0, n);
+    }
+    return y - y;                                // inf, NaN -> NaN
+}
 // x / y for the same kernels: v_rcp_f32 + multiply (1 ulp) instead of the 10-instruction IEEE division.  0 / 0 is still
 // NaN and t / 0 still +-inf (quirk Q6's cases).
 TD_DEV float fdiv_fast(float x, float y) { return x * __builtin_amdgcn_rcpf(y); }
@@ -1244,7 +1307,8 @@ TD_DEV float sine_frame(const SineDesc& d, uint32_t m) {
     float acc = 0.0f;
     for (uint32_t v = v0; v < v1; ++v) {
         const float4 nv = d.tab.voices[v];   // (hz, vel)
-        acc += sin_any(time * nv.x * 2.0f * kPi) * nv.y;
+        const float arg = time * nv.x * 2.0f * kPi;
+        acc += (d.exact_sin ? sin_glibc(arg) : sin_any(arg)) * nv.y;
     }
     return acc;
 }
@@ -1265,32 +1329,38 @@ __global__ __launch_bounds__(kThreads) void k_debug_sine(const SineDesc* __restr
 // ------------------------------------------------------------------------------------------------
 // k_synth (extensions.rs:460-529, synth.rs:21-34)
 // ------------------------------------------------------------------------------------------------
-// one voice, one frame: oscillators x velocity x envelope x volume (extensions.rs:499-524)
+// a voice's envelope at one frame (extensions.rs:505-507): the reciprocal form of the tolerance class, or -- sine_mode 1, where
+// the vertex is to carry the reference's bits -- adsr.rs's own divisions (apply_ads / apply_r_rt, as the Adsr vertex has them)
+TD_DEV float synth_env1(const SynthDesc& d, const AdsrConfD& c, float env_time, float rel_t) {
+    if (d.exact_sin) return rel_t == 0.0f ? apply_ads(c, env_time) : apply_r_rt(c, env_time, rel_t);   // (uniform)
+    return rel_t == 0.0f ? apply_ads_fast(c, env_time) : apply_r_rt_fast(c, env_time, rel_t);
+}
+// one voice, one frame: oscillators x velocity x envelope x volume (extensions.rs:499-524), in the reference's order
 TD_DEV float synth_voice(const SynthDesc& d, const float4 n, float time, float off) {   // n = (hz, vel, env_t, rel_t)
     const float hz = n.x, vel = n.y, rel_t = n.w;
     const float env_time = n.z + off;
     float s = 0.0f;
     float sn = 0.0f;
     float env_sq = 0.0f, env_tf = 0.0f;
-    if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = sin_any(time * hz * 2.0f * kPi);
+    if (d.square.volume > 0.0f || d.topflat.volume > 0.0f) sn = d.exact_sin ? sin_glibc(time * hz * 2.0f * kPi) : sin_any(time * hz * 2.0f * kPi);
     if (d.square.volume > 0.0f) {
         const float z = d.square.param;
         const float osc = fminf(fmaxf(sn, -z), z) * (1.0f / z);
-        env_sq = rel_t == 0.0f ? apply_ads_fast(d.square.adsr, env_time) : apply_r_rt_fast(d.square.adsr, env_time, rel_t);
+        env_sq = synth_env1(d, d.square.adsr, env_time, rel_t);
         s += osc * vel * env_sq * d.square.volume;
     }
     if (d.topflat.volume > 0.0f) {
         const float z = d.topflat.param;
         const float osc = (fminf(sn, z) + ((1.0f - z) / 2.0f)) * (2.0f / (1.0f + z));
         env_tf = d.tf_env_src == 1u ? env_sq
-               : rel_t == 0.0f ? apply_ads_fast(d.topflat.adsr, env_time) : apply_r_rt_fast(d.topflat.adsr, env_time, rel_t);
+               : synth_env1(d, d.topflat.adsr, env_time, rel_t);
         s += osc * vel * env_tf * d.topflat.volume;
     }
     if (d.triangle.volume > 0.0f) {
         const float th = time * hz;
         const float osc = 4.0f * fabsf(th - floorf(th + 0.5f)) - 1.0f;
         const float env = d.tr_env_src == 1u ? env_sq : d.tr_env_src == 2u ? env_tf
-                        : rel_t == 0.0f ? apply_ads_fast(d.triangle.adsr, env_time) : apply_r_rt_fast(d.triangle.adsr, env_time, rel_t);
+                        : synth_env1(d, d.triangle.adsr, env_time, rel_t);
         s += osc * vel * env * d.triangle.volume;
     }
     return s * d.osc_amp_multiplier;
@@ -1379,7 +1449,11 @@ TD_DEV f2 synth_osc2(const SynthDesc& d, const float4 n, const SynthEnv2& e, con
     const bool tr_on = SPEC ? true : d.triangle.volume > 0.0f;
     const f2 th = time * hz;
     f2 sn = (f2)(0.0f);
-    if (sq_on || tf_on) sn = sin_any2(th * (2.0f * kPi));
+    if (sq_on || tf_on) {
+        const f2 arg = th * (2.0f * kPi);
+        if (d.exact_sin) { sn.x = sin_glibc(arg.x); sn.y = sin_glibc(arg.y); }   // (uniform; engine option sine_mode 1)
+        else sn = sin_any2(arg);
+    }
     if (sq_on) {
         const float z = d.square.param;
         f2 osc;
@@ -1445,7 +1519,8 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
     const uint32_t i0 = find_interval(d.tab, ma), i1 = two_a ? find_interval(d.tab, ma + 1u) : i0;
     const uint32_t i2 = find_interval(d.tab, mb), i3 = two_b ? find_interval(d.tab, mb + 1u) : i2;
     const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
-    if (__all((i0 == it0 && i1 == it0 && i2 == it0 && i3 == it0) ? 1 : 0)) {
+    // (sine_mode 1: every frame takes the per-frame form below -- the reference's own order of operations, exact divisions)
+    if (!d.exact_sin && __all((i0 == it0 && i1 == it0 && i2 == it0 && i3 == it0) ? 1 : 0)) {
         const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
         const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
         typedef float f4c __attribute__((ext_vector_type(4)));
