@@ -403,13 +403,15 @@ def other_configs(api, workloads, ub, chain_ns):
     issue_ns = float(ub.td_ubench_fma_issue_ns(SIMDS // 4)) if ub is not None else -1.0
     plan = (("config1", workloads.config1, None, 50, ()),
             ("config3", workloads.config3, "exact", 10, (8, 32)), ("config3", workloads.config3, "scan", 10, (8, 32)),
-            ("config3", workloads.config3, "guard", 10, ()),
+            ("config3", workloads.config3, "guard", 10, ()), ("config3", workloads.config3, "exact+sine", 6, ()),
             ("config4", workloads.config4, "exact", 4, (8, 32)), ("config4", workloads.config4, "scan", 10, (8, 32)),
             ("config4", workloads.config4, "guard", 10, (32,)))
     for name, mk, mode, reps, batches in plan:
         p = mk()
         frames = p.cs * p.bl
         opts = {} if mode is None else {"band_mode": {"scan": 1, "guard": 2}.get(mode, 0)}
+        if mode == "exact+sine":   # what a bare td_graph does when nothing is set: every kind the reference's bytes (glibc's sinf on the device)
+            opts["sine_mode"] = 1
         ms, kernels, hosts, built = time_project(p, api, opts, reps)
         g = built[2]
         dom = kernels[0]
@@ -426,11 +428,16 @@ def other_configs(api, workloads, ub, chain_ns):
             entry["band_mode"] = mode
             entry["band_mode_note"] = ("exact: speculative-segment kernels, bit-identical to the reference's serial recurrence (default, parity mode)"
                                        if mode == "exact" else
+                                       "exact+sine: the exact band-pass kernels AND engine option sine_mode 1 -- the oscillators evaluate glibc's sinf operation "
+                                       "for operation (kernels.hip sin_glibc): the whole render bit for bit the oracle's (tests/test_gpu_sine_exact.py); "
+                                       "what a bare td_graph does with nothing set" if mode == "exact+sine" else
                                        "guard: the scan kernels under the guard (band_mode 2, the front-end's default): every render estimates its own "
                                        "deviation and is redone with the exact kernels when over 2e-7 RMS (tests/test_gpu_band_guard.py)" if mode == "guard" else
                                        "scan: blocked affine scan (k_band_scan / k_band_chain), tolerance class: <= 1e-6 RMS and +-1 LSB against the "
                                        "oracle (tests/test_gpu_band_scan.py; measured RMS per chain depth: profiles/%s_scan_rms.txt)" % PROFILE_TAG)
         vkey = name if mode in (None, "exact") else name + "_scan"   # (the guarded launches are priced with the scan entry's counters)
+        if mode == "exact+sine":
+            vkey = "-"   # (no counters committed for the exact-sine form of k_synth: no bound claimed)
         insts = (valu.get(vkey, {}).get(dom[0]) or {}).get("SQ_INSTS_VALU")
         if name == "config1":
             floor = launches * 1.45e-3    # MI355X_MICROARCH.md price list, row "boundary": dependent kernel boundary 1.45 us
@@ -685,6 +692,9 @@ def compact(o):
             row = {"config": x["config"], "ms": x["ms_per_render"], "Msps": x["Msamples_per_s"], "launches": x["launches_per_render"]}
             if "band_mode" in x:
                 row["band_mode"] = x["band_mode"]
+            if x.get("band_mode") == "exact+sine":   # (the line's budget: time only)
+                rows.append(row)
+                continue
             if "guard" in x:
                 row["guard"] = {"redos": x["guard"]["redos"], "est": float("%.3g" % x["guard"]["max_est"])}
             ks = x.get("kernels") or []

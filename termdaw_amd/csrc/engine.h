@@ -398,7 +398,7 @@ struct td_graph {
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
-    int sine_mode = 0;                         // 0: the device sine of the tolerance class (<= 3.3e-7 from glibc's sinf), 1: glibc's sinf operation for operation (bit-exact; ~6 x the cost per oscillator)
+    int sine_mode = 1;                         // 1 (a bare td_graph's default, like band_mode 0: the reference's bytes): debug_sine / synth evaluate glibc's sinf operation for operation and adsr.rs's own divisions; 0 (the front-end's default): the device sine of the tolerance class (<= 3.3e-7 from sinf) and the affine / one-grid Synth forms
     int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
                                                //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex),
                                                // 2: the scan under the guard (tde::Guard below): every render estimates its own

@@ -41,14 +41,24 @@ def test_sine_kinds_bit_exact(gpu_api, oracle, name, mk):
         _assert_bits(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
 
 
-def test_the_default_is_the_fast_sine_and_differs(gpu_api, oracle):
-    """... and without the option the same project is in the tolerance class (<= 1e-6 RMS, not the same bits): the option is what
-    does it."""
+def test_the_fast_sine_differs_and_the_bare_graph_defaults_to_the_exact_one(gpu_api, oracle):
+    """sine_mode 0 (the front-end's default, and what workloads.ProjectScript builds with) is the tolerance class -- <= 1e-6 RMS,
+    not the same bits: the option is what does it.  A bare td_graph (nothing set) evaluates the exact sine, as it runs the exact
+    band-pass kernels."""
     p = W.synth_project(seconds=1.0)
+    rp, rf = p.render(oracle)
     gf = p.render(gpu_api)[1]
-    rf = p.render(oracle)[1]
     assert not np.array_equal(_bits(gf), _bits(rf))
     assert float(np.sqrt(np.mean((gf.astype(np.float64) - rf.astype(np.float64)) ** 2))) <= 1e-6
+    sb, fb, g = gpu_api.SampleBank(48000), gpu_api.FlowwBank(48000, 256), gpu_api.Graph(256, 48000)
+    ob, of_, og = oracle.SampleBank(48000), oracle.FlowwBank(48000, 256), oracle.Graph(256, 48000)
+    ev = np.array([(0.0, 57.0, 0.9), (0.21, 64.0, 0.7), (0.4, 57.0, 0.0)], np.float32)
+    for f_, g_ in ((fb, g), (of_, og)):
+        f_.add_events("f", ev)
+        g_.add_debug_sine("s", 0.9, 10.0, 0)
+        g_.set_output("s")
+    got, ref = g.render_all(sb, fb, 100), og.render_all(ob, of_, 100)
+    _assert_bits(got, ref)
 
 
 @pytest.mark.parametrize("seed", list(range(100, 124)) + [123475, 131214, 133930])

@@ -3,7 +3,9 @@
 python tools/fuzz_soak.py 1000 3000 scan (the same random graphs with the tolerance-class band-pass, engine option band_mode 1:
 chains, the Sum vertex in front and the Normalize vertex behind a scan launch -- <= 1e-6 RMS of the output's scale),
 python tools/fuzz_soak.py 1000 3000 guard (the same in band_mode 2, the front-end's default: the scan under the guard -- renders
-whose own estimate is over the bound are done again with the exact kernels; the summary counts them).  `--jobs N` as a last
+whose own estimate is over the bound are done again with the exact kernels; the summary counts them),
+python tools/fuzz_soak.py 1000 3000 exactsin (the graphs with debug_sine / synth again, engine option sine_mode 1: glibc's sinf on
+the device -- every render bit for bit, like the first form).  `--jobs N` as a last
 argument pair splits the seed range over N processes (the CPU oracle is the slow side)."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +34,7 @@ if "--jobs" in sys.argv:
 sinf = len(sys.argv) > 3 and sys.argv[3] in ("sinf", "scan", "guard")
 scan_mode = len(sys.argv) > 3 and sys.argv[3] in ("scan", "guard")
 guard_mode = len(sys.argv) > 3 and sys.argv[3] == "guard"
+exact_sine = len(sys.argv) > 3 and sys.argv[3] == "exactsin"   # debug_sine / synth allowed, engine option sine_mode 1: bit for bit
 bad, rejected = [], 0
 sine_class = []   # (scan / guard modes) renders over 1e-6 that are as far off with the exact band-pass kernels
 audits = redos = renders = 0
@@ -40,7 +43,7 @@ only = os.environ.get("TD_SOAK_ONLY", "")
 for seed in range(lo_seed, hi_seed):
     if os.environ.get("TD_SOAK_VERBOSE"):
         print("seed", seed, file=sys.stderr, flush=True)
-    p = F.random_project(seed, allow_sinf=sinf)
+    p = F.random_project(seed, allow_sinf=sinf or exact_sine)
     if only == "bl64wt" and not (p.bl == 64 and p.calls["add_sampsyn"]):   # (the class the load faults of DESIGN.md 7 were seen in)
         continue
     try:
@@ -56,6 +59,8 @@ for seed in range(lo_seed, hi_seed):
     gb = p.build(api)
     if scan_mode:
         gb[2].set_option("band_mode", 2 if guard_mode else 1)
+    if exact_sine:
+        gb[2].set_option("sine_mode", 1)
     for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=norm_debug=1
         gb[2].set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for ki, scan in enumerate((False, True, False)):
