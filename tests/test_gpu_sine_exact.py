@@ -41,6 +41,16 @@ def test_sine_kinds_bit_exact(gpu_api, oracle, name, mk):
         _assert_bits(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
 
 
+def test_config3_full_60s_bit_exact(gpu_api, oracle):
+    """BASELINE config 3 at the size the bench times it (2 813 blocks; 32 voices x 3 oscillators -> adsr -> band-pass ->
+    normalize) with every kind exact: PCM and f32 the oracle's, bit for bit."""
+    p = W.config3()
+    assert p.cs == 2813
+    gb = _exact(p, gpu_api)
+    gb[2].set_option("band_mode", 0)
+    _assert_bits(p.render(gpu_api, built=gb), p.render(oracle))
+
+
 def test_the_fast_sine_differs_and_the_bare_graph_defaults_to_the_exact_one(gpu_api, oracle):
     """sine_mode 0 (the front-end's default, and what workloads.ProjectScript builds with) is the tolerance class -- <= 1e-6 RMS,
     not the same bits: the option is what does it.  A bare td_graph (nothing set) evaluates the exact sine, as it runs the exact
