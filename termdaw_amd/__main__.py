@@ -32,7 +32,7 @@ def main(argv=None):
                          "<= 1e-6 RMS / +-1 LSB, 28x faster on a deep effect chain)")
     ap.add_argument("--exact-sine", action="store_true",
                     help="debug_sine / synth vertices evaluate glibc's sinf bit for bit (default: the tolerance-class device sine, <= 1e-6 RMS; "
-                         "config 3's oscillators take 0.38 instead of 0.09 ms)")
+                         "config 3's oscillators take 0.32 instead of 0.09 ms)")
     ap.add_argument("--stream", action="store_true", help="stream workflow: events from stdin, block pulls at the playhead")
     ap.add_argument("--realtime", action="store_true", help="with --stream: pace the pulls against the wall clock")
     args = ap.parse_args(argv)

@@ -1519,8 +1519,29 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
     const uint32_t i0 = find_interval(d.tab, ma), i1 = two_a ? find_interval(d.tab, ma + 1u) : i0;
     const uint32_t i2 = find_interval(d.tab, mb), i3 = two_b ? find_interval(d.tab, mb + 1u) : i2;
     const uint32_t it0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)i0);
-    // (sine_mode 1: every frame takes the per-frame form below -- the reference's own order of operations, exact divisions)
-    if (!d.exact_sin && __all((i0 == it0 && i1 == it0 && i2 == it0 && i3 == it0) ? 1 : 0)) {
+    const bool one_interval = __all((i0 == it0 && i1 == it0 && i2 == it0 && i3 == it0) ? 1 : 0) != 0;
+    if (d.exact_sin && one_interval) {
+        // sine_mode 1: every frame in the reference's own order of operations (synth_voice: exact divisions, sin_glibc) -- what the
+        // wave shares is the walk: one interval look-up, the voice records through scalar loads, once for its four frames each
+        const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
+        const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
+        typedef float f4c __attribute__((ext_vector_type(4)));
+        const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
+        const f2 ta = synth_time2(d, ma), tb = synth_time2(d, mb), oa = synth_off2(d, ma), ob = synth_off2(d, mb);
+        float a0 = 0.0f, a1 = 0.0f, b0 = 0.0f, b1 = 0.0f;
+        for (uint32_t v = v0; v < v1; ++v) {
+            const f4c q = vc[v];
+            const float4 n = make_float4(q.x, q.y, q.z, q.w);
+            a0 += synth_voice(d, n, ta.x, oa.x);
+            a1 += synth_voice(d, n, ta.y, oa.y);
+            b0 += synth_voice(d, n, tb.x, ob.x);
+            b1 += synth_voice(d, n, tb.y, ob.y);
+        }
+        pa = make_float2(a0, two_a ? a1 : 0.0f);
+        pb = make_float2(b0, two_b ? b1 : 0.0f);
+        return;
+    }
+    if (!d.exact_sin && one_interval) {
         const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
         const uint32_t v0 = off_c[it0], v1 = off_c[it0 + 1u];
         typedef float f4c __attribute__((ext_vector_type(4)));

@@ -493,7 +493,7 @@ td_state* td_state_new(const char* wdir, size_t project_samplerate, size_t buffe
     // redone).  td_state_set_option(s, "band_mode", 0) selects the exact kernels outright, 1 the scan without the guard.
     s->g->band_mode = 2;
     // ... and its debug_sine / synth vertices the tolerance-class sine ("sine_mode" 0: <= 1e-6 RMS on the vertex' output; config 3's
-    // oscillators in 0.09 instead of 0.38 ms).  td_state_set_option(s, "sine_mode", 1): glibc's sinf bit for bit (kernels.hip sin_glibc).
+    // oscillators in 0.09 instead of 0.32 ms).  td_state_set_option(s, "sine_mode", 1): glibc's sinf bit for bit (kernels.hip sin_glibc).
     s->g->sine_mode = 0;
     return s;
 }
