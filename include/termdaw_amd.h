@@ -328,16 +328,18 @@ td_state* td_state_new(const char* wdir, size_t project_samplerate, size_t buffe
 /* Reads <wdir>/project.toml ([settings] main, buffer_length=1024, project_samplerate=44100; config.rs:19-76). */
 td_state* td_state_open(const char* wdir);
 void td_state_free(td_state* s);
-/* Engine options of the State's graph (the keys of td_graph_set_option; they survive td_state_refresh).  ONE default
- * differs from a bare td_graph: a State renders band-pass vertices in SCAN mode ("band_mode" 1) -- band_pass_gen
- * (extensions.rs:654-689) as a blocked affine scan, tolerance class: <= 1e-6 RMS on the f32 output and +-1 LSB on the PCM
- * against the reference's serial recurrence (measured 6.3e-8 RMS through 84 band-pass vertices in a row; above 1e-6 of the
- * output peak only where a band-pass vertex removes >= 30 dB of its input and a Normalize vertex brings the rest back up: 8 of
- * 18 000 random graphs, at most 3.3e-6).  That is the bound BASELINE's north_star sets for float filter paths, and it is what
- * makes a deep effect chain fast: BASELINE config 4 (84 band-pass vertices) renders in 0.39 ms in scan mode and 12.0 ms with the
- * exact kernels.  td_state_set_option(s, "band_mode", 0) selects the exact kernels -- bit-identical to the reference's
- * recurrence, the mode every bit-exact parity test runs in; a project without band-pass vertices renders the same bytes in
- * both. */
+/* Engine options of the State's graph (the keys of td_graph_set_option; they survive td_state_refresh).  TWO defaults differ
+ * from a bare td_graph's -- a State trades the reference's bytes for speed inside the bound BASELINE's north_star sets for float
+ * synth / filter paths (1e-6 RMS), a bare graph does not:
+ *   "band_mode" 2: band-pass vertices (band_pass_gen, extensions.rs:654-689) as a blocked affine scan UNDER THE GUARD -- every
+ *     render estimates its own deviation from the reference's serial recurrence and is rendered again with the exact kernels when
+ *     the estimate is over 2e-7 (td_graph_band_guard_stats).  BASELINE config 4 (84 band-pass vertices): 0.39 ms instead of 12.2 ms;
+ *     180 000 random-graph renders: none above 1e-6 by the filter arithmetic.  td_state_set_option(s, "band_mode", 0): the exact
+ *     kernels outright, bit-identical to the reference's recurrence;
+ *   "sine_mode" 0: debug_sine / synth with the tolerance-class device sine (<= 3.3e-7 from libm's sinf per oscillator; <= 1e-6 RMS of
+ *     the vertex' scale) and the affine / one-grid Synth forms.  td_state_set_option(s, "sine_mode", 1): glibc's sinf operation for
+ *     operation, the reference's bytes.
+ * A project without band-pass, debug_sine and synth vertices renders the same bytes either way. */
 int td_state_set_option(td_state* s, const char* key, long value);
 /* State::refresh state.rs:50-471 on the given Lua source / on <wdir>/<main>. 1 = loaded. */
 int td_state_refresh_source(td_state* s, const char* lua_source);
