@@ -185,6 +185,9 @@ size_t td_graph_device_bytes(const td_graph* g);
  * DESIGN.md 3 "Memory").  td_trim_memory gives everything on the free lists back to the driver now; td_cached_memory_bytes
  * says how much is there. */
 void td_trim_memory(void);
+/* Diagnostic (no reference counterpart): out[i] = the engine's sine of in[i], evaluated on the device -- sine_mode 1: glibc's sinf
+ * restated (what debug_sine / synth use under engine option "sine_mode" 1; tests compare it with the host's sinf on all 2^32 bit patterns), 0: the tolerance-class sine.  Host pointers, n values; 1 = done. */
+int td_device_sinf(const float* in, float* out, size_t n, int sine_mode);
 size_t td_cached_memory_bytes(void);
 /* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
  * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "td_graph_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
     "td_graph_device_bytes": (_sz, [_vp]),
     "td_trim_memory": (None, []),
+    "td_device_sinf": (_i32, [_fp, _fp, _sz, _i32]),
     "td_cached_memory_bytes": (_sz, []),
     "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
     "td_graph_band_stats": (_i32, [_vp, C.POINTER(C.c_uint32)]),

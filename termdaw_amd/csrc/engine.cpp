@@ -2001,6 +2001,22 @@ size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float*
     (void)hipStreamSynchronize(g->stream);
     return prof_collect(g->prof, names, ms, launches, cap);
 }
+int td_device_sinf(const float* in, float* out, size_t n, int sine_mode) {   // (diagnostic: the engine's sine over a host array)
+    if (!n) return 1;
+    if (n > 0xFFFFFFFFu) return fail("td_device_sinf: at most 2^32 - 1 values per call");
+    if (!ensure_device(cur_device())) return 0;
+    float *d_in = nullptr, *d_out = nullptr;
+    TD_HIP(hipMalloc(&d_in, n * sizeof(float)));
+    if (hipMalloc(&d_out, n * sizeof(float)) != hipSuccess) { (void)hipFree(d_in); return fail("td_device_sinf: out of device memory"); }
+    int ok = hipMemcpy(d_in, in, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    if (ok) {
+        launch_sinf(d_in, d_out, (uint32_t)n, sine_mode != 0, nullptr);
+        ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(out, d_out, n * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    return ok ? 1 : fail("td_device_sinf: HIP error");
+}
 void td_trim_memory(void) { tde::mem_trim(); }
 size_t td_cached_memory_bytes(void) { return tde::mem_cached_bytes(); }
 size_t td_graph_device_bytes(const td_graph* g) { return g->device_bytes + g->arena.device_bytes; }

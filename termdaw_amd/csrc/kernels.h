@@ -522,6 +522,7 @@ void launch_scale(const ScaleDesc* d, int n_desc, uint32_t frames, uint32_t bl, 
 // second half of the speculative single-pass normalize: a no-op unless a block peak exceeded the carried max
 void launch_norm_fix(const SumDesc* d, int n_desc, uint32_t frames, uint32_t bl, hipStream_t s);
 void launch_quantise(const QuantDesc* d, int n_desc, uint32_t frames, hipStream_t s);
+void launch_sinf(const float* in, float* out, uint32_t n, int exact, hipStream_t s);   // out[i] = sin_glibc(in[i]) (exact) or sin_any(in[i])
 void launch_debug_verify(const uint32_t* p, uint32_t n_words, const uint32_t* seg_sums, uint32_t* report, hipStream_t s);   // (TD_DEBUG_SYNC & 16)
 void launch_sample_loop(const LoopDesc* d, int n_desc, uint32_t frames, hipStream_t s);
 void launch_sample_multi(const MultiDesc* d, int n_desc, uint32_t frames, hipStream_t s);

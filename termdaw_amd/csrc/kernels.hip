@@ -4323,6 +4323,14 @@ __global__ __launch_bounds__(kThreads) void k_debug_verify(const uint32_t* __res
         }
     }
 }
+// the engine's two sines over an array (td_device_sinf: what tests/test_gpu_sine_exact.py compares with the host's sinf)
+__global__ __launch_bounds__(kThreads) void k_sinf(const float* __restrict__ in, float* __restrict__ out, uint32_t n, int exact) {
+    for (uint32_t i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) out[i] = exact ? sin_glibc(in[i]) : sin_any(in[i]);
+}
+void launch_sinf(const float* in, float* out, uint32_t n, int exact, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_sinf, dim3(std::min<uint32_t>((n + kThreads - 1) / kThreads, 8192u)), dim3(kThreads), 0, s, in, out, n, exact);
+}
 void launch_debug_verify(const uint32_t* p, uint32_t n_words, const uint32_t* seg_sums, uint32_t* report, hipStream_t s) {
     if (!n_words) return;
     hipLaunchKernelGGL(k_debug_verify, dim3(512), dim3(kThreads), 0, s, p, n_words, seg_sums, report);

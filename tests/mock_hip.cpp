@@ -114,6 +114,7 @@ void launch_adsr_env(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t) {
         if (d[i].env_tile) touch_w(d[i].env_tile, (size_t)((frames + 511) / 512) * 4);
     }
 }
+void launch_sinf(const float* in, float* out, uint32_t n, int, hipStream_t) { touch(in, (size_t)n * 4); touch_w(out, (size_t)n * 4); }
 void launch_debug_verify(const uint32_t* p, uint32_t n_words, const uint32_t* seg, uint32_t* report, hipStream_t) { touch(p, (size_t)n_words * 4); touch(seg, (size_t)((n_words + 63) / 64) * 4); touch_w(report, 256); }
 void launch_band_audit(const AuditHead* h, int n, hipStream_t) {
     touch_descs(h, n);

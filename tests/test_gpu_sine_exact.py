@@ -98,3 +98,37 @@ def test_front_end_option(gpu_api, oracle, tmp_path):
     assert np.array_equal(s.render_to_memory(), ref_pcm)
     assert s.refresh(p.to_lua(str(tmp_path / "a"))), gpu_api.last_error()      # (options survive State::refresh)
     assert np.array_equal(s.render_to_memory(), ref_pcm)
+
+
+def test_the_device_sine_is_the_hosts_sinf_over_every_magnitude(gpu_api, tmp_path):
+    """td_device_sinf(.., sine_mode 1) = kernels.hip sin_glibc on the device, against THIS host's sinf (a two-line C shim, built
+    here) on EVERY float there is -- all 2^32 bit patterns, denormals, both zeros, infinities and NaNs included: the same bits,
+    NaN where sinf gives NaN."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("needs gcc for the host shim")
+    src = tmp_path / "shim.c"
+    src.write_text("#include <math.h>\n#include <stddef.h>\nvoid host_sinf(const float* in, float* out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = sinf(in[i]); }\n")
+    so = str(tmp_path / "shim.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", str(src), "-o", so, "-lm"])
+    shim = C.CDLL(so)
+    fp = C.POINTER(C.c_float)
+    shim.host_sinf.argtypes = [fp, fp, C.c_size_t]
+    lib = gpu_api.lib()
+
+    def check(bits):
+        x = bits.view(np.float32)
+        dev = np.empty_like(x)
+        ref = np.empty_like(x)
+        assert lib.td_device_sinf(x.ctypes.data_as(fp), dev.ctypes.data_as(fp), x.size, 1), gpu_api.last_error()
+        shim.host_sinf(x.ctypes.data_as(fp), ref.ctypes.data_as(fp), x.size)
+        nan = np.isnan(ref)
+        assert np.array_equal(np.isnan(dev), nan)
+        bad = np.nonzero((dev.view(np.uint32) != ref.view(np.uint32)) & ~nan)[0]
+        assert bad.size == 0, "sin(%r): device %r host %r (%d of %d differ)" % (x[bad[0]], dev[bad[0]], ref[bad[0]], bad.size, x.size)
+
+    step = 1 << 24
+    for lo in range(0, 1 << 32, step):        # 256 chunks of 2^24: every bit pattern there is (22 s on the MI355X box)
+        check(np.arange(lo, lo + step, dtype=np.uint64).astype(np.uint32))
