@@ -215,7 +215,7 @@ size_t td_cached_memory_bytes(void);
  * "sine_mode" 0|1 (default 1 on a bare td_graph, 0 on a State's graph: debug_sine_gen / synth_gen, extensions.rs:450,501 `f32::sin`.
  * 1 = the oscillators evaluate glibc's sinf -- libm's, what `f32::sin` calls on Linux -- operation for operation in double
  * precision (glibc 2.28 and later, x86-64 FMA variant; tools/sinf_restate.c agrees with the host's sinf on every finite float) and
- * the envelopes adsr.rs's own divisions: the two kinds carry the reference's bits like every other kind (20 000 random graphs x 3
+ * the envelopes adsr.rs's own divisions: the two kinds carry the reference's bits like every other kind (50 000 random graphs x 3
  * renders bit for bit).  0 = the tolerance class: a 14-instruction f32 sine (<= 3.3e-7 from sinf), reciprocal envelopes, the
  * affine / one-grid Synth forms -- <= 1e-6 RMS of the vertex' scale, 0.09 instead of 0.32 ms for BASELINE config 3's oscillators);
  * "one_grid_sources" 0|1 (default 1: the launches of a level that read no edge buffer -- affine Synth, wavetable voice,
