@@ -2003,7 +2003,7 @@ size_t td_graph_last_kernel_times(const td_graph* gc, const char** names, float*
 }
 int td_device_sinf(const float* in, float* out, size_t n, int sine_mode) {   // (diagnostic: the engine's sine over a host array)
     if (!n) return 1;
-    if (n > 0xFFFFFFFFu) return fail("td_device_sinf: at most 2^32 - 1 values per call");
+    if (n > 0x40000000u) return fail("td_device_sinf: at most 2^30 values per call");   // (the kernel strides a 32-bit index)
     if (!ensure_device(cur_device())) return 0;
     float *d_in = nullptr, *d_out = nullptr;
     TD_HIP(hipMalloc(&d_in, n * sizeof(float)));
