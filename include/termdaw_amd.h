@@ -337,7 +337,7 @@ void td_state_free(td_state* s);
  *   "band_mode" 2: band-pass vertices (band_pass_gen, extensions.rs:654-689) as a blocked affine scan UNDER THE GUARD -- every
  *     render estimates its own deviation from the reference's serial recurrence and is rendered again with the exact kernels when
  *     the estimate is over 2e-7 (td_graph_band_guard_stats).  BASELINE config 4 (84 band-pass vertices): 0.39 ms instead of 12.2 ms;
- *     180 000 random-graph renders: none above 1e-6 by the filter arithmetic.  td_state_set_option(s, "band_mode", 0): the exact
+ *     270 000 random-graph renders: none above 1e-6 by the filter arithmetic.  td_state_set_option(s, "band_mode", 0): the exact
  *     kernels outright, bit-identical to the reference's recurrence;
  *   "sine_mode" 0: debug_sine / synth with the tolerance-class device sine (<= 3.3e-7 from libm's sinf per oscillator; <= 1e-6 RMS of
  *     the vertex' scale) and the affine / one-grid Synth forms.  td_state_set_option(s, "sine_mode", 1): glibc's sinf operation for
