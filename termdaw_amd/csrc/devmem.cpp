@@ -32,7 +32,6 @@ struct MemCache {
     std::mutex mu;
     std::map<void*, Block> live;
     std::multimap<std::tuple<int, unsigned, size_t>, void*> free_list;
-    std::map<void*, size_t> free_size;
     std::atomic<size_t> cached_bytes{0};
     size_t budget() {
         static const size_t b = (size_t)(getenv("TD_ALLOC_CACHE_MB") ? atoll(getenv("TD_ALLOC_CACHE_MB")) : 2048) << 20;
@@ -69,7 +68,6 @@ struct MemCache {
                 p = it->second;
                 size = std::get<2>(it->first);
                 free_list.erase(it);
-                free_size.erase(p);
                 cached_bytes -= size;
             }
         }
@@ -92,16 +90,20 @@ struct MemCache {
     hipError_t put(void* p) {
         if (!p) return hipSuccess;
         Block b{};
+        bool ours = false;
         {
             std::lock_guard<std::mutex> lk(mu);
             auto it = live.find(p);
-            if (it == live.end()) {   // (not from here: the driver's own calls)
-                if ((hipFree)(p) == hipSuccess) return hipSuccess;
-                (void)hipGetLastError();
-                return (hipHostFree)(p);
+            if (it != live.end()) {
+                b = it->second;
+                live.erase(it);
+                ours = true;
             }
-            b = it->second;
-            live.erase(it);
+        }
+        if (!ours) {   // (not from here: the driver's own calls)
+            if ((hipFree)(p) == hipSuccess) return hipSuccess;
+            (void)hipGetLastError();
+            return (hipHostFree)(p);
         }
         // what hipFree does before it lets go of memory -- on the block's own device: nothing that uses it is still running
         int cur = 0;
@@ -113,7 +115,6 @@ struct MemCache {
         } else {
             std::lock_guard<std::mutex> lk(mu);
             free_list.emplace(std::make_tuple(b.device, b.kind, b.size), p);
-            free_size[p] = b.size;
             cached_bytes += b.size;
         }
         if (cur != b.device) (void)hipSetDevice(cur);
@@ -130,7 +131,6 @@ struct MemCache {
                     if (std::get<2>(j->first) > std::get<2>(it->first)) it = j;
                 gone.push_back({it->second, it->first});
                 cached_bytes -= std::get<2>(it->first);
-                free_size.erase(it->second);
                 free_list.erase(it);
             }
         }
