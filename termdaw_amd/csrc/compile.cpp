@@ -19,7 +19,7 @@ using namespace tdk;
 namespace tde {
 
 const char* const kFamilyName[F_COUNT] = {"k_sample_loop", "k_sample_multi", "k_sample_lerp", "k_debug_sine",
-                                           "k_synth",       "k_sampsyn", "k_adsr_env", "k_sum",          "k_scale",       "k_norm_fix",
+                                           "k_synth",       "k_sampsyn", "k_adsr_env", "k_sine_probe", "k_sum",          "k_scale",       "k_norm_fix",
                                            "k_adsr",        "k_band_pass",    "k_band_spec", "k_band_fix", "k_band_fill", "k_band_scan", "k_quantise", "k_band_audit", "k_sources"};
 
 
@@ -106,6 +106,9 @@ struct VTables {   // per-vertex compile result: offsets into the vertex' table 
     size_t istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0, tile_order_off = 0;
     uint32_t n_int = 0;
     uint64_t t0 = 0;
+    size_t raw_istart_off = 0, raw_ivoff_off = 0, raw_voices_off = 0, raw_tile_first_off = 0;   // (TableCache: a probed affine Synth vertex)
+    uint32_t raw_n_int = 0;
+    size_t probe_v_off = 0;   // (a probed sine / Synth vertex) per sample of k_sine_probe: its frame's voice range in the raw table
 };
 
 static PanGain make_pg(float gain, float angle) {
@@ -233,6 +236,29 @@ static void put_intervals(IntervalView ib, Staging& st, VTables& vt) {
     vt.voices_off = st.put(ib.voices);
 }
 
+// k_sine_probe's sampling of a chunk of M frames (kernels.h ProbeDesc): one frame in every `1 << lg` -- every 256th of a long
+// chunk, every 16th of a single block
+static uint32_t probe_stride_log2(size_t M) {
+    uint32_t lg = 4;
+    while (lg < 8 && ((size_t)128 << lg) <= M) ++lg;
+    return lg;
+}
+// ... and, per sample, the voice records of its frame's interval {first, one past the last} -- what the kernel would find by
+// walking the interval table (two or three dependent loads in a launch that is nothing but latency)
+static size_t put_probe_ranges(IntervalView ib, Staging& st) {
+    const uint32_t lg = probe_stride_log2(ib.limit);
+    const uint32_t n = (uint32_t)(((size_t)ib.limit + ((size_t)1 << lg) - 1) >> lg);
+    std::vector<uint32_t> r((size_t)n * 2 + 2, 0u);
+    size_t it = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t m = probe_frame(i, lg);   // (ascending in i)
+        if (m >= ib.limit || ib.istart.empty()) continue;
+        while (it + 1 < ib.istart.size() && ib.istart[it + 1] <= m) ++it;
+        r[2 * (size_t)i] = ib.ivoff[it];
+        r[2 * (size_t)i + 1] = ib.ivoff[it + 1];
+    }
+    return st.put(r);
+}
 // ---- DebugSine (extensions.rs:423-457) ----
 static void compile_sine(Vertex& v, const td_flowwbank* fb, const std::vector<BlockCursor>& cur, size_t bl,
                          Staging& st, VTables& vt) {
@@ -261,6 +287,7 @@ static void compile_sine(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
             [&](size_t i) { emit(b * bl + i); });
     }
     put_intervals(ib, st, vt);
+    if (v.probe) vt.probe_v_off = put_probe_ranges(IntervalView{ib.istart, ib.ivoff, ib.voices, ib.limit}, st);
 }
 
 // ---- Synth (extensions.rs:460-529) ----
@@ -456,9 +483,19 @@ static int compile_synth(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
         std::vector<float4> rec;
         synth_refine_affine(v, ib, bl, sr, istart, ivoff, rec);
         put_intervals(IntervalView{istart, ivoff, rec, ib.limit}, st, vt);
+        if (v.probe) {   // (sine_mode 2) the raw table too: k_sine_probe evaluates the reference's own per-frame form
+            VTables raw;
+            put_intervals(IntervalView{ib.istart, ib.ivoff, ib.voices, ib.limit}, st, raw);
+            vt.raw_istart_off = raw.istart_off; vt.raw_ivoff_off = raw.ivoff_off; vt.raw_voices_off = raw.voices_off;
+            vt.raw_tile_first_off = raw.tile_first_off; vt.raw_n_int = raw.n_int;
+            vt.probe_v_off = put_probe_ranges(IntervalView{ib.istart, ib.ivoff, ib.voices, ib.limit}, st);
+        }
         return 1;
     }
     put_intervals(ib, st, vt);
+    vt.raw_istart_off = vt.istart_off; vt.raw_ivoff_off = vt.ivoff_off; vt.raw_voices_off = vt.voices_off;
+    vt.raw_tile_first_off = vt.tile_first_off; vt.raw_n_int = vt.n_int;
+    if (v.probe) vt.probe_v_off = put_probe_ranges(IntervalView{ib.istart, ib.ivoff, ib.voices, ib.limit}, st);
     return 1;
 }
 
@@ -586,7 +623,8 @@ static void table_key(const Vertex& v, const td_flowwbank* fb, const std::vector
     switch (v.kind) {
         case K_SAMPLE_MULTI: put_pod(key, (uint64_t)sample_len); break;
         case K_SAMPLE_LERP: put_pod(key, (uint64_t)v.lerp_len); break;
-        case K_SYNTH: put_pod(key, v.square); put_pod(key, v.topflat); put_pod(key, v.triangle); put_pod(key, (uint8_t)v.exact_sin); break;   // (retain rule: release times; the table's form)
+        case K_DEBUG_SINE: put_pod(key, (uint8_t)v.probe); break;   // (the table's form: with or without k_sine_probe's voice ranges)
+        case K_SYNTH: put_pod(key, v.square); put_pod(key, v.topflat); put_pod(key, v.triangle); put_pod(key, (uint8_t)v.exact_sin); put_pod(key, (uint8_t)v.probe); break;   // (retain rule: release times; the table's form)
         case K_SAMPSYN: put_pod(key, v.conf); break;
         case K_ADSR: put_pod(key, (uint8_t)v.use_off); put_pod(key, v.conf); break;
         default: break;
@@ -744,6 +782,83 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     g->band_stats_off.clear();
     g->band_stats_base = nullptr;
     g->guard.chunk_audited = false;
+    std::vector<std::vector<size_t>> cons(nv);
+    for (size_t vi : g->order)
+        for (size_t u : g->edges[vi]) cons[u].push_back(vi);
+    const bool scan_on = g->band_mode >= 1;
+    // ---- the guard (band_mode 2, engine.h tde::Guard): a band-pass vertex takes the scan only where the launch's own estimate
+    // of its deviation can be carried to the graph's output -- `down[u]`: the static gain from vertex u's output to the
+    // graph's (pan / gain of everything downstream, largest channel; several paths add up; an Adsr vertex on the way at the
+    // largest gain its conf and its events' velocities allow) and the ONE Normalize vertex every path runs through, if any
+    // (its 1 / max is read from its peak table by k_band_audit); anything else -- two Normalize vertices in a row, paths that
+    // differ in it -- keeps the exact kernels.  So does a vertex downstream of a sample loop shorter than 2 048 frames:
+    // a period shorter than the smoother's memory repeats its rounding pattern, the offsets add up coherently and no
+    // level-based estimate bounds them (DESIGN.md 3e "The guard").
+    const bool guard_on = g->band_mode == 2 && !g->guard.in_redo && g->band_chain;
+    // ---- the sine kinds under the same guard (engine option "sine_mode" 2, kernels.h ProbeDesc): a debug_sine / synth vertex
+    // takes its fast form only where what k_sine_probe measures at its output can be carried to the graph's output the same way;
+    // anything else -- and the second render of a graph whose verdict was over the bound -- takes glibc's sinf (sine_mode 1's form)
+    const bool sguard_on = g->sine_mode == 2 && !g->guard.in_redo;
+    struct PathGain { double g; long norm; };   // norm: -1 none, >= 0 that Normalize vertex, -2 not analysable
+    std::vector<PathGain> down;
+    std::vector<char> short_up;
+    auto own_gain = [](const Vertex& v) {
+        const PanGain pg = make_pg(v.gain, v.angle);
+        double a = 1.0;
+        if (pg.flags & 1u) a *= std::max(fabs((double)pg.l_amp), fabs((double)pg.r_amp));
+        if (pg.flags & 2u) a *= fabs((double)pg.gain);
+        return a;
+    };
+    if (guard_on || sguard_on) {
+        down.assign(nv, PathGain{0.0, -1});
+        short_up.assign(nv, 0);
+        for (size_t vi : g->order) {   // inputs first
+            const Vertex& v = g->vertices[vi];
+            char su = (v.kind == K_SAMPLE_LOOP && v.sample_index < sb->samples.size() && sb->samples[v.sample_index].len < 2048) ? 1 : 0;
+            for (size_t u : g->edges[vi]) su = su || short_up[u];
+            short_up[vi] = su;
+        }
+        for (size_t k = g->order.size(); k-- > 0;) {   // consumers first
+            const size_t u = g->order[k];
+            if ((long)u == g->output_vertex) { down[u] = PathGain{1.0, -1}; continue; }
+            double sum = 0.0;
+            long nz = -1;
+            bool first = true;
+            for (size_t w : cons[u]) {   // (a duplicate edge is listed twice: the term is summed twice)
+                const Vertex& wv = g->vertices[w];
+                long through = down[w].norm;
+                if (through == -2) { nz = -2; break; }
+                double L = own_gain(wv);
+                if (wv.kind == K_ADSR && !(wv.wet < 0.0001f)) {   // |lerp(1, level x vel, wet)| <= max(1, |level| |vel|)
+                    const AdsrConfD& c = wv.conf;
+                    double lv = std::max(std::max(fabs((double)c.std_vel), fabs((double)c.attack_vel)),
+                                         std::max(std::max(fabs((double)c.decay_vel), fabs((double)c.sustain_vel)), fabs((double)c.release_vel)));
+                    double mv = 0.0;
+                    for (const td_event& e : floww_of(fb, wv.floww_index)) mv = std::max(mv, fabs((double)e.vel));
+                    L *= std::max(1.0, lv * mv);
+                }
+                if (wv.kind == K_NORMALIZE) {
+                    if (through != -1) { nz = -2; break; }
+                    through = (long)w;
+                }
+                if (first) { nz = through; first = false; }
+                else if (nz != through) { nz = -2; break; }
+                sum += L * down[w].g;
+            }
+            if (!(sum == sum) || std::isinf(sum)) nz = -2;
+            down[u] = PathGain{sum, nz};
+        }
+    }
+    auto guard_ok = [&](size_t vi, const ScanPlan& sp) {   // (`pass` vertices: the chain launch; `cut` vertices: k_band_scan, one vertex per launch)
+        (void)sp;
+        return down[vi].norm != -2 && !short_up[vi];
+    };
+    for (size_t vi : g->order) {
+        Vertex& v = g->vertices[vi];
+        if (v.kind != K_DEBUG_SINE && v.kind != K_SYNTH) continue;
+        v.probe = sguard_on && down[vi].norm != -2;
+        v.exact_sin = g->sine_mode == 1 || (g->sine_mode == 2 && !v.probe);
+    }
     // ---- 1. host compile: sequential bookkeeping -> tables
     const auto tp0 = std::chrono::steady_clock::now();
     Staging& st = *cb.st;   // capacity kept from render to render
@@ -810,6 +925,8 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                 tc->istart_off = t.istart_off; tc->ivoff_off = t.ivoff_off; tc->voices_off = t.voices_off;
                 tc->tile_first_off = t.tile_first_off; tc->n_int = t.n_int;
                 tc->tile_order_off = t.tile_order_off;
+                tc->raw_istart_off = t.raw_istart_off; tc->raw_ivoff_off = t.raw_ivoff_off; tc->raw_voices_off = t.raw_voices_off;
+                tc->raw_tile_first_off = t.raw_tile_first_off; tc->raw_n_int = t.raw_n_int; tc->probe_v_off = t.probe_v_off;
                 tc->end_state.clear();
                 save_state(v, tc->end_state);
                 tc->key = key;
@@ -822,6 +939,8 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
         o.istart_off = tc->istart_off; o.ivoff_off = tc->ivoff_off; o.voices_off = tc->voices_off;
         o.tile_first_off = tc->tile_first_off; o.n_int = tc->n_int;
         o.tile_order_off = tc->tile_order_off;
+        o.raw_istart_off = tc->raw_istart_off; o.raw_ivoff_off = tc->raw_ivoff_off; o.raw_voices_off = tc->raw_voices_off;
+        o.raw_tile_first_off = tc->raw_tile_first_off; o.raw_n_int = tc->raw_n_int; o.probe_v_off = tc->probe_v_off;
     }
 
     // ---- 2. descriptors: walk levels, assign edge buffers
@@ -843,9 +962,6 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     // ... and an Adsr vertex with one materialised input and ONE consumer whose kernel is of the summing family (a Sum, a
     // Normalize, a band-pass -- directly or through one gain / pan stage): that consumer evaluates the envelope itself,
     // as its only term or among others (term kind 5); inlined 3 = such an Adsr vertex, 4 = the stage behind one
-    std::vector<std::vector<size_t>> cons(nv);
-    for (size_t vi : g->order)
-        for (size_t u : g->edges[vi]) cons[u].push_back(vi);
     auto is_stage = [&](size_t vi) {   // a single-input Sum that is not the output
         return g->vertices[vi].kind == K_SUM && (long)vi != g->output_vertex && g->edges[vi].size() == 1;
     };
@@ -915,70 +1031,6 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     std::map<size_t, ScanPlan> scan_plan;                        // band-pass vertices that take k_band_scan
     std::map<size_t, std::vector<size_t>> chain_of;              // last vertex of a launch -> its vertices, first to last
     std::map<size_t, std::vector<ChainLink>> links_before;       // band-pass vertex -> the links between its predecessor and it
-    const bool scan_on = g->band_mode >= 1;
-    // ---- the guard (band_mode 2, engine.h tde::Guard): a band-pass vertex takes the scan only where the launch's own estimate
-    // of its deviation can be carried to the graph's output -- `down[u]`: the static gain from vertex u's output to the
-    // graph's (pan / gain of everything downstream, largest channel; several paths add up; an Adsr vertex on the way at the
-    // largest gain its conf and its events' velocities allow) and the ONE Normalize vertex every path runs through, if any
-    // (its 1 / max is read from its peak table by k_band_audit); anything else -- two Normalize vertices in a row, paths that
-    // differ in it -- keeps the exact kernels.  So does a vertex downstream of a sample loop shorter than 2 048 frames:
-    // a period shorter than the smoother's memory repeats its rounding pattern, the offsets add up coherently and no
-    // level-based estimate bounds them (DESIGN.md 3e "The guard").
-    const bool guard_on = g->band_mode == 2 && !g->guard.in_redo && g->band_chain;
-    struct PathGain { double g; long norm; };   // norm: -1 none, >= 0 that Normalize vertex, -2 not analysable
-    std::vector<PathGain> down;
-    std::vector<char> short_up;
-    auto own_gain = [](const Vertex& v) {
-        const PanGain pg = make_pg(v.gain, v.angle);
-        double a = 1.0;
-        if (pg.flags & 1u) a *= std::max(fabs((double)pg.l_amp), fabs((double)pg.r_amp));
-        if (pg.flags & 2u) a *= fabs((double)pg.gain);
-        return a;
-    };
-    if (guard_on) {
-        down.assign(nv, PathGain{0.0, -1});
-        short_up.assign(nv, 0);
-        for (size_t vi : g->order) {   // inputs first
-            const Vertex& v = g->vertices[vi];
-            char su = (v.kind == K_SAMPLE_LOOP && v.sample_index < sb->samples.size() && sb->samples[v.sample_index].len < 2048) ? 1 : 0;
-            for (size_t u : g->edges[vi]) su = su || short_up[u];
-            short_up[vi] = su;
-        }
-        for (size_t k = g->order.size(); k-- > 0;) {   // consumers first
-            const size_t u = g->order[k];
-            if ((long)u == g->output_vertex) { down[u] = PathGain{1.0, -1}; continue; }
-            double sum = 0.0;
-            long nz = -1;
-            bool first = true;
-            for (size_t w : cons[u]) {   // (a duplicate edge is listed twice: the term is summed twice)
-                const Vertex& wv = g->vertices[w];
-                long through = down[w].norm;
-                if (through == -2) { nz = -2; break; }
-                double L = own_gain(wv);
-                if (wv.kind == K_ADSR && !(wv.wet < 0.0001f)) {   // |lerp(1, level x vel, wet)| <= max(1, |level| |vel|)
-                    const AdsrConfD& c = wv.conf;
-                    double lv = std::max(std::max(fabs((double)c.std_vel), fabs((double)c.attack_vel)),
-                                         std::max(std::max(fabs((double)c.decay_vel), fabs((double)c.sustain_vel)), fabs((double)c.release_vel)));
-                    double mv = 0.0;
-                    for (const td_event& e : floww_of(fb, wv.floww_index)) mv = std::max(mv, fabs((double)e.vel));
-                    L *= std::max(1.0, lv * mv);
-                }
-                if (wv.kind == K_NORMALIZE) {
-                    if (through != -1) { nz = -2; break; }
-                    through = (long)w;
-                }
-                if (first) { nz = through; first = false; }
-                else if (nz != through) { nz = -2; break; }
-                sum += L * down[w].g;
-            }
-            if (!(sum == sum) || std::isinf(sum)) nz = -2;
-            down[u] = PathGain{sum, nz};
-        }
-    }
-    auto guard_ok = [&](size_t vi, const ScanPlan& sp) {   // (`pass` vertices: the chain launch; `cut` vertices: k_band_scan, one vertex per launch)
-        (void)sp;
-        return down[vi].norm != -2 && !short_up[vi];
-    };
     if (scan_on) {
         for (size_t vi : g->order) {
             const Vertex& v = g->vertices[vi];
@@ -1177,9 +1229,41 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     // the guard's bookkeeping (band_mode 2): where every Normalize vertex of the chunk keeps its peak table and carried max,
     // and what every guarded scan launch leaves for k_band_audit
     std::map<size_t, std::pair<size_t, size_t>> audit_norm;   // Normalize vertex -> scratch offsets (peaks, init snapshot)
-    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; size_t desc_off; uint32_t tile_frames; };   // from: the vertex whose output the estimate stands at
+    struct AuditSrc { size_t noise_off; uint32_t n_wt; size_t from; bool fused; size_t desc_off; uint32_t tile_frames; bool sampled = false; };   // from: the vertex whose output the estimate stands at
     std::vector<AuditSrc> audit_src;
 
+    auto synth_desc_of = [&](size_t vi) {   // a Synth vertex' descriptor, tables aside
+        const Vertex& v = g->vertices[vi];
+        SynthDesc x{};
+        x.tab.n_int = vt[vi].n_int;
+        x.out = g->vbuf[vi];
+        x.t0 = t0;
+        x.sr = (uint32_t)sr;
+        x.bl = (uint32_t)bl;
+        x.square = v.square;
+        x.topflat = v.topflat;
+        x.triangle = v.triangle;
+        x.osc_amp_multiplier =   // extensions.rs:465-468
+            1.0f / (v.square.volume * adsr_max_vel(v.square.adsr) +
+                    v.topflat.volume * adsr_max_vel(v.topflat.adsr) +
+                    v.triangle.volume * adsr_max_vel(v.triangle.adsr));
+        x.pg = make_pg(v.gain, v.angle);
+        x.affine = synth_affine_ok(v) ? 1u : 0u;   // (the tables then hold affine records: compile_synth)
+        x.exact_sin = v.exact_sin ? 1u : 0u;
+        {
+            auto same = [](const AdsrConfD& a, const AdsrConfD& b) { return memcmp(&a, &b, sizeof(AdsrConfD)) == 0; };
+            const bool sq = v.square.volume > 0.0f, tf = v.topflat.volume > 0.0f;
+            x.tf_env_src = (sq && same(v.topflat.adsr, v.square.adsr)) ? 1u : 0u;
+            x.tr_env_src = (sq && same(v.triangle.adsr, v.square.adsr)) ? 1u
+                         : (tf && same(v.triangle.adsr, v.topflat.adsr)) ? 2u : 0u;
+        }
+        return x;
+    };
+    // k_sine_probe's sampling of this chunk (kernels.h ProbeDesc): one frame in every `1 << probe_lg` -- every 256th of a long
+    // chunk, every 16th of a single block -- 64 samples per workgroup
+    const uint32_t probe_lg = probe_stride_log2(M);
+    const uint32_t probe_stride = 1u << probe_lg, probe_n = (uint32_t)((M + probe_stride - 1) / probe_stride), probe_groups = (probe_n + 15u) / 16u;
+    std::vector<std::pair<size_t, size_t>> probe_src;   // (vertex, scratch offset of its ProbeDesc::noise)
     for (int lv = 0; lv < g->n_levels; ++lv) {
         std::vector<size_t> fam_v[F_COUNT];
         std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
@@ -1201,8 +1285,8 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                 case K_SAMPLE_LOOP: fam_v[F_LOOP].push_back(vi); break;
                 case K_SAMPLE_MULTI: fam_v[F_MULTI].push_back(vi); break;
                 case K_SAMPLE_LERP: fam_v[F_LERP].push_back(vi); break;
-                case K_DEBUG_SINE: fam_v[F_SINE].push_back(vi); break;
-                case K_SYNTH: fam_v[F_SYNTH].push_back(vi); break;
+                case K_DEBUG_SINE: fam_v[F_SINE].push_back(vi); if (v.probe) fam_v[F_PROBE].push_back(vi); break;
+                case K_SYNTH: fam_v[F_SYNTH].push_back(vi); if (v.probe) fam_v[F_PROBE].push_back(vi); break;
                 case K_SAMPSYN: fam_v[F_SAMPSYN].push_back(vi); break;
                 case K_SUM: fam_v[F_SUM].push_back(vi); break;
                 case K_NORMALIZE:
@@ -1428,33 +1512,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                     std::vector<SynthDesc> d;
                     // (k_synth and k_synth_affine are two kernels: the generic vertices first, the affine ones behind them)
                     std::stable_sort(vs.begin(), vs.end(), [&](size_t a, size_t b) { return synth_affine_ok(g->vertices[a]) < synth_affine_ok(g->vertices[b]); });
-                    for (size_t vi : vs) {
-                        const Vertex& v = g->vertices[vi];
-                        SynthDesc x{};
-                        x.tab.n_int = vt[vi].n_int;
-                        x.out = g->vbuf[vi];
-                        x.t0 = t0;
-                        x.sr = (uint32_t)sr;
-                        x.bl = (uint32_t)bl;
-                        x.square = v.square;
-                        x.topflat = v.topflat;
-                        x.triangle = v.triangle;
-                        x.osc_amp_multiplier =   // extensions.rs:465-468
-                            1.0f / (v.square.volume * adsr_max_vel(v.square.adsr) +
-                                    v.topflat.volume * adsr_max_vel(v.topflat.adsr) +
-                                    v.triangle.volume * adsr_max_vel(v.triangle.adsr));
-                        x.pg = make_pg(v.gain, v.angle);
-                        x.affine = synth_affine_ok(v) ? 1u : 0u;   // (the tables then hold affine records: compile_synth)
-                        x.exact_sin = v.exact_sin ? 1u : 0u;
-                        {
-                            auto same = [](const AdsrConfD& a, const AdsrConfD& b) { return memcmp(&a, &b, sizeof(AdsrConfD)) == 0; };
-                            const bool sq = v.square.volume > 0.0f, tf = v.topflat.volume > 0.0f;
-                            x.tf_env_src = (sq && same(v.topflat.adsr, v.square.adsr)) ? 1u : 0u;
-                            x.tr_env_src = (sq && same(v.triangle.adsr, v.square.adsr)) ? 1u
-                                         : (tf && same(v.triangle.adsr, v.topflat.adsr)) ? 2u : 0u;
-                        }
-                        d.push_back(x);
-                    }
+                    for (size_t vi : vs) d.push_back(synth_desc_of(vi));
                     off = st.put(d);
                     for (size_t i = 0; i < vs.size(); ++i) {
                         const size_t o = off + i * sizeof(SynthDesc) + offsetof(SynthDesc, tab);
@@ -1495,6 +1553,54 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                         tab_field(o, offsetof(IntervalTab, voices), vt[vs[i]], vt[vs[i]].voices_off);
                     }
                 } break;
+                case F_PROBE: {   // (behind F_SINE / F_SYNTH of this level: their buffers are assigned)
+                    std::vector<ProbeDesc> d;
+                    for (size_t vi : vs) {
+                        const Vertex& v = g->vertices[vi];
+                        ProbeDesc x{};
+                        x.kind = v.kind == K_SYNTH ? 1u : 0u;
+                        x.stride_log2 = probe_lg;
+                        x.n_groups = probe_groups;
+                        if (x.kind) {
+                            x.syn = synth_desc_of(vi);
+                            x.syn.affine = 0u;
+                            x.syn.exact_sin = 1u;
+                            x.syn.tab.n_int = vt[vi].raw_n_int;
+                        } else {
+                            x.sine.tab.n_int = vt[vi].n_int;
+                            x.sine.out = g->vbuf[vi];
+                            x.sine.t0 = t0;
+                            x.sine.sr = (uint32_t)sr;
+                            x.sine.exact_sin = 1u;
+                            x.sine.pg = make_pg(v.gain, v.angle);
+                        }
+                        d.push_back(x);
+                    }
+                    off = st.put(d);
+                    for (size_t i = 0; i < vs.size(); ++i) {
+                        const VTables& t = vt[vs[i]];
+                        const size_t po = off + i * sizeof(ProbeDesc);
+                        if (d[i].kind) {
+                            const size_t o = po + offsetof(ProbeDesc, syn) + offsetof(SynthDesc, tab);
+                            tab_field(o, offsetof(IntervalTab, istart), t, t.raw_istart_off);
+                            tab_field(o, offsetof(IntervalTab, tile_first), t, t.raw_tile_first_off);
+                            tab_field(o, offsetof(IntervalTab, ivoff), t, t.raw_ivoff_off);
+                            tab_field(o, offsetof(IntervalTab, voices), t, t.raw_voices_off);
+                        } else {
+                            const size_t o = po + offsetof(ProbeDesc, sine) + offsetof(SineDesc, tab);
+                            tab_field(o, offsetof(IntervalTab, istart), t, t.istart_off);
+                            tab_field(o, offsetof(IntervalTab, tile_first), t, t.tile_first_off);
+                            tab_field(o, offsetof(IntervalTab, ivoff), t, t.ivoff_off);
+                            tab_field(o, offsetof(IntervalTab, voices), t, t.voices_off);
+                        }
+                        tab_field(po, offsetof(ProbeDesc, ranges), t, t.probe_v_off);
+                        const size_t no = scratch((size_t)probe_groups * 16 * sizeof(float));
+                        scratch_field(po, offsetof(ProbeDesc, noise), no);
+                        probe_src.push_back({vs[i], no});
+                    }
+                    add_launch(fam, off, (int)vs.size(), probe_groups, lv);
+                    continue;
+                }
                 case F_SUM: {
                     std::vector<SumDesc> d;
                     // parallel band-pass vertices first get their summed input materialised (no epilogue)
@@ -1991,9 +2097,33 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     }
     // the guard's verdict on this chunk: one workgroup adds up what the guarded scan launches estimated (k_band_audit)
     const double guard_thr = (double)g->band_guard_ppb * 1e-9;
-    if (guard_on && audit_src.size() == 1 && audit_src[0].fused) {
+    // (sine_mode 2) what k_sine_probe measured at the probed sine vertices' outputs joins the verdict: through the one launch that
+    // gives it itself, where every probed vertex reaches the output through that launch's Normalize vertex (BASELINE config 3's
+    // shape: no audit launch) -- else as audit sources of their own
+    bool in_launch = guard_on && audit_src.size() == 1 && audit_src[0].fused && probe_src.size() <= 2;
+    double probe_g2[2] = {0.0, 0.0};
+    if (in_launch && !probe_src.empty()) {
+        const size_t ni = audit_src[0].from;
+        const double to_out = own_gain(g->vertices[ni]) * down[ni].g;   // from the Normalize vertex' raw frames to the graph's output
+        for (size_t q = 0; q < probe_src.size(); ++q) {
+            const size_t u = probe_src[q].first;
+            const double r = down[u].g / to_out;
+            if (down[u].norm != (long)ni || !(to_out > 0.0) || !std::isfinite(r)) in_launch = false;
+            probe_g2[q] = r * r;
+        }
+    }
+    if (!in_launch)
+        for (const auto& ps : probe_src) audit_src.push_back({ps.second, probe_n, ps.first, false, 0, probe_stride, true});
+    if (in_launch) {
         // ONE guarded launch and it ends in the Normalize vertex: the launch gives the verdict itself (BandScanDesc::nz_acc)
         const size_t o = audit_src[0].desc_off;
+        for (size_t q = 0; q < probe_src.size(); ++q) {
+            scratch_field(o, offsetof(BandScanDesc, nz_extra) + q * sizeof(const float*), probe_src[q].second);
+            const float g2 = (float)probe_g2[q];
+            memcpy(&st.b[o + offsetof(BandScanDesc, nz_xg2) + q * sizeof(float)], &g2, 4);
+        }
+        const uint32_t xcnt = (uint32_t)kTileFrames >> probe_lg;   // samples per wave-tile (4 .. 64)
+        memcpy(&st.b[o + offsetof(BandScanDesc, nz_xcnt)], &xcnt, 4);
         const double gout = down[audit_src[0].from].g;
         const float scale = (float)(gout * gout / (double)M), thr2 = (float)(guard_thr * guard_thr);
         const uint64_t hw = (uint64_t)(uintptr_t)g->guard.d_word;
@@ -2004,7 +2134,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
         cb.sync_fix.push_back({o + offsetof(BandScanDesc, nz_sync), cb.sync_bytes});   // one granule per tile, zeroed before the launch
         cb.sync_bytes += ((size_t)n_tiles4 * 8 + 63) & ~(size_t)63;
         g->guard.chunk_audited = true;
-    } else if (guard_on && !audit_src.empty()) {
+    } else if ((guard_on || sguard_on) && !audit_src.empty()) {
         g->guard.chunk_audited = true;
         std::vector<AuditDesc> ad;
         for (const AuditSrc& a : audit_src) {
@@ -2014,6 +2144,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
             x.nb = (uint32_t)nb;
             x.bl = (uint32_t)bl;
             x.gain = (float)down[a.from].g;
+            x.sampled = a.sampled ? 1u : 0u;
             ad.push_back(x);
         }
         const size_t ao = st.put(ad);
@@ -2054,6 +2185,7 @@ size_t desc_size(int fam) {
         case F_SYNTH: return sizeof(SynthDesc);
         case F_SAMPSYN: return sizeof(SampsynDesc);
         case F_ENV: return sizeof(AdsrVDesc);
+        case F_PROBE: return sizeof(ProbeDesc);
         case F_SUM: return sizeof(SumDesc);
         case F_SCALE: return sizeof(ScaleDesc);
         case F_NORMFIX: return sizeof(SumDesc);

@@ -955,6 +955,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_SYNTH: launch_synth((const SynthDesc*)d, L.n, L.M, (L.aux & 1u) != 0u, s); break;
                 case F_SAMPSYN: launch_sampsyn((const SampsynDesc*)d, L.n, L.M, s); break;
                 case F_ENV: launch_adsr_env((const AdsrVDesc*)d, L.n, L.M, s); break;
+                case F_PROBE: launch_sine_probe((const ProbeDesc*)d, L.n, L.M, L.aux, s); break;
                 case F_SUM:
                     if (L.aux >> 12) launch_norm1((const SumDesc*)d, L.n, L.M, L.aux & 0xFFu, (int)(L.aux >> 12), sum_tag, s);   // single-pass Normalize, narrow forms
                     else launch_sum((const SumDesc*)d, L.n, L.M, L.bl, L.aux & 0xFFu, (L.aux & 0x100u) != 0u, (L.aux & 0x200u) != 0u, sum_tag, s);
@@ -1125,6 +1126,16 @@ static bool has_reachable_band(const td_graph* g) {
         if (g->vertices[vi].kind == K_BAND_PASS) return true;
     return false;
 }
+// May the render about to start carry an audit?  band_mode 2 with a band-pass vertex on the way to the output, or sine_mode 2
+// with a debug_sine / synth vertex there (k_sine_probe's measurements: kernels.h ProbeDesc).
+static bool may_be_audited(const td_graph* g) {
+    if (g->guard.in_redo) return false;
+    if (g->band_mode == 2 && has_reachable_band(g)) return true;
+    if (g->sine_mode == 2)
+        for (size_t vi : g->order)
+            if (g->vertices[vi].kind == K_DEBUG_SINE || g->vertices[vi].kind == K_SYNTH) return true;
+    return false;
+}
 // In front of a render that may carry an audit: what it takes to do the render again (called once the plan and the state
 // slots are in place, before the first chunk compiles).
 static int guard_begin(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, size_t n_blocks, bool is_scan, int bits,
@@ -1236,7 +1247,7 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
     if (!settle_before_render(g)) return 0;
     if (!prepare_render(g, n_blocks, bits, want_pcm, &rp)) return 0;
     g->defer_fix = !rp.multi;   // (a later chunk reads the carried max; the f32 copy of a multi-chunk render reads the frames)
-    const bool guarded = g->band_mode == 2 && !g->guard.in_redo && has_reachable_band(g);
+    const bool guarded = may_be_audited(g);
     if (guarded && !guard_begin(g, sb, fb, n_blocks, is_scan, bits, advance_graph_time, scan_t0, want_pcm)) return 0;
     bool audited = false;
     ChunkBuild& cb = g->build;
@@ -1315,7 +1326,7 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
     for (size_t i = 0; i < P; ++i) {
         td_graph* g = b->graphs[lo + i];
         g->defer_fix = allow_defer && !any_multi;
-        if (g->band_mode == 2 && !g->guard.in_redo && has_reachable_band(g) &&
+        if (may_be_audited(g) &&
             !guard_begin(g, b->sbs[lo + i], b->fbs[lo + i], n_blocks, is_scan, bits, advance_graph_time, 0, want_pcm)) return 0;
     }
     ChunkBuild& cb = b->build;
@@ -2076,7 +2087,8 @@ int td_graph_set_option(td_graph* g, const char* key, long value) {
     if (k == "fuse_normalize") { g->fuse_normalize = value != 0; return 1; }
     if (k == "one_grid_sources") { g->one_grid_sources = value != 0; return 1; }
     if (k == "sine_mode") {   // 0: the tolerance-class device sine (default), 1: glibc's sinf operation for operation (kernels.hip sin_glibc)
-        if (value != 0 && value != 1) return fail("td_graph_set_option: sine_mode is 0 or 1");
+        if (value != 0 && value != 1 && value != 2) return fail("td_graph_set_option: sine_mode is 0 (fast), 1 (glibc's sinf) or 2 (fast under the guard)");
+        if (g->guard.armed && !drain(g)) return 0;   // (a verdict still out belongs to the mode it was rendered in)
         g->sine_mode = (int)value;
         for (auto& v : g->vertices)
             if (v.kind == K_DEBUG_SINE || v.kind == K_SYNTH) v.exact_sin = value != 0;

@@ -97,6 +97,11 @@ struct TableCache {
     // table layout: offsets into d
     size_t hits_off = 0, istart_off = 0, ivoff_off = 0, voices_off = 0, tile_first_off = 0, tile_order_off = 0;
     uint32_t n_hits = 0, n_int = 0;
+    // a probed affine Synth vertex (sine_mode 2): the RAW interval table beside the affine one -- k_sine_probe evaluates the
+    // reference's own form, which reads (hz, vel, env_t, rel_t) records
+    size_t raw_istart_off = 0, raw_ivoff_off = 0, raw_voices_off = 0, raw_tile_first_off = 0;
+    uint32_t raw_n_int = 0;
+    size_t probe_v_off = 0;   // ... and k_sine_probe's per-sample voice ranges (ProbeDesc::ranges)
 };
 
 struct Vertex {
@@ -112,6 +117,7 @@ struct Vertex {
     tdk::AdsrConfD conf{};
     bool use_off = false, use_max = false, pass = true;
     bool exact_sin = false;   // (debug_sine, synth) the graph's "sine_mode" option at the last set_option / add: glibc's sinf on the device
+    bool probe = false;       // (debug_sine, synth; set per chunk by compile_chunk) sine_mode 2: the fast form, its deviation measured by k_sine_probe
     float lgamma = 0, hgamma = 0;
     tdk::WaveTableD wavetable{};   // K_SAMPSYN: table in HBM (owned by the graph)
     // carried host state (what the reference keeps inside VertexExt, extensions.rs:15-80)
@@ -398,7 +404,7 @@ struct td_graph {
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
     bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
-    int sine_mode = 1;                         // 1 (a bare td_graph's default, like band_mode 0: the reference's bytes): debug_sine / synth evaluate glibc's sinf operation for operation and adsr.rs's own divisions; 0 (the front-end's default): the device sine of the tolerance class (<= 3.3e-7 from sinf) and the affine / one-grid Synth forms
+    int sine_mode = 1;                         // 1 (a bare td_graph's default, like band_mode 0: the reference's bytes): debug_sine / synth evaluate glibc's sinf operation for operation and adsr.rs's own divisions; 0: the device sine of the tolerance class (<= 3.3e-7 from sinf) and the affine / one-grid Synth forms, unguarded; 2 (the front-end's default): the fast forms under the guard -- k_sine_probe measures their deviation at the vertex, the audit carries it to the output, over the bound the render is done again in mode 1's form
     int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
                                                //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex),
                                                // 2: the scan under the guard (tde::Guard below): every render estimates its own

@@ -440,6 +440,13 @@ struct BandScanDesc {
     unsigned long long* nz_sync;   // [n_tiles] granules, zeroed before the launch; nullptr: leave the wave-tiles' energies in `noise`
     uint32_t* nz_host;          // AuditHead::host_word
     float nz_thr2, pad5;
+    // ... and with it what the graph's probed sine vertices measured (ProbeDesc::noise; engine option "sine_mode" 2), where every
+    // one of them reaches the output through this launch's Normalize vertex: per sample frame the energy of the vertex' deviation
+    // at its own output, nz_xcnt (<= 64) samples per wave-tile; nz_xg2 = (its static gain to the Normalize vertex' INPUT)^2.
+    // The tile adds its own samples through its own 1 / max, like its own estimate.  nullptr: none.
+    const float* nz_extra[2];
+    float nz_xg2[2];
+    uint32_t nz_xcnt, pad6;
 };
 // The guard's verdict (engine option "band_mode" 2): one workgroup per graph adds up what its scan launches estimated, carried to
 // the graph's output -- a static gain per launch (the host walks the graph: pan / gain of everything downstream) and, where the
@@ -453,7 +460,8 @@ struct AuditDesc {
     uint32_t n_wt, nb, bl;      // entries of `noise`; the Normalize vertex' blocks and block length
     uint32_t tile_frames;       // frames per entry of `noise`: 1 024 (k_band_chain: a wave-tile) or NF x 256 (k_band_scan: a workgroup tile)
     float gain;                 // static gain from the launch's output to the graph's
-    uint32_t pad2[3];
+    uint32_t sampled;           // 1: the entries are k_sine_probe's samples (ProbeDesc::noise) -- entry w was measured AT frame probe_frame(w, log2 tile_frames), whose block's running max it goes through
+    uint32_t pad2[2];
 };
 struct AuditHead {              // one graph of the submission
     const AuditDesc* descs;
@@ -463,6 +471,34 @@ struct AuditHead {              // one graph of the submission
     uint32_t* host_word;        // page-locked host memory (device address): [0] raised when over the bound, [1] the estimate (f32 bits)
 };
 void launch_band_audit(const AuditHead* heads, int n_heads, hipStream_t s);
+
+// The sine kinds' guard (engine option "sine_mode" 2 -- the front-end's default).  The fast forms of debug_sine /
+// synth (sin_any, affine envelopes, folded products) differ from the reference's own arithmetic by a white, signal-sized
+// rounding noise that a graph can amplify without bound (43 dB of cancellation in a `cut` band-pass, then a Normalize vertex).
+// Nothing models that noise: k_sine_probe MEASURES it.  Behind the vertex' launch, on a sample of the chunk's frames -- one in
+// every 1 << stride_log2, at an offset that walks all residues -- it evaluates the frame the reference's way (synth_frame /
+// sine_frame with exact_sin: glibc's sinf, adsr.rs's divisions, the reference's order of products -- what "sine_mode" 1 renders)
+// and takes the squared distance to what the fast launch left in the vertex' buffer (pan / gain applied on both sides; the
+// larger channel).  noise[i] = that x the frames the sample stands for: an energy in the audit's own units (AuditDesc::noise
+// with tile_frames = the stride), carried to the output by k_band_audit -- or by the chain launch's own verdict -- like a scan
+// launch's estimate: static gain, the Normalize vertex' running 1 / max AT THE SAMPLE'S OWN BLOCK.  A NaN on one side only
+// counts as an infinite energy.
+// sample i of a chunk probed with stride 1 << lg: one frame inside [i << lg, (i + 1) << lg), at an offset that walks all residues
+// (block starts, in-block envelope clocks and event frames are not favoured)
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline uint32_t probe_frame(uint32_t i, uint32_t lg) { return (i << lg) + (((i & 63u) * 37u + (i >> 6) * 11u) & ((1u << lg) - 1u)); }
+struct ProbeDesc {
+    SynthDesc syn;              // kind 1: the vertex' descriptor with exact_sin = 1, affine = 0 and the RAW interval tables
+    SineDesc sine;              // kind 0: ... with exact_sin = 1
+    uint32_t kind;
+    uint32_t stride_log2;       // one sample per 1 << stride_log2 frames (4 .. 8: short chunks are sampled densely)
+    uint32_t n_groups, pad;     // workgroups: 16 samples each
+    float* noise;               // [ceil(frames >> stride_log2)], one entry per sample
+    const uint32_t* ranges;     // [2 x samples] host-made: the voice records {first, one past the last} of the sample frame's interval
+};
+void launch_sine_probe(const ProbeDesc* d, int n_desc, uint32_t frames, uint32_t n_groups, hipStream_t s);
 void launch_band_scan(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, int nf, hipStream_t s);
 int band_scan_resident_capacity(int nf);   // workgroups of k_band_scan resident at once (0: unknown)
 void launch_band_chain(const BandScanDesc* d, int n_desc, uint32_t frames, uint32_t term_mode, bool guarded, hipStream_t s);   // NF 16; guarded: every descriptor has `noise`

@@ -1713,6 +1713,71 @@ __global__ __launch_bounds__(kThreads, 6) void k_synth_affine(const SynthDesc* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_sine_probe: what the fast sine kinds' output differs by from the reference's own arithmetic, MEASURED on a sample of the
+// chunk's frames (kernels.h ProbeDesc; engine option "sine_mode" 2)
+// ------------------------------------------------------------------------------------------------
+// A workgroup owns 16 sample frames, a row of 16 lanes each: lane `sub` evaluates voices sub, sub + 16, ... of the frame's
+// interval the reference's way (synth_voice with exact_sin / sin_glibc) and the row adds them up in the voice order of the
+// reference's loop (`acc += voice`: the additions are what is serial, the voices are not) -- lane 0 takes lane k's value as the
+// DPP operand of a move (row_shl:k), no trip through LDS.  The kernel is latency: ~700 workgroups for 60 s, one pass.
+TD_DEV float probe_dev2(float got, float want) {
+    if (got == want || (got != got && want != want)) return 0.0f;   // (NaN where the reference is NaN: nothing to answer for)
+    const float d = got - want, e = d * d;
+    return e == e ? e : __builtin_inff();                          // a NaN / infinity on one side only: over any bound
+}
+template <int K>
+TD_DEV float row_shl(float v) {   // lane i of a row of 16 receives lane i + K's value (lanes past the row's end: 0)
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + K, 0xF, 0xF, true));
+}
+__global__ __launch_bounds__(kThreads) void k_sine_probe(const ProbeDesc* __restrict__ descs, uint32_t M) {
+    const ProbeDesc& p = descs[blockIdx.y];
+    const uint32_t lg = p.stride_log2, stride = 1u << lg;
+    const uint32_t idx = blockIdx.x * 16u + (threadIdx.x >> 4), sub = threadIdx.x & 15u;   // the sample stands for frames [idx << lg, (idx + 1) << lg)
+    const uint32_t m = probe_frame(idx, lg);
+    const bool valid = m < M;                                    // (the last sample's frame may lie beyond the chunk: nothing measured)
+    const uint32_t mc = valid ? m : 0u;
+    const bool synth = p.kind == 1u;
+    const IntervalTab& tab = synth ? p.syn.tab : p.sine.tab;
+    const uint64_t t0 = synth ? p.syn.t0 : p.sine.t0;
+    const uint32_t sr = synth ? p.syn.sr : p.sine.sr;
+    // (the frame's interval is the host's look-up: one load instead of find_interval's walk; what the fast launch left, early)
+    u2v vr; vr.x = 0u; vr.y = 0u;
+    if (valid) vr = *reinterpret_cast<const u2v TD_GLOBAL*>((const TD_GLOBAL char*)(p.ranges + 2u * idx));
+    const uint32_t v0 = vr.x, v1 = vr.y;
+    const float2 got = (valid && sub == 0u) ? gload2((synth ? p.syn.out : p.sine.out) + m) : make_float2(0.0f, 0.0f);
+    const float time = (float)(t0 + mc) / (float)sr;
+    const float off = synth ? (float)(mc % p.syn.bl) / (float)sr : 0.0f;
+    float acc = 0.0f;
+    for (uint32_t r = v0;; r += 16u) {
+        if (!__any((r < v1) ? 1 : 0)) break;
+        const uint32_t v = r + sub;
+        float val = 0.0f;
+        if (v < v1) {
+            const float4 nv = tab.voices[v];
+            if (synth) val = synth_voice(p.syn, nv, time, off);
+            else val = sin_glibc(time * nv.x * 2.0f * kPi) * nv.y;   // sine_frame's term, exact_sin
+        }
+        const uint32_t left = r < v1 ? v1 - r : 0u;               // voices of this round (lane 0 of the row adds them in order)
+#define TD_PROBE_ADD(K) { const float vk = (K) ? row_shl<(K) ? (K) : 1>(val) : val; if ((uint32_t)(K) < left) acc += vk; }
+        TD_PROBE_ADD(0) TD_PROBE_ADD(1) TD_PROBE_ADD(2) TD_PROBE_ADD(3) TD_PROBE_ADD(4) TD_PROBE_ADD(5) TD_PROBE_ADD(6) TD_PROBE_ADD(7)
+        TD_PROBE_ADD(8) TD_PROBE_ADD(9) TD_PROBE_ADD(10) TD_PROBE_ADD(11) TD_PROBE_ADD(12) TD_PROBE_ADD(13) TD_PROBE_ADD(14) TD_PROBE_ADD(15)
+#undef TD_PROBE_ADD
+    }
+    if (sub == 0u && (idx << lg) < M) {
+        float e = 0.0f;
+        if (valid) {
+            const PanGain& pg = synth ? p.syn.pg : p.sine.pg;
+            const float2 want = epilogue(make_float2(acc, acc), pg);
+            e = fmaxf(probe_dev2(got.x, want.x), probe_dev2(got.y, want.y));
+        }
+        p.noise[idx] = e * (float)min(stride, M - (idx << lg));
+    }
+}
+void launch_sine_probe(const ProbeDesc* d, int n_desc, uint32_t frames, uint32_t n_groups, hipStream_t s) {   // n_groups: workgroups, 16 samples each
+    if (n_desc > 0 && n_groups > 0) hipLaunchKernelGGL(k_sine_probe, dim3(n_groups, (uint32_t)n_desc), dim3(kThreads), 0, s, d, frames);
+}
+
+// ------------------------------------------------------------------------------------------------
 // k_sampsyn (extensions.rs:532-578; oscillator and table format are this engine's own, see kernels.h)
 // ------------------------------------------------------------------------------------------------
 TD_DEV float wavetable_act(const WaveTableD& w, float hz, float t) {
@@ -3918,6 +3983,20 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off, 64);
             unsigned long long* const nzs = dl->nz_sync;
             if (nzs) {
+                // ... and what the graph's probed sine vertices measured at their own outputs (k_sine_probe, earlier on the stream;
+                // BandScanDesc::nz_extra), through the same 1 / max: this wave-tile's share of its probe group's energy
+                if (dl->nz_extra[0] && wt0 < M) {   // (uniform)
+                    const uint32_t cnt = dl->nz_xcnt, i0 = wt * cnt + lane_e;   // this wave-tile's samples: cnt <= 64, one a lane
+                    const uint32_t ns = (M + (uint32_t)kTileFrames / cnt - 1u) / ((uint32_t)kTileFrames / cnt);
+                    float xe = 0.0f;
+                    if (lane_e < cnt && i0 < ns) {
+                        xe = gload1(dl->nz_extra[0] + i0) * dl->nz_xg2[0];
+                        if (dl->nz_extra[1]) xe += gload1(dl->nz_extra[1] + i0) * dl->nz_xg2[1];
+                    }
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) xe += __shfl_xor(xe, off, 64);
+                    e += xe * gq * gq;
+                }
                 // The graph's only guarded launch: the verdict right here (kernels.h BandScanDesc::nz_sync).  Every tile leaves its
                 // energy as ONE granule -- a plain tagged store: 2 813 atomic adds to one word took 60 us of the launch -- and the
                 // tile with the last ticket, which every other ticket holder is running ahead of or beside, gathers them.
@@ -3985,36 +4064,80 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
 // (extensions.rs:321-329): segment maxima of the peak table, their prefix, then a short walk inside the tile's segment.
 // Launches add up as amplitudes (the same rounding pattern may reach the output twice).  NaN energies (tiles the
 // reference turns NaN as well) count as 0, infinite ones trip the guard.
+constexpr uint32_t kAuditBlocks = 8192;   // running maxima held in LDS (a longer chunk of shorter blocks walks the peak table per entry)
 __global__ __launch_bounds__(kThreads) void k_band_audit(const AuditHead* __restrict__ heads) {
     const AuditHead h = heads[blockIdx.x];
     __shared__ float seg_max[kThreads], seg_pre[kThreads + 1], part[kThreads];
+    __shared__ float runmax[kAuditBlocks];   // max(carried max, peaks[0 .. b]) of the Normalize vertex whose table was read last
     const uint32_t tid = threadIdx.x;
     float amp = 0.0f;   // (thread 0) sum over the launches of sqrt(energy at the output)
+    const float* have = nullptr;   // the peak table `runmax` / `seg_pre` stand for (k_sine_probe's sources of one graph share one)
+    const float* have_init = nullptr;
     for (uint32_t i = 0; i < h.n; ++i) {
         const AuditDesc d = h.descs[i];
         const uint32_t seg = d.peaks ? (d.nb + (uint32_t)kThreads - 1u) / (uint32_t)kThreads : 0u;
-        if (d.peaks) {
+        const bool in_lds = d.nb <= kAuditBlocks;
+        if (d.peaks && !(d.peaks == have && d.init_copy == have_init)) {
+            __syncthreads();
             float m = 0.0f;
-            for (uint32_t b = tid * seg; b < min(d.nb, (tid + 1u) * seg); ++b) m = fmaxf(m, gload1(d.peaks + b));
+            if (in_lds) {   // the table through LDS: coalesced loads, every thread then walks its own segment there
+                for (uint32_t b = tid; b < d.nb; b += (uint32_t)kThreads) runmax[b] = gload1(d.peaks + b);
+                __syncthreads();
+                for (uint32_t b = tid * seg; b < min(d.nb, (tid + 1u) * seg); ++b) m = fmaxf(m, runmax[b]);
+            } else {
+                for (uint32_t b = tid * seg; b < min(d.nb, (tid + 1u) * seg); ++b) m = fmaxf(m, gload1(d.peaks + b));
+            }
+            // seg_pre[q] = max(carried max, peaks of the segments before q): an inclusive scan of the segment maxima, shifted by one
+            for (uint32_t off = 1u; off < (uint32_t)kThreads; off <<= 1) {
+                seg_max[tid] = m;
+                __syncthreads();
+                if (tid >= off) m = fmaxf(m, seg_max[tid - off]);
+                __syncthreads();
+            }
             seg_max[tid] = m;
             __syncthreads();
-            if (tid == 0u) {
-                float run = gload1(d.init_copy);
-                for (uint32_t q = 0; q < (uint32_t)kThreads; ++q) { seg_pre[q] = run; run = fmaxf(run, seg_max[q]); }
+            const float init = gload1(d.init_copy);
+            seg_pre[tid] = tid ? fmaxf(init, seg_max[tid - 1u]) : init;
+            if (in_lds) {
+                float run = seg_pre[tid];
+                for (uint32_t b = tid * seg; b < min(d.nb, (tid + 1u) * seg); ++b) { run = fmaxf(run, runmax[b]); runmax[b] = run; }
             }
             __syncthreads();
+            have = d.peaks;
+            have_init = d.init_copy;
         }
         float e = 0.0f;
-        for (uint32_t w = tid; w < d.n_wt; w += (uint32_t)kThreads) {
-            float v = fmaxf(gload1(d.noise + w), 0.0f);   // (NaN -> 0)
-            if (d.peaks) {
-                const uint32_t b0 = min(d.nb - 1u, (uint32_t)(((uint64_t)w * (uint64_t)d.tile_frames) / d.bl));
+        const uint32_t lg_tf = 31u - (uint32_t)__clz((int)max(d.tile_frames, 1u));
+        const uint32_t bl_sh = (d.bl & (d.bl - 1u)) == 0u ? 31u - (uint32_t)__clz((int)max(d.bl, 1u)) : 0xFFFFFFFFu;   // (block length a power of two: a shift)
+        auto inv_max2 = [&](uint32_t frame) {   // (1 / the Normalize vertex' running max at `frame`)^2
+            const uint32_t b0 = min(d.nb - 1u, bl_sh != 0xFFFFFFFFu ? frame >> bl_sh : frame / d.bl);
+            float run;
+            if (in_lds) {
+                run = runmax[b0];
+            } else {
                 const uint32_t sg = b0 / seg;
-                float run = seg_pre[sg];
+                run = seg_pre[sg];
                 for (uint32_t b = sg * seg; b <= b0; ++b) run = fmaxf(run, gload1(d.peaks + b));
-                const float r = 1.0f / run;
-                v *= r * r;
             }
+            const float r = 1.0f / run;
+            return r * r;
+        };
+        // k_sine_probe's samples four at a time where four consecutive ones lie in one block (60 s at 1 024-frame blocks: 11 000
+        // samples, one 16-byte load and one look-up per four); everything else entry by entry
+        uint32_t w_done = 0u;
+        if (d.sampled && d.peaks && d.bl % (4u * d.tile_frames) == 0u && (reinterpret_cast<uintptr_t>(d.noise) & 15u) == 0u) {
+            const uint32_t nq = d.n_wt / 4u;
+            for (uint32_t q = tid; q < nq; q += (uint32_t)kThreads) {
+                const float4 v = gload4(d.noise + 4u * q);
+                const float sum = (fmaxf(v.x, 0.0f) + fmaxf(v.y, 0.0f)) + (fmaxf(v.z, 0.0f) + fmaxf(v.w, 0.0f));   // (NaN -> 0)
+                e += sum * inv_max2((4u * q) << lg_tf);
+            }
+            w_done = nq * 4u;
+        }
+        for (uint32_t w = w_done + tid; w < d.n_wt; w += (uint32_t)kThreads) {
+            float v = fmaxf(gload1(d.noise + w), 0.0f);   // (NaN -> 0)
+            // (a scan launch's tile goes through the running max at its first frame; a probe's sample through that at its own frame)
+            if (d.peaks) v *= inv_max2(d.sampled ? probe_frame(w, lg_tf) : w * d.tile_frames);
             e += v;
         }
         part[tid] = e;

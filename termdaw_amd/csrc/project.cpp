@@ -492,9 +492,13 @@ td_state* td_state_new(const char* wdir, size_t project_samplerate, size_t buffe
     // with the exact kernels (engine.h tde::Guard; BASELINE config 4 renders in 0.4 ms instead of 12 ms and is never
     // redone).  td_state_set_option(s, "band_mode", 0) selects the exact kernels outright, 1 the scan without the guard.
     s->g->band_mode = 2;
-    // ... and its debug_sine / synth vertices the tolerance-class sine ("sine_mode" 0: <= 1e-6 RMS on the vertex' output; config 3's
-    // oscillators in 0.09 instead of 0.32 ms).  td_state_set_option(s, "sine_mode", 1): glibc's sinf bit for bit (kernels.hip sin_glibc).
-    s->g->sine_mode = 0;
+    // ... and its debug_sine / synth vertices their fast forms UNDER THE SAME GUARD ("sine_mode" 2; config 3's oscillators in 0.09
+    // instead of 0.32 ms): k_sine_probe measures, on a sample of every chunk's frames, how far the fast launch's output is from the
+    // reference's own arithmetic (glibc's sinf, adsr.rs's divisions: what "sine_mode" 1 renders), the audit carries that to the
+    // graph's output beside the band-pass estimate -- a graph can amplify the white part of a 3e-8 difference without bound (a
+    // `cut` band-pass that cancels 43 dB, then a Normalize vertex) -- and over 2e-7 the render is done again in mode 1's form.
+    // td_state_set_option(s, "sine_mode", 1): glibc's sinf bit for bit outright; 0: the fast forms without the guard.
+    s->g->sine_mode = 2;
     return s;
 }
 

@@ -114,6 +114,24 @@ void launch_adsr_env(const AdsrVDesc* d, int n, uint32_t frames, hipStream_t) {
         if (d[i].env_tile) touch_w(d[i].env_tile, (size_t)((frames + 511) / 512) * 4);
     }
 }
+void launch_sine_probe(const ProbeDesc* d, int n, uint32_t frames, uint32_t n_groups, hipStream_t) {
+    touch_descs(d, n);
+    for (int i = 0; i < n; ++i) {
+        const ProbeDesc& p = d[i];
+        const IntervalTab& t = p.kind ? p.syn.tab : p.sine.tab;
+        touch_interval_tab(t, frames);
+        touch(t.voices, (size_t)t.ivoff[t.n_int] * sizeof(float4));   // (the RAW table of a Synth vertex: one float4 per voice)
+        touch(p.kind ? p.syn.out : p.sine.out, (size_t)frames * sizeof(float2));
+        if (p.n_groups != n_groups || ((size_t)p.n_groups << (4 + p.stride_log2)) < frames) abort();
+        touch_w(p.noise, (size_t)((frames + (1u << p.stride_log2) - 1) >> p.stride_log2) * 4);
+        {   // the host-made voice ranges: every sample's inside the raw table
+            const uint32_t ns = (frames + (1u << p.stride_log2) - 1) >> p.stride_log2;
+            touch(p.ranges, (size_t)ns * 8);
+            for (uint32_t q = 0; q < ns; ++q)
+                if (p.ranges[2 * q] > p.ranges[2 * q + 1] || p.ranges[2 * q + 1] > t.ivoff[t.n_int]) abort();
+        }
+    }
+}
 void launch_sinf(const float* in, float* out, uint32_t n, int, hipStream_t) { touch(in, (size_t)n * 4); touch_w(out, (size_t)n * 4); }
 void launch_debug_verify(const uint32_t* p, uint32_t n_words, const uint32_t* seg, uint32_t* report, hipStream_t) { touch(p, (size_t)n_words * 4); touch(seg, (size_t)((n_words + 63) / 64) * 4); touch_w(report, 256); }
 void launch_band_audit(const AuditHead* h, int n, hipStream_t) {
@@ -160,6 +178,11 @@ static void touch_scan(const BandScanDesc* d, int n, uint32_t frames, bool chain
         if (x.noise) {   // (per wave-tile in the chain launch, per workgroup tile in k_band_scan)
             touch_w(x.noise, (size_t)(chain ? (frames + kTileFrames - 1) / kTileFrames : x.n_tiles) * 4);
             if (x.nz_sync) { touch_w(x.nz_sync, (size_t)x.n_tiles * 8); touch_w(x.nz_host, 8); }
+            for (int q = 0; q < 2; ++q)   // (sine_mode 2: the probed sine vertices' energies, nz_xcnt samples per wave-tile)
+                if (x.nz_extra[q]) {
+                    if (!x.nz_xcnt || x.nz_xcnt > 64u || (kTileFrames % x.nz_xcnt)) abort();
+                    touch(x.nz_extra[q], (size_t)((frames + kTileFrames / x.nz_xcnt - 1) / (kTileFrames / x.nz_xcnt)) * 4);
+                }
         }
     }
 }

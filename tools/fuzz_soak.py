@@ -2,8 +2,9 @@
 (bit-exact kinds), python tools/fuzz_soak.py 1000 3000 sinf (projects with debug_sine / synth: <= 1e-6 RMS),
 python tools/fuzz_soak.py 1000 3000 scan (the same random graphs with the tolerance-class band-pass, engine option band_mode 1:
 chains, the Sum vertex in front and the Normalize vertex behind a scan launch -- <= 1e-6 RMS of the output's scale),
-python tools/fuzz_soak.py 1000 3000 guard (the same in band_mode 2, the front-end's default: the scan under the guard -- renders
-whose own estimate is over the bound are done again with the exact kernels; the summary counts them),
+python tools/fuzz_soak.py 1000 3000 guard (the same in band_mode 2 + sine_mode 2, the front-end's defaults: the scan and the fast
+sine kinds under the guard -- renders whose own estimate is over the bound are done again with the exact kernels and glibc's sinf;
+the summary counts them),
 python tools/fuzz_soak.py 1000 3000 exactsin (the graphs with debug_sine / synth again, engine option sine_mode 1: glibc's sinf on
 the device -- every render bit for bit, like the first form).  `--jobs N` as a last
 argument pair splits the seed range over N processes (the CPU oracle is the slow side)."""
@@ -59,6 +60,8 @@ for seed in range(lo_seed, hi_seed):
     gb = p.build(api)
     if scan_mode:
         gb[2].set_option("band_mode", 2 if guard_mode else 1)
+    if guard_mode:
+        gb[2].set_option("sine_mode", 2)   # (the front-end's default since round 6: the fast sine kinds under the guard too)
     if exact_sine:
         gb[2].set_option("sine_mode", 1)
     for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=norm_debug=1
