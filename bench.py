@@ -302,10 +302,12 @@ def time_batch(batch, cs, steps, warmup, barrier, exchange):
     for _ in range(steps):
         step()
     batch.mark(1)
-    # The closing barrier.  With more than one rank it IS the path's only exchange -- one all-reduce(max) of the peak table on
-    # device memory, which no rank leaves before every rank has contributed, i.e. has finished its K steps (each contributes
-    # only after synchronising its engine stream) -- followed by torch.cuda.synchronize(): a second collective (dist.barrier)
-    # behind it would time the same rendezvous twice.  A single rank has no collective and takes the plain barrier.
+    # The closing barrier.  With more than one rank it IS the path's only exchange -- td_batch_exchange_peaks: one
+    # ncclAllReduce(max) of the peak table on device memory, queued by the library on the engine's own stream right behind the K
+    # steps (no host synchronisation in between); no rank's stream gets past it before every rank has contributed, i.e. has
+    # finished its K steps; exchange() returns when the stream has drained -- followed by torch.cuda.synchronize(): a second
+    # collective (dist.barrier) behind it would time the same rendezvous twice.  A single rank without a process group has no
+    # collective and takes the plain barrier.
     exchange.exchange()
     if exchange.is_collective():
         import torch
@@ -781,7 +783,10 @@ def main():
     def make_exchange(batch, n_per_gpu):
         """Per-project peak table of the whole job (n_per_gpu x world floats), see termdaw_amd.batch.PeakExchange."""
         from termdaw_amd import batch as tb
-        return tb.PeakExchange(batch, n_per_gpu, rank, world, dist if use_dist else None, on_device=(backend == "nccl"))
+        ex = tb.PeakExchange(batch, n_per_gpu, rank, world, dist if use_dist else None, on_device=(backend == "nccl"), comm=make_exchange.comm)
+        make_exchange.comm = ex.comm          # (one communicator for every batch of this process)
+        return ex
+    make_exchange.comm = None
 
     def gather_ranks(mine):
         """Every rank's own view of the timed region (outside it): what explains a scaling curve -- per-rank region and
@@ -811,7 +816,9 @@ def main():
     batch, project = build_batch(api, workloads, rank, world, P, args.seconds, args.no_fuse, args.no_pack)
     cs, bl = project.cs, project.bl
     frames = cs * bl
-    dt, ktimes, peaks, prof_every, marked_ms = time_batch(batch, cs, args.steps, args.warmup, barrier, make_exchange(batch, P))
+    main_exchange = make_exchange(batch, P)
+    exchange_backend = main_exchange.backend()
+    dt, ktimes, peaks, prof_every, marked_ms = time_batch(batch, cs, args.steps, args.warmup, barrier, main_exchange)
     ranks = gather_ranks(time_batch.last_ranks)
     dt = reduce_max(dt)
     device_bytes = sum(g.device_bytes() for _, _, g in batch.projects)
@@ -1020,7 +1027,7 @@ def main():
             "n_gpus": world,
             "n_ranks_seen": dist.get_world_size() if use_dist else 1,   # what the process group itself reports
             "ranks": ranks,   # per-rank view of the timed region: dt / render min-max, exchange_ms (rank 0), start skew (profiles/NOTES.md#ranks)
-            "exchange_backend": (backend if use_dist else "none"),      # "nccl" = RCCL: the peak table is all-reduced on device memory
+            "exchange_backend": exchange_backend,      # "rccl-native": td_batch_exchange_peaks -- ncclAllReduce(max) on the engine's own stream, device memory; "host-callback": the gloo self-test; "none": one rank without a process group
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),

@@ -33,6 +33,7 @@ typedef struct td_flowwbank td_flowwbank;
 typedef struct td_graph td_graph;
 typedef struct td_state td_state;
 typedef struct td_batch td_batch;
+typedef struct td_comm td_comm;       /* the ranks of a multi-GPU job, for the one collective of the path (td_batch_exchange_peaks) */
 
 /* One event of a floww: the (_, t, note, vel) tuple of the floww crate as used at floww.rs:74-75,
  * 105-116, 131-135 (field 0 is never read on the render path). vel <= 0.001 means note-off. */
@@ -316,6 +317,32 @@ const void* td_batch_host_pcm(const td_batch* b, size_t i, size_t* bytes);
  * goes to entry first + i * stride, all other entries are zeroed. */
 int td_batch_peaks(td_batch* b, float* out);
 int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size_t first, size_t stride);
+/* ---- the job's one collective, behind the C ABI (round 6).  BASELINE config 5: 512 independent projects over the 8 GPUs of a
+ * node, one process per GPU, "RCCL over xGMI only for the final peak all-reduce".  The reference renders one project per process
+ * (State::render's loop, state.rs:563-575); a batch driver running that loop on every GPU ends with this exchange.
+ * td_comm_unique_id: rank 0 makes the 128-byte id (ncclGetUniqueId) and hands it to the other ranks by whatever the host has
+ *   (a file, a socket, MPI); td_comm_init: every rank, on its own device (td_set_device first), joins (ncclCommInitRank -- it
+ *   returns when all `world` ranks have called it).  RCCL is dlopen'ed (librccl.so.1 as the process already holds it, else from the
+ *   ROCm install, else $TD_RCCL_LIB): without it only td_comm_init fails.  td_comm_init_host: the same job over the HOST's own
+ *   all-reduce -- `allreduce_max(ctx, table, n)` replaces table[0 .. n) (host memory) by its element-wise maximum over the ranks and
+ *   returns 1 -- for hosts that bring MPI, and for tests that put two ranks on one GPU (RCCL refuses that).
+ * td_batch_exchange_peaks: the table of per_rank * world floats -- this rank's project i (td_batch_add order) at entry
+ *   rank + i * world, zeros elsewhere (td_batch_peak_table_device) -- then ONE ncclAllReduce(ncclMax, ncclFloat32), in place, on
+ *   the batch's own stream right behind the renders: no host synchronisation between the last render and the collective.  Returns
+ *   when it is enqueued (RCCL kind); td_batch_sync waits for it.  c NULL = a job of one rank (no collective).  Every rank passes
+ *   the same per_rank (>= its own project count).  td_batch_peak_table: the table in device memory (valid after td_batch_sync,
+ *   until the next exchange); td_batch_read_peak_table: synchronises and copies n entries out.
+ * td_comm_backend: "rccl-native" | "host-callback"; td_comm_library: the RCCL library dlopen resolved ("" if none yet). */
+int td_comm_unique_id(void* out, size_t bytes);
+td_comm* td_comm_init(const void* unique_id, size_t bytes, int rank, int world);
+typedef int (*td_allreduce_max_fn)(void* ctx, float* table, size_t n);
+td_comm* td_comm_init_host(td_allreduce_max_fn allreduce_max, void* ctx, int rank, int world);
+void td_comm_free(td_comm* c);
+const char* td_comm_backend(const td_comm* c);
+const char* td_comm_library(void);
+int td_batch_exchange_peaks(td_batch* b, td_comm* c, size_t per_rank);
+const float* td_batch_peak_table(const td_batch* b, size_t* n);
+int td_batch_read_peak_table(td_batch* b, float* out, size_t n);
 /* bench hooks, as for a graph */
 void td_batch_set_profiling(td_batch* b, int on);
 size_t td_batch_last_kernel_times(td_batch* b, const char** names, float* ms, size_t* launches, size_t cap);

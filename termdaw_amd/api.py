@@ -109,6 +109,15 @@ SIGNATURES = {
     "td_batch_host_pcm": (_vp, [_vp, _sz, C.POINTER(_sz)]),
     "td_batch_peaks": (_i32, [_vp, _fp]),
     "td_batch_peak_table_device": (_i32, [_vp, _vp, _sz, _sz, _sz]),
+    "td_comm_unique_id": (_i32, [_vp, _sz]),
+    "td_comm_init": (_vp, [_vp, _sz, _i32, _i32]),
+    "td_comm_init_host": (_vp, [_vp, _vp, _i32, _i32]),
+    "td_comm_free": (None, [_vp]),
+    "td_comm_backend": (_cp, [_vp]),
+    "td_comm_library": (_cp, []),
+    "td_batch_exchange_peaks": (_i32, [_vp, _vp, _sz]),
+    "td_batch_peak_table": (_vp, [_vp, C.POINTER(_sz)]),
+    "td_batch_read_peak_table": (_i32, [_vp, _fp, _sz]),
     "td_batch_set_profiling": (None, [_vp, _i32]),
     "td_batch_last_kernel_times": (_sz, [_vp, C.POINTER(_cp), _fp, C.POINTER(_sz), _sz]),
     "td_batch_host_times": (_sz, [_vp, C.POINTER(C.c_double), _i32]),
@@ -460,6 +469,59 @@ class Graph:
         _check(lib().td_graph_set_option(self.h, key.encode(), int(value)))
 
 
+COMM_ID_BYTES = 128
+_HOST_ALLREDUCE = C.CFUNCTYPE(_i32, _vp, _fp, _sz)
+
+
+def comm_unique_id():
+    """rank 0: the 128-byte id every rank hands to Comm (ncclGetUniqueId behind td_comm_unique_id)."""
+    buf = (C.c_char * COMM_ID_BYTES)()
+    _check(lib().td_comm_unique_id(buf, COMM_ID_BYTES))
+    return bytes(buf)
+
+
+class Comm:
+    """The ranks of a multi-GPU job (td_comm): `Comm(unique_id, rank, world)` joins over RCCL on the current device;
+    `Comm.over_host(fn, rank, world)` runs the same exchange over the host's own all-reduce -- fn(table: np.float32[n]) replaces
+    the table in place by its element-wise maximum over the ranks (MPI hosts; two ranks on one GPU in tests)."""
+
+    def __init__(self, unique_id=None, rank=0, world=1, _h=None, _keep=None):
+        self._keep = _keep
+        if _h is not None:
+            self.h = _h
+        else:
+            if unique_id is None or len(unique_id) < COMM_ID_BYTES:
+                raise ValueError("Comm needs the 128-byte id of comm_unique_id()")
+            self.h = lib().td_comm_init(bytes(unique_id), len(unique_id), rank, world)
+        if not self.h:
+            raise TermdawError(last_error())
+        self.rank, self.world = rank, world
+
+    @classmethod
+    def over_host(cls, fn, rank, world):
+        def tramp(_ctx, table, n):
+            try:
+                fn(np.ctypeslib.as_array(table, shape=(n,)))
+                return 1
+            except Exception:   # (an exception must not cross the C ABI: the entry reports a failed exchange)
+                return 0
+        cb = _HOST_ALLREDUCE(tramp)
+        h = lib().td_comm_init_host(C.cast(cb, _vp), None, rank, world)
+        return cls(rank=rank, world=world, _h=h, _keep=cb)
+
+    def backend(self):
+        return lib().td_comm_backend(self.h).decode()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().td_comm_free(self.h)
+            self.h = None
+
+
+def comm_library():
+    return lib().td_comm_library().decode()
+
+
 class Batch:
     """Many independent projects rendered together on one GPU (BASELINE config 5): State::render's loop
     (state.rs:563-575) for every project, same-kind launches of different projects merged into one grid."""
@@ -529,6 +591,20 @@ class Batch:
         out = np.zeros(max(len(self), 1), np.float32)
         _check(lib().td_batch_peaks(self.h, out.ctypes.data_as(_fp)))
         return out[:len(self)]
+
+    def exchange_peaks(self, comm, per_rank):
+        """The job's one collective (td_batch_exchange_peaks): this rank's peaks into the per_rank x world table, then ONE
+        all-reduce(max) on the batch's stream -- enqueued, not waited for (sync() does).  comm None: a job of one rank."""
+        _check(lib().td_batch_exchange_peaks(self.h, comm.h if comm is not None else None, per_rank))
+
+    def peak_table(self, n=None):
+        """The exchanged table, copied to the host (synchronises)."""
+        cnt = _sz(0)
+        lib().td_batch_peak_table(self.h, C.byref(cnt))
+        n = cnt.value if n is None else n
+        out = np.zeros(max(n, 1), np.float32)
+        _check(lib().td_batch_read_peak_table(self.h, out.ctypes.data_as(_fp), n))
+        return out[:n]
 
     def peak_table_device(self, device_ptr, n_total, first=0, stride=1):
         """Fills n_total floats at `device_ptr` (e.g. torch_tensor.data_ptr()): own entries at first + i*stride, 0 elsewhere."""

@@ -55,40 +55,48 @@ def exchange_peaks(local_peaks, n_projects, dist=None, device="cpu", buf=None):
 
 
 class PeakExchange:
-    """The per-project peak table of the whole job, kept on the device: the engine writes this rank's entries straight
-    into the tensor the collective runs on (td_batch_peak_table_device: own entries at rank + i * world, zeros
-    elsewhere), then ONE all-reduce(max) -- RCCL on device memory, no host round trip.  `exchange()` returns when the
-    table is complete in device memory; `host()` copies it out (the caller's report, not part of the exchange).  With a
-    host-side backend (gloo, CPU tests of the N > 1 path) the collective itself needs the table on the host."""
+    """The per-project peak table of the whole job, exchanged by the LIBRARY (td_batch_exchange_peaks, include/termdaw_amd.h): the
+    engine writes this rank's entries into its own device table (own entries at rank + i * world, zeros elsewhere) and runs ONE
+    ncclAllReduce(ncclMax, ncclFloat32) on the batch's stream right behind the renders -- RCCL on device memory, no host
+    synchronisation in between, no torch in the data path.  `dist` (torch.distributed) only carries the 128-byte RCCL id from
+    rank 0 to the others -- what a Rust host would do over a socket -- and, with a host-side backend (gloo: the CPU-hosted tests
+    of the N > 1 path, two ranks on one GPU), serves as the host's own all-reduce behind td_comm_init_host.
+    `exchange()` returns when the table is complete in device memory; `host()` copies it out (the report, not the exchange)."""
 
-    def __init__(self, batch, per_rank, rank, world, dist=None, on_device=True):
-        import torch
-        self.batch, self.rank, self.world, self.dist, self.on_device = batch, rank, world, dist, on_device
+    def __init__(self, batch, per_rank, rank, world, dist=None, on_device=True, comm=None):
+        """comm: an api.Comm of the same job to share (one communicator serves every batch of a process)."""
+        from . import api
+        self.batch, self.per_rank, self.rank, self.world, self.dist, self.on_device = batch, per_rank, rank, world, dist, on_device
         self.n_total = per_rank * world
-        self.table = torch.zeros(self.n_total, dtype=torch.float32, device="cuda")
-        self._host = None
-        torch.cuda.synchronize()
+        self.comm = None
+        live = dist is not None and dist.is_initialized()
+        if comm is not None:
+            self.comm = comm
+        elif live and on_device:
+            box = [api.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.comm = api.Comm(box[0], rank, world)          # ncclCommInitRank: returns when every rank has joined
+        elif live:
+            import torch
+
+            def allreduce_max(table):                          # (np.float32 view of the library's page-locked mirror)
+                t = torch.from_numpy(table)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self.comm = api.Comm.over_host(allreduce_max, rank, world)
+
+    def backend(self):
+        return self.comm.backend() if self.comm is not None else "none"
 
     def exchange(self):
-        import torch
-        self.batch.peak_table_device(self.table.data_ptr(), self.n_total, first=self.rank, stride=self.world)
-        self.batch.sync()                 # the engine's stream has written this rank's entries
-        self._host = None
-        if self.dist is not None and self.dist.is_initialized():
-            if self.on_device:
-                self.dist.all_reduce(self.table, op=self.dist.ReduceOp.MAX)
-                torch.cuda.synchronize()  # the reduced table stands in device memory
-            else:
-                t = self.table.cpu()
-                self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-                self._host = t.numpy()
+        self.batch.exchange_peaks(self.comm, self.per_rank)   # table kernel + collective, enqueued on the batch's stream
+        self.batch.sync()                                      # the reduced table stands in device memory
 
     def is_collective(self):
         """True when exchange() runs an all-reduce over more than one rank (it then also is a barrier between them)."""
-        return self.dist is not None and self.dist.is_initialized() and self.dist.get_world_size() > 1
+        return self.comm is not None and self.world > 1
 
     def host(self):
-        return self._host if self._host is not None else self.table.cpu().numpy()
+        return self.batch.peak_table(self.n_total)
 
     def __call__(self):
         self.exchange()

@@ -9,6 +9,7 @@
 #include <chrono>
 
 #include "engine.h"
+#include "comm.h"
 #include "compile.h"
 #include "devmem.h"
 #include "midi.h"
@@ -2134,6 +2135,8 @@ void td_batch_free(td_batch* b) {
         free_arena(b->arena);
         free_prof(b->prof);
         if (b->d_peaks) (void)hipFree(b->d_peaks);
+        if (b->d_table) (void)hipFree(b->d_table);
+        if (b->h_table) (void)hipHostFree(b->h_table);
         if (b->copy_stream) { (void)hipStreamSynchronize(b->copy_stream); (void)hipStreamDestroy(b->copy_stream); }
         if (b->d_pcm_arena) (void)hipFree(b->d_pcm_arena);
         for (hipEvent_t e : b->ev_pool) (void)hipEventDestroy(e);
@@ -2415,6 +2418,8 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
         if (P > b->peaks_cap) {
             TD_HIP(hipStreamSynchronize(b->stream));
             if (b->d_peaks) (void)hipFree(b->d_peaks);
+        if (b->d_table) (void)hipFree(b->d_table);
+        if (b->h_table) (void)hipHostFree(b->h_table);
             b->d_peaks = nullptr;
             b->peaks_cap = 0;
             TD_HIP(hipMalloc(&b->d_peaks, (P + 10) * (sizeof(float) + sizeof(float*))));
@@ -2468,6 +2473,86 @@ int td_batch_peaks(td_batch* b, float* out) {   // host copy of this batch's own
         ok = fail("td_batch_peaks: read-back failed");
     (void)hipFree(d_tab);
     return ok;
+}
+// ---- the job's one collective (comm.h): all-reduce(max) of the per-project peak table across the ranks, behind the C ABI
+int td_comm_unique_id(void* out, size_t bytes) {
+    if (!out || bytes < 128) return fail("td_comm_unique_id: the id takes 128 bytes");
+    return rccl_unique_id(out);
+}
+td_comm* td_comm_init(const void* unique_id, size_t bytes, int rank, int world) {
+    if (!unique_id || bytes < 128) { fail("td_comm_init: the id takes 128 bytes"); return nullptr; }
+    if (world < 1 || rank < 0 || rank >= world) { fail("td_comm_init: rank outside the job"); return nullptr; }
+    if (!ensure_device(t_device)) return nullptr;
+    td_comm* c = new td_comm();
+    c->rank = rank; c->world = world; c->device = t_device; c->kind = 0;
+    if (!rccl_init(c, unique_id, rank, world)) { delete c; return nullptr; }
+    return c;
+}
+td_comm* td_comm_init_host(td_allreduce_max_fn allreduce_max, void* ctx, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) { fail("td_comm_init_host: rank outside the job"); return nullptr; }
+    if (!allreduce_max && world > 1) { fail("td_comm_init_host: no all-reduce given"); return nullptr; }
+    td_comm* c = new td_comm();
+    c->rank = rank; c->world = world; c->device = t_device; c->kind = 1;
+    c->host_allreduce_max = allreduce_max;
+    c->host_ctx = ctx;
+    return c;
+}
+void td_comm_free(td_comm* c) {
+    if (!c) return;
+    if (c->kind == 0 && hipSetDevice(c->device) == hipSuccess) rccl_destroy(c);
+    delete c;
+}
+const char* td_comm_backend(const td_comm* c) { return !c ? "none" : c->kind == 0 ? "rccl-native" : "host-callback"; }
+const char* td_comm_library(void) { return rccl_library_path(); }
+// The peak table of the whole job, per_rank x world floats: this rank's project i at entry rank + i * world, then ONE
+// all-reduce(max) -- on the batch's stream right behind the renders and the table kernel, no host synchronisation in between
+// (RCCL kind), or through the host's own all-reduce on the page-locked mirror (host kind).  c NULL: a job of one rank.
+int td_batch_exchange_peaks(td_batch* b, td_comm* c, size_t per_rank) {
+    const int rank = c ? c->rank : 0, world = c ? c->world : 1;
+    if (b->graphs.size() > per_rank) return fail("td_batch_exchange_peaks: the batch holds more projects than per_rank");
+    if (c && c->kind == 0 && c->device != b->device) return fail("td_batch_exchange_peaks: the communicator belongs to another device");
+    const size_t n = per_rank * (size_t)world;
+    if (!ensure_device(b->device)) return 0;
+    if (!b->stream) TD_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    {   // (a guarded render whose verdict is still out may be done again: its peak is final only then)
+        bool any_armed = false;
+        for (td_graph* g : b->graphs) any_armed = any_armed || g->guard.armed;
+        if (any_armed && !td_batch_sync(b)) return 0;
+    }
+    if (n > b->table_cap) {
+        TD_HIP(hipStreamSynchronize(b->stream));
+        if (b->d_table) (void)hipFree(b->d_table);
+        if (b->h_table) (void)hipHostFree(b->h_table);
+        b->d_table = b->h_table = nullptr;
+        b->table_cap = 0;
+        TD_HIP(hipMalloc((void**)&b->d_table, (n + 16) * sizeof(float)));
+        TD_HIP(hipHostMalloc((void**)&b->h_table, (n + 16) * sizeof(float), hipHostMallocDefault));
+        b->table_cap = n + 16;
+    }
+    b->table_n = n;
+    if (!n) return 1;
+    if (!td_batch_peak_table_device(b, b->d_table, n, (size_t)rank, (size_t)world)) return 0;
+    if (!c) return 1;
+    if (c->kind == 0) return rccl_allreduce_max_f32(c, b->d_table, n, b->stream);   // (a job of one rank too: the same call)
+    if (world == 1 && !c->host_allreduce_max) return 1;
+    TD_HIP(hipMemcpyAsync(b->h_table, b->d_table, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    TD_HIP(hipStreamSynchronize(b->stream));
+    if (!c->host_allreduce_max(c->host_ctx, b->h_table, n)) return fail("td_batch_exchange_peaks: the host's all-reduce failed");
+    TD_HIP(hipMemcpyAsync(b->d_table, b->h_table, n * sizeof(float), hipMemcpyHostToDevice, b->stream));
+    return 1;
+}
+const float* td_batch_peak_table(const td_batch* b, size_t* n) {
+    if (n) *n = b->table_n;
+    return b->d_table;
+}
+int td_batch_read_peak_table(td_batch* b, float* out, size_t n) {
+    if (n > b->table_n) return fail("td_batch_read_peak_table: the table is shorter");
+    if (!n) return 1;
+    if (!ensure_device(b->device)) return 0;
+    TD_HIP(hipMemcpyAsync(b->h_table, b->d_table, n * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+    TD_HIP(hipStreamSynchronize(b->stream));
+    memcpy(out, b->h_table, n * sizeof(float));
+    return 1;
 }
 void td_batch_set_profiling(td_batch* b, int on) { prof_set(b->prof, on); }
 int td_batch_mark(td_batch* b, int which) {

@@ -441,6 +441,9 @@ struct td_batch {
     tde::ChunkBuild build;
     tde::ProfCtx prof;
     float* d_peaks = nullptr;            // [size] per-project peak scratch + [size] source pointers behind it
+    float* d_table = nullptr;            // td_batch_exchange_peaks: the job's peak table, per_rank x world floats (device)
+    float* h_table = nullptr;            // ... its page-locked host mirror (a td_comm of the host kind reduces there)
+    size_t table_cap = 0, table_n = 0;
     size_t peaks_cap = 0;
     std::vector<const float*> peak_src;  // the source-pointer table as the device holds it (td_batch_peak_table_device)
     double host_ms[4] = {0, 0, 0, 0};

@@ -18,7 +18,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "termdaw_amd", "csrc")
-SOURCES = ["engine.cpp", "compile.cpp", "devmem.cpp", "project.cpp", "lua_subset.cpp", "wav.cpp", "midi.cpp"]
+SOURCES = ["engine.cpp", "compile.cpp", "devmem.cpp", "comm.cpp", "project.cpp", "lua_subset.cpp", "wav.cpp", "midi.cpp"]
 
 
 def _build(out_dir):
@@ -30,7 +30,7 @@ def _build(out_dir):
     for p in procs:
         assert p.wait() == 0
     exe = os.path.join(out_dir, "asan_compile")
-    subprocess.check_call(["g++", "-fsanitize=address,undefined", "-o", exe] + [o for _, o in jobs] + ["-lpthread"])
+    subprocess.check_call(["g++", "-fsanitize=address,undefined", "-o", exe] + [o for _, o in jobs] + ["-lpthread", "-ldl"])
     return exe
 
 

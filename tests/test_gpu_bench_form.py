@@ -169,7 +169,7 @@ def test_bench_one_rank_over_rccl():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["n_ranks_seen"] == 1 and out["value"] > 0
-    assert out["exchange_backend"] == "nccl"
+    assert out["exchange_backend"] == "rccl-native"      # td_batch_exchange_peaks: ncclAllReduce on the engine's stream, no torch in the data path
     assert out["peak_table_entries"] == 3 and all(v > 0 for v in out["peak_table"])
     assert out["ranks"]["n"] == 1 and out["ranks"]["exchange_ms"] >= 0.0 and out["ranks"]["start_skew_us"] == 0.0
 
