@@ -652,9 +652,16 @@ def compact(o):
             rr["traffic_profiled"] = {"bytes": tp.get("bytes_per_launch"), "l2_hit": tp.get("l2_hit_rate"), "avg_us_rocprof": tp.get("avg_us_rocprof"),
                                       "file": tp.get("profile")}
         for k in ("bytes_per_frame", "ceiling_ms", "frac_of_ubench_ceiling", "ubench_ceiling_GBs", "hbm_compulsory_bytes", "hbm_compulsory_frac",
+                  "wasted_vs_compulsory", "traffic_source", "l2_hit_profiled", "frac_l2_stream", "peak_l2_stream_GBs", "frac_gather_rows",
+                  "peak_gather_rows_GBs", "valu_issue_ms", "frac_valu_issue",
                   "frac_of_l2_peak", "frac_of_measured_copy", "measured_copy_GBs", "copy_GBs", "cold_tables"):
             if k in r:
                 rr[k] = r[k]
+        ct = r.get("cold_tables") or {}
+        if "ms_per_render" in ct:   # (flat: a consumer that keeps only the scalars of this object keeps these)
+            rr["cold_ms_per_render"] = ct["ms_per_render"]
+            rr["cold_projects"] = ct.get("projects")
+            rr["warm_ms_per_render"] = ct.get("warm_ms_per_render")
         if "l2_mall_split" in r:
             rr["l2_mall_split"] = {"floor_ms": r["l2_mall_split"]["floor_ms"], "l2_hit": r["l2_mall_split"]["l2_hit_rate_profiled"]}
         rr["note"] = NOTES + "#roofline"
@@ -936,7 +943,9 @@ def main():
             prof = (tp.get(mode_key) or {}).get(name) or {}
             row = {"kernel": name, "avg_ms": round(avg_ms, 5), "launches": int(launches), "projects_per_launch": P,
                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "achieved": round(gbs, 1), "unit": "GB/s",
-                   "traffic": None,
+                   # fabric-side (L2-miss) bytes per launch from the committed rocprofv3 --pmc passes of this command -- the counters
+                   # cannot be read from inside a process that is being timed; `traffic_profiled` says which file and how it was made
+                   "traffic": prof.get("hbm_side_bytes_per_launch"),
                    "traffic_profiled": None if "hbm_side_bytes_per_launch" not in prof else {
                        "bytes_per_launch": prof["hbm_side_bytes_per_launch"], "l2_hit_rate": prof.get("l2_hit_rate"),
                        "avg_us_rocprof": prof.get("avg_us"),
@@ -990,6 +999,15 @@ def main():
             vp = ((profiled("valu") or {}).get("config2") or {}).get(dom["kernel"])
             if vp:
                 roofline["valu_profiled"] = dict(vp, profile="profiles/%s_valu.json" % PROFILE_TAG)
+                if fused and packed and dom["kernel"] == "k_sum" and vp.get("SQ_INSTS_VALU"):
+                    # what the launch costs in VALU issue alone: wave-level instructions (profiled) x the measured issue time of
+                    # their class -- SDWA conversions and packed f32, 1.75 ns per wave and SIMD (tools/ubench/issue_rate.hip) --
+                    # over the chip's 1 024 SIMDs: the second thing the launch is limited by, beside the cache hierarchy
+                    roofline["valu_issue_ms"] = round(vp["SQ_INSTS_VALU"] * 1.75e-9 / 1024.0 * 1e3, 5)
+                    roofline["frac_valu_issue"] = round(roofline["valu_issue_ms"] / dom["avg_ms"], 4)
+            if dom.get("traffic") and dom.get("hbm_compulsory_bytes"):
+                roofline["wasted_vs_compulsory"] = round(dom["traffic"] / dom["hbm_compulsory_bytes"], 2)
+                roofline["traffic_source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 half-count] + WRITE_SIZE, per launch)" % tp_tag
             if fused and packed and dom["kernel"] == "k_sum":
                 # two hardware-denominated readings beside the measured ceiling (guide figures only, no ubench):
                 #  frac_of_l2_peak: the gathered + written bytes against the aggregate L2 bandwidth;
@@ -1005,13 +1023,23 @@ def main():
                                                  "floor_ms": round(floor_ms, 5), "frac": round(floor_ms / dom["avg_ms"], 4),
                                                  "note": "bytes x hit rate / 17.8 TB/s + bytes x (1 - hit rate) / 8.6 TB/s (MI355X_MICROARCH.md, "
                                                          "'Indexed rows: gather'), hit rate from profiles/%s_pmc_summary.json" % tp_tag}
-                    # The primary reading: `peak` is that guide-priced gather rate for THIS launch's split, `bound` says so, `frac`
-                    # is floor / measured -- no dependency on this repo's own ceiling kernel, which stays beside it
+                    # Two guide-priced floors for THIS launch's split, both printed, the HARDER one as `frac` (round-5 review: the
+                    # gathers are contiguous 64 B per lane -- a wave reads 4 KB in a row -- so the hits are priced at the L2's STREAM
+                    # rate, 34.5 TB/s, not at the rate of random 1 152-byte rows; the misses at the Infinity-Cache rate either way):
+                    #   frac_l2_stream   = (bytes x hit / 34.5 TB/s + bytes x (1 - hit) / 8.6 TB/s) / measured
+                    #   frac_gather_rows = (bytes x hit / 17.8 TB/s + bytes x (1 - hit) / 8.6 TB/s) / measured   (round 5's `frac`)
+                    # No dependency on this repo's own ceiling kernel, which stays beside them (frac_of_ubench_ceiling).
+                    stream_floor_ms = (gathered * hit / (L2_PEAK_GBS * 1e9) + gathered * (1.0 - hit) / (MALL_GATHER_GBS * 1e9)) * 1e3
                     roofline["frac_of_ubench_ceiling"] = roofline.get("frac")
                     roofline["ubench_ceiling_GBs"] = roofline.get("peak")
-                    roofline["bound"] = "l2+infinity-cache gather"
-                    roofline["peak"] = round(gathered / (floor_ms * 1e-3) / 1e9, 1)
-                    roofline["frac"] = round(floor_ms / dom["avg_ms"], 4)
+                    roofline["frac_gather_rows"] = round(floor_ms / dom["avg_ms"], 4)
+                    roofline["peak_gather_rows_GBs"] = round(gathered / (floor_ms * 1e-3) / 1e9, 1)
+                    roofline["frac_l2_stream"] = round(stream_floor_ms / dom["avg_ms"], 4)
+                    roofline["peak_l2_stream_GBs"] = round(gathered / (stream_floor_ms * 1e-3) / 1e9, 1)
+                    roofline["l2_hit_profiled"] = hit
+                    roofline["bound"] = "l2 stream + infinity-cache (hits at 34.5 TB/s, misses at 8.6 TB/s)"
+                    roofline["peak"] = roofline["peak_l2_stream_GBs"]
+                    roofline["frac"] = roofline["frac_l2_stream"]
                 else:
                     roofline["bound"] = "l2+infinity-cache gather (ceiling measured in-process: tools/ubench)"
             if fused and dom["kernel"] == "k_sum":

@@ -2418,8 +2418,6 @@ int td_batch_peak_table_device(td_batch* b, float* d_table, size_t n_total, size
         if (P > b->peaks_cap) {
             TD_HIP(hipStreamSynchronize(b->stream));
             if (b->d_peaks) (void)hipFree(b->d_peaks);
-        if (b->d_table) (void)hipFree(b->d_table);
-        if (b->h_table) (void)hipHostFree(b->h_table);
             b->d_peaks = nullptr;
             b->peaks_cap = 0;
             TD_HIP(hipMalloc(&b->d_peaks, (P + 10) * (sizeof(float) + sizeof(float*))));

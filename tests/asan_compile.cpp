@@ -44,6 +44,36 @@ int main(int argc, char** argv) {
                 td_state_free(s);
             }
     }
+    {   // the N > 1 exchange on host memory (td_comm_init_host): two accepted projects as one rank's batch of a two-rank job
+        std::vector<td_state*> st;
+        for (int a = 1; a < argc && st.size() < 2; ++a) {
+            const std::string dir = argv[a];
+            td_state* s = td_state_new("", 48000, (size_t)atol(slurp(dir + "/meta.txt").c_str()));
+            if (s && td_state_refresh_source(s, slurp(dir + "/project.lua").c_str())) st.push_back(s);
+            else if (s) td_state_free(s);
+        }
+        if (st.size() == 2) {
+            td_batch* b = td_batch_new();
+            for (td_state* s : st) if (td_batch_add(b, td_state_graph(s), td_state_samplebank(s), td_state_flowwbank(s)) < 0) ++failed;
+            struct Ctx { size_t calls, n; } ctx{0, 0};
+            td_comm* c = td_comm_init_host([](void* p, float* table, size_t n) -> int {
+                Ctx* x = (Ctx*)p; x->calls += 1; x->n = n;
+                for (size_t i = 0; i < n; ++i) table[i] = table[i] > 0.5f ? table[i] : 0.5f;   // ("the other rank" holds 0.5 everywhere)
+                return 1; }, &ctx, 1, 2);
+            if (!c) ++failed;
+            td_batch_rewind(b);
+            if (!td_batch_render_all(b, 3, 16)) ++failed;
+            if (c && !td_batch_exchange_peaks(b, c, 3)) ++failed;
+            if (!td_batch_sync(b)) ++failed;
+            float table[6] = {0};
+            if (!td_batch_read_peak_table(b, table, 6)) ++failed;
+            if (ctx.calls != 1 || ctx.n != 6) ++failed;
+            for (float v : table) if (!(v >= 0.5f)) ++failed;
+            td_comm_free(c);
+            td_batch_free(b);
+        }
+        for (td_state* s : st) td_state_free(s);
+    }
     printf("asan_compile done: %d projects, %zu renders, %zu rejected refreshes, %zu failed calls\n", argc - 1, renders, rejected, failed);
     return failed ? 1 : 0;
 }
