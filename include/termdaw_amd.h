@@ -190,68 +190,66 @@ void td_trim_memory(void);
  * restated (what debug_sine / synth use under engine option "sine_mode" 1; tests compare it with the host's sinf on all 2^32 bit patterns), 0: the tolerance-class sine.  Host pointers, n values; 1 = done. */
 int td_device_sinf(const float* in, float* out, size_t n, int sine_mode);
 size_t td_cached_memory_bytes(void);
-/* Engine options (no reference counterpart): "fuse_sources" 0|1 (default 1: sample_loop sources are
- * gathered inside the consuming sum kernel instead of through an edge buffer -- same values, same order);
+/* Engine options (no reference counterpart).  SEVEN supported keys:
+ * "fuse_sources" 0|1 (default 1: sample_loop sources are gathered inside the consuming sum kernel instead of through an edge
+ *   buffer -- same values, same order; 0 = SURVEY 8(d)'s edge-buffer model, `bench.py --no-fuse`);
+ * "packed_samples" 0|1 (default 1: inlined sources gather the packed 16-bit form of samples that came from <= 16-bit integer
+ *   PCM -- (float)int * scale is how the f32 bank entry was made, so values are identical);
  * "max_chunk_frames" n (edge-buffer chunk cap, default 2^24; smaller values force multi-chunk renders);
- * "packed_samples" 0|1 (default 1: inlined sources gather the packed 16-bit form of samples that came from
- * <= 16-bit integer PCM -- (float)int * scale is how the f32 bank entry was made, so values are identical);
- * "inline_adsr" 0|1 (default 1: an Adsr vertex with one input (not itself such a vertex) whose only consumer -- directly or through
- * one single-input Sum -- is a Sum / Normalize / band-pass is evaluated inside that consumer's summing kernel, as one
- * of its input terms: same operations in the same order, one launch and one edge buffer less; needs fuse_sources);
- * "band_parallel" 0|1 (default 1: band-pass vertices use the speculative-segment kernels, still exact);
- * "band_mode" 0|1|2 (default 0 = exact: band_pass_gen, extensions.rs:654-689, bit-identical to the reference's serial
- * recurrence -- the parity mode.  1 = scan: the same filter as a blocked affine scan, TOLERANCE class: another
- * realisation of the reference's own f32 rounding noise -- measured 6.3e-8 RMS through 84 band-pass vertices in a row,
- * +-1 LSB on the PCM; above 1e-6 of the output peak only where a band-pass vertex removes >= 30 dB of its input and a
- * Normalize vertex brings the rest back up (8 of 18 000 random graphs, at most 3.3e-6).  A state that goes
- * NaN / infinite stays NaN, as in the reference.  One launch per band-pass vertex, and ONE launch for a whole chain of
- * `pass` band-pass vertices linked by single-input Sum / Adsr vertices, with the Sum vertex in front and the Normalize
- * vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers reach its
- * output only as NaN once they are not finite (extensions.rs:685-687): the chain launch does not run them and tracks the
- * first non-finite right input frame instead.  2 = the scan UNDER THE GUARD -- what a State defaults to: `pass` vertices take
- * the chain launch wherever its own estimate of its deviation can be carried to the output (any static path, at most one
- * Normalize vertex on it; no sample loop shorter than 2 048 frames upstream), every other band-pass vertex keeps the exact
- * kernels, and a render whose estimate is over "band_guard_ppb" x 1e-9 RMS (default 200) is rendered again with the exact
- * kernels when the graph is drained: td_graph_band_guard_stats);
- * "sine_mode" 0|1 (default 1 on a bare td_graph, 0 on a State's graph: debug_sine_gen / synth_gen, extensions.rs:450,501 `f32::sin`.
- * 1 = the oscillators evaluate glibc's sinf -- libm's, what `f32::sin` calls on Linux -- operation for operation in double
- * precision (glibc 2.28 and later, x86-64 FMA variant; tools/sinf_restate.c agrees with the host's sinf on every finite float) and
- * the envelopes adsr.rs's own divisions: the two kinds carry the reference's bits like every other kind (50 000 random graphs x 3
- * renders bit for bit).  0 = the tolerance class: a 14-instruction f32 sine (<= 3.3e-7 from sinf), reciprocal envelopes, the
- * affine / one-grid Synth forms -- <= 1e-6 RMS of the vertex' scale, 0.09 instead of 0.32 ms for BASELINE config 3's oscillators);
- * "one_grid_sources" 0|1 (default 1: the launches of a level that read no edge buffer -- affine Synth, wavetable voice,
- *   SampleLerp, the Adsr vertices' envelope buffers -- go out as ONE grid, each workgroup running its own family's code: same
- *   values as the separate launches, one ramp and one tail instead of up to four) /
- * "band_chain" 0|1 (default 1; 0: scan mode launches every band-pass vertex on its own) / "fuse_normalize" 0|1 (default 1:
- * in scan mode a Normalize vertex whose one input is a scan launch's last vertex is evaluated by that launch) / "band_scan_nf" 8|16 (frames
- * per lane of a single vertex' launch) / "band_scan_depth" n (default 64: the look-back reaches back until what a tile
- * still weighs is below e^-n) / "band_scan_debug" n (tests: bit 0 forces the bounded-wait fallback);
- * "band_warmup" n / "band_short" n / "band_live_exp" n (defaults 150 / 40 / 9: long and short speculative
- * warm-up = n / gamma frames, and the energy ratio 1e-n under which the short one is taken -- they move speed
- * only, the bit-wise check and repair keep every result exact);
- * "band_quick" n / "band_medium" n / "band_depth" n / "band_guess_min" n (defaults 12 / 30 / 100 / 4096 frames: the
- * guess is used where the short warm-up is at least band_guess_min long; band_quick 0 switches the mechanism off):
- * for cut-offs below ~75 Hz the warm-up starts from the exact-arithmetic state at its first frame (per-256-frame
- * block responses of the two smoothers, chained in double until (1-gamma)^(256 K) <= e^-band_depth) and then only
- * takes n / gamma frames -- again speed only;
- * "spec_normalize" 0|1 (default 1: a render after td_graph_normalize_scan normalises in ONE pass, speculating that
- * no block exceeds the scanned peak; a check kernel redoes the vertex the two-pass way when one does -- same values);
- * "single_pass_normalize" 0|1 (default 1: a FRESH render of a Normalize vertex whose inputs are all looping samples on a
- * timeline of >= 1 800 blocks finds the running peak inside the summing launch -- every tile publishes its maximum and
- * reads the earlier tiles' -- and scales, pans, gains and quantises out of registers; the same check kernel stands behind
- * it; 0: the two launches sum + peaks / scale -- same values) / "norm_debug" n (tests: bit 0 makes every tile of such a launch
- * give up its wait for the earlier tiles at once, so the check kernel redoes the vertex: same values);
  * "output_f32" 0|1 (default 1; 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames --
- * td_graph_read_f32 then fails, the PCM is unchanged);
- * "table_cache" 0|1 (default 1: the compiled event tables of an event-driven vertex stay on the device and are
- * reused while events, FlowwBank cursor, chunk shape and the vertex' carried state at the chunk start are unchanged;
- * identical vertices of one chunk share one set -- 0 replays the events for every vertex and render);
- * "graph_replay" 0|1 (default 0: when 1, a submission whose uploaded bytes and launch list equal the previous one's replays
- * the captured HIP graph of that one -- one hipGraphLaunch instead of one call per kernel; measured: host launch time of a
- * 425-launch project 1.16 -> 0.01 ms, GPU time unchanged, short projects slower by the replay's fixed cost);
- * "branch_streams" 0|1 (default 0: when 1, independent launch families of a level run on separate HIP
- * streams with a fork/join per level -- measured slower than the single-stream batched schedule). */
+ *   td_graph_read_f32 then fails, the PCM is unchanged);
+ * "band_mode" 0|1|2 (default 0 = exact: band_pass_gen, extensions.rs:654-689, bit-identical to the reference's serial
+ *   recurrence -- the parity mode.  1 = scan: the same filter as a blocked affine scan, TOLERANCE class: another
+ *   realisation of the reference's own f32 rounding noise -- measured 6.3e-8 RMS through 84 band-pass vertices in a row,
+ *   +-1 LSB on the PCM; above 1e-6 of the output peak only where a band-pass vertex removes >= 30 dB of its input and a
+ *   Normalize vertex brings the rest back up (8 of 18 000 random graphs, at most 3.3e-6).  A state that goes
+ *   NaN / infinite stays NaN, as in the reference.  One launch per band-pass vertex, and ONE launch for a whole chain of
+ *   `pass` band-pass vertices linked by single-input Sum / Adsr vertices, with the Sum vertex in front and the Normalize
+ *   vertex behind.  Cut-offs below ~1.5 Hz keep the exact kernels.  A `pass` vertex' right-channel smoothers reach its
+ *   output only as NaN once they are not finite (extensions.rs:685-687): the chain launch does not run them and tracks the
+ *   first non-finite right input frame instead.  2 = the scan UNDER THE GUARD -- what a State defaults to: `pass` vertices take
+ *   the chain launch wherever its own estimate of its deviation can be carried to the output (any static path, at most one
+ *   Normalize vertex on it; no sample loop shorter than 2 048 frames upstream), every other band-pass vertex keeps the exact
+ *   kernels, and a render whose estimate is over the bound is rendered again with the exact kernels when the graph is drained:
+ *   td_graph_band_guard_stats);
+ * "band_guard_ppb" n (default 200: the guard's bound on the estimated RMS deviation of a render, in 1e-9 of full scale -- for
+ *   band_mode 2 and sine_mode 2 alike; 0: every audited render is done again);
+ * "sine_mode" 0|1|2 (default 1 on a bare td_graph, 2 on a State's graph: debug_sine_gen / synth_gen, extensions.rs:450,501 `f32::sin`.
+ *   1 = the oscillators evaluate glibc's sinf -- libm's, what `f32::sin` calls on Linux -- operation for operation in double
+ *   precision (glibc 2.28 and later, x86-64 FMA variant; tools/sinf_restate.c agrees with the host's sinf on every finite float) and
+ *   the envelopes adsr.rs's own divisions: the two kinds carry the reference's bits like every other kind (50 000 random graphs x 3
+ *   renders bit for bit).  0 = the fast forms: a 14-instruction f32 sine (<= 3.3e-7 from sinf), reciprocal envelopes, the
+ *   affine / one-grid Synth forms -- ~3e-8 RMS of the vertex' OWN scale (what a graph makes of that -- cancellation, then a Normalize
+ *   vertex -- is not bounded), 0.09 instead of 0.32 ms for BASELINE config 3's oscillators.  2 = the fast forms UNDER THE GUARD:
+ *   behind every fast launch k_sine_probe evaluates one frame in 256 the reference's way (mode 1's code) and measures the
+ *   distance; the audit carries it to the output like a scan launch's estimate (static gains, the Normalize vertex' running
+ *   1 / max at the sample's own block); over the bound the render is done again in mode 1's form.  A vertex whose path to the
+ *   output the audit cannot follow (two Normalize vertices in a row) renders in mode 1's form from the start).
+ * The defaults of td_graph_new and of a State's graph differ in exactly two keys, band_mode (0 | 2) and sine_mode (1 | 2)
+ * (tests/test_host_logic.py::test_the_two_default_sets_differ_in_two_keys).
+ *
+ * Test hooks, "debug.<name>" -- not part of the supported surface: each selects an older or alternative form of a launch, or moves
+ * a speculation parameter whose outcome the device verifies; value-neutral by construction, and each pinned by the test named:
+ *   debug.norm n (bit 0: every single-pass Normalize tile gives up its wait at once -> the check kernel redoes the vertex;
+ *     tests/test_gpu_bench_form.py) / debug.spec_normalize 0|1 / debug.single_pass_normalize 0|1 / debug.fuse_normalize 0|1
+ *     (the two-launch Normalize forms; tests/test_gpu_spec_normalize.py, test_gpu_band_scan.py) /
+ *   debug.inline_adsr 0|1 (an Adsr vertex materialised instead of read through; tests/test_gpu_parity.py) /
+ *   debug.one_grid_sources 0|1 (a level's source launches one by one instead of as k_sources; tests/test_gpu_sources_grid.py) /
+ *   debug.table_cache 0|1 (event tables recompiled every render; tests/test_gpu_parity.py) /
+ *   debug.band_chain 0|1, debug.band_scan_nf 8|16, debug.band_scan n (scan mode: one launch per vertex, frames per lane, bit 0
+ *     = every look-back poll times out and predecessors are recomputed; tests/test_gpu_band_scan.py) /
+ *   debug.band_serial 0|1 (1: every band-pass vertex on the serial kernel; tests/test_gpu_parity.py) /
+ *   debug.band_quick n, debug.band_medium n, debug.band_short n, debug.band_warmup n, debug.band_live_exp n, debug.band_depth n
+ *     (the exact band-pass' speculative warm-up lengths in 1 / gamma frames and its liveness thresholds: speed only, the
+ *     bit-wise check and repair of k_band_fix keep every result exact; tests/test_gpu_quirks.py, tools/band_*_sweep.py).
+ * Gone in round 6, with the measurements that retired them in DESIGN.md 7: "branch_streams" (a HIP stream per independent
+ * branch of a level: 1.64 against 1.10 ms), "graph_replay" (HIP-graph capture of an unchanged submission: GPU time unchanged,
+ * short projects slower), "band_parallel" 0 (the serial band-pass kernel for everything: 58 against 0.7 ms; it remains the
+ * fallback for cut-offs below 5 Hz and block pulls), "band_guess_min" / "band_scan_depth" (constants now). */
 int td_graph_set_option(td_graph* g, const char* key, long value);
+/* Reads any key td_graph_set_option takes (1 = found).  td_graph_option_key(n): the n-th key, NULL behind the last. */
+int td_graph_get_option(const td_graph* g, const char* key, long* value);
+const char* td_graph_option_key(size_t n);
 /* Counters of the exact parallel band-pass for the last rendered chunk, summed over its band-pass
  * vertices: out[0] repair cascades started (segments whose entry state failed the bit-wise check, incl.
  * re-checks after optimistic repairs), out[1] segments recomputed, out[2] of those cut short by a fixed point

@@ -94,6 +94,8 @@ SIGNATURES = {
     "td_device_sinf": (_i32, [_fp, _fp, _sz, _i32]),
     "td_cached_memory_bytes": (_sz, []),
     "td_graph_set_option": (_i32, [_vp, _cp, _lng]),
+    "td_graph_get_option": (_i32, [_vp, _cp, C.POINTER(_lng)]),
+    "td_graph_option_key": (_cp, [_sz]),
     "td_graph_band_stats": (_i32, [_vp, C.POINTER(C.c_uint32)]),
     "td_graph_band_guard_stats": (_i32, [_vp, C.POINTER(C.c_double)]),
     "td_batch_new": (_vp, []),
@@ -467,6 +469,11 @@ class Graph:
 
     def set_option(self, key, value):
         _check(lib().td_graph_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = _lng(0)
+        _check(lib().td_graph_get_option(self.h, key.encode(), C.byref(v)))
+        return int(v.value)
 
 
 COMM_ID_BYTES = 128

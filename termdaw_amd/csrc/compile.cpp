@@ -671,6 +671,10 @@ void build_plan(td_graph* g) {
 // Band-pass execution plan (DESIGN.md "exact parallel band-pass"): segment length S, warm-up W.  The
 // warm-up must outlast the contraction (1 - gamma)^W of the slower chain.  The choice affects speed only --
 // k_band_fix verifies every segment bit for bit and repairs what failed.
+constexpr size_t kBandBatchQuads = 12288;   // segments of one launch over all its projects before they are made longer (192 workgroups; measured: P = 2 .. 32 config-4 projects)
+constexpr uint32_t kBandBatchMaxS = 4096;
+constexpr uint32_t kBandGuessMin = 4096;    // the block-response guess is used where the short warm-up is at least this long (frames)
+constexpr unsigned kBandScanDepth = 64;     // band_mode 1 / 2: look-back until (1 - gamma)^(tile K) <= e^-64
 struct BandPlan {
     bool parallel = false;
     uint32_t S = 0, W = 0, Ws = 0, nseg = 0;
@@ -684,7 +688,7 @@ struct BandPlan {
 };
 static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     BandPlan p;
-    if (!g->band_parallel) return p;
+    if (g->band_serial) return p;   // (tests: the serial kernel)
     float gmin = 1.0f;
     if (v.lgamma != 0.0f) gmin = fminf(gmin, fabsf(v.lgamma));
     if (v.hgamma != 0.0f) gmin = fminf(gmin, fabsf(v.hgamma));
@@ -696,14 +700,9 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
     p.Ws = std::min(p.W, ((uint32_t)((double)g->band_short / (double)gmin + 64.0) + 31u) & ~31u);   // coalescence only
     p.Ws = (p.Ws + 255u) & ~255u;                                                   // whole 256-frame liveness blocks
     p.W = (std::max(p.W, p.Ws) + 255u) & ~255u;                                     // (every window starts on a block boundary)
-    p.S = 256;
-    while ((M + p.S - 1) / p.S > kBandMaxSegs && p.S < kBandMaxS) p.S *= 2;
-    p.nseg = (uint32_t)((M + p.S - 1) / p.S);
-    if (p.nseg > kBandMaxSegs) return p;
-    p.parallel = p.nseg >= 8;        // tiny chunks (block pulls) stay on the serial kernel
     // (the guess pays where the short warm-up is long -- cut-offs below ~75 Hz; elsewhere the walk is a few
     // hundred steps anyway and the block responses would only cost their reduction in the input-sum kernel)
-    if (p.parallel && g->band_quick && p.S == 256 && p.Ws >= g->band_guess_min) {
+    if (g->band_quick && p.Ws >= kBandGuessMin) {   // (segments are whole 256-frame blocks: a window starts where a block does)
         // Horner depth: the chained block responses must carry the memory of everything that can still matter.  A deep
         // effect chain swings over tens of decades (84 envelope stages: 25), so "matter" is priced against the whole
         // f32 exponent range a past burst can tower over the present: (1 - gamma)^(256 K) <= e^-band_depth, 100 by
@@ -727,6 +726,26 @@ static BandPlan plan_band(const td_graph* g, const Vertex& v, size_t M) {
             p.Wq2 = std::min(p.Ws, (std::max(wq, wq2) + 255u) & ~255u);
         }
     }
+    p.S = 256;
+    while ((M + p.S - 1) / p.S > kBandMaxSegs && p.S < kBandMaxS) p.S *= 2;
+    // In a batch the segments grow with the number of projects rendering beside this one (round 6): every segment pays its
+    // warm-up walk -- ~12 000 frames of input re-read for a 20 Hz smoother -- and a lone project needs all the 256-frame segments
+    // it can get to fill the chip (11 252 quads for 60 s), where the neighbouring windows' re-reads hit L2.  P projects offer P
+    // times the quads, their buffers no longer fit any cache, and the walks become HBM traffic: 11.3 ms per config-4 project
+    // at P = 32, the same as alone.  Longer segments, fewer walks: the smallest power of two that still leaves ~1.5 workgroups
+    // per CU (4.5 ms per project at P = 32 with 4 096 frames).  Speed only: k_band_fix checks every hand-over bit for bit.
+    {
+        const size_t P = std::max<size_t>(1, g->batch_projects);
+        static const long seg_env = getenv("TD_BAND_SEG") ? atol(getenv("TD_BAND_SEG")) : 0;   // (experiments: the length by hand)
+        // (... and never longer than the walk it saves: a 200 Hz smoother's 1 600 frames are not worth a 4 096-frame segment's
+        // serial output phase -- BASELINE config 3 in a batch of 32: 0.35 ms per project with 4 096 frames, 0.20 with 1 024)
+        const uint32_t walk = p.Wq2 ? p.Wq2 : p.Ws;
+        if (seg_env >= 256 && seg_env % 256 == 0) p.S = (uint32_t)seg_env;
+        else while (P * ((M + p.S - 1) / p.S) > kBandBatchQuads && p.S < kBandBatchMaxS && 2u * p.S <= walk) p.S *= 2;
+    }
+    p.nseg = (uint32_t)((M + p.S - 1) / p.S);
+    p.parallel = p.nseg <= kBandMaxSegs && p.nseg >= 8;   // tiny chunks (block pulls) stay on the serial kernel
+    if (!p.parallel) p.Wq = p.Wq2 = p.Kl = p.Kh = 0;     // (the serial kernel takes no guess)
     return p;
 }
 
@@ -753,7 +772,7 @@ static bool plan_band_scan(const td_graph* g, const Vertex& v, size_t M, ScanPla
         const double q = 1.0 - (double)gamma;
         if (!(q > 0.0)) continue;               // gamma = 1: the state is the last input frame
         const double per_tile = -tile * log(q); // nats of decay per tile
-        kmax = std::max(kmax, ceil((double)g->band_scan_depth / per_tile));
+        kmax = std::max(kmax, ceil((double)kBandScanDepth / per_tile));
     }
     if (!(kmax <= (double)kScanMaxK)) return false;
     sp->K = (uint32_t)kmax;

@@ -492,21 +492,12 @@ static int ensure_graph_device(td_graph* g) {
         TD_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         g->owns_stream = true;
     }
-    if (!g->ev_fork) {
-        TD_HIP(hipEventCreateWithFlags(&g->ev_fork, hipEventDisableTiming));
-        TD_HIP(hipMalloc(&g->d_scalar, 256));
-    }
+    if (!g->d_scalar) TD_HIP(hipMalloc(&g->d_scalar, 256));
     if (!g->guard.h_word) {   // (band_mode 2: k_band_audit's verdict lands here)
         TD_HIP(hipHostMalloc((void**)&g->guard.h_word, 64, hipHostMallocMapped | hipHostMallocCoherent));
         g->guard.h_word[0] = 0u;
         g->guard.h_word[1] = 0u;
         TD_HIP(hipHostGetDevicePointer((void**)&g->guard.d_word, g->guard.h_word, 0));
-    }
-    if (g->branch_streams && !g->aux[0]) {   // branch streams are made on first use (a batch of 64 graphs never needs them)
-        for (int a = 0; a < td_graph::kAuxStreams; ++a) {
-            TD_HIP(hipStreamCreateWithFlags(&g->aux[a], hipStreamNonBlocking));
-            TD_HIP(hipEventCreateWithFlags(&g->ev_join[a], hipEventDisableTiming));
-        }
     }
     return 1;
 }
@@ -615,7 +606,6 @@ static int ensure_arena(Arena& ar, size_t bytes, hipStream_t stream) {
     ar.device_bytes = cap;
     ar.inflight = false;
     ar.valid = 0;
-    ar.graph_key.clear();
     ar.esync_len = 0;   // (new memory: the epoch-tagged words are zeroed by the next submission that has any)
     return 1;
 }
@@ -624,7 +614,6 @@ static void free_arena(Arena& ar) {
     if (ar.h) (void)hipHostFree(ar.h);
     if (ar.d) (void)hipFree(ar.d);
     if (ar.copied) (void)hipEventDestroy(ar.copied);
-    if (ar.graph_exec) (void)hipGraphExecDestroy(ar.graph_exec);
     if (ar.h_flag) (void)hipHostFree(ar.h_flag);
     ar = Arena{};
 }
@@ -661,31 +650,14 @@ struct Prof {
     }
 };
 
-// Branch streams: vertices of one topological level are mutually independent.  Same-kind vertices already
-// share one batched launch; launches of DIFFERENT kinds in a level go to separate HIP streams (fork after the
-// previous level, join before the next) so independent branches of the graph overlap on the device.  The
-// sum -> scale -> band-pass chain of a level stays on the main stream.
-static int aux_stream_of(int fam) {
-    switch (fam) {
-        case F_LOOP: return 0;
-        case F_MULTI: return 1;
-        case F_LERP: return 2;
-        case F_SINE: return 3;
-        case F_SYNTH: return 4;
-        case F_SAMPSYN: return 4;
-        case F_ADSR: return 5;
-        case F_BAND: return 6;
-        default: return -1;
-    }
-}
-
 // Steps 3 and 4 for everything compiled into `cb`: patch pointers, upload the tables (skipped when the device
 // copy is already byte-identical), launch level by level on `stream`.  With several graphs in `cb` (a batch)
 // the launches are first merged: same level, family, launch parameters -> ONE grid whose blockIdx.y runs over
 // the descriptors of all the graphs (their descriptors are copied into one contiguous array behind the tables).
-// `fork_g`: the graph whose aux streams carry the independent launch families of a level (branch streams; single
-// graph only).  *scratch_base = device address the scratch offsets of this submission refer to.
-static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& prof, td_graph* fork_g,
+// *scratch_base = device address the scratch offsets of this submission refer to.  (Launches of one level go out on the ONE
+// stream in launch order: a stream per independent branch -- built in round 2 -- cost more in fork / join events than the
+// branches overlapped, 1.64 against 1.10 ms on the 60 s drum project; same-kind branches share a batched launch anyway.)
+static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& prof, td_graph* /* the graph when there is ONE: unused */,
                         const uint8_t** scratch_base, double* host_ms /* [2]: upload, launches */) {
     const auto tp2 = std::chrono::steady_clock::now();
     Staging& st = *cb.st;
@@ -763,9 +735,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     ar.inflight = false;
     // re-rendering unchanged projects from the same state compiles to byte-identical tables: the copy
     // already on the device is reused (kernels never write the uploaded region)
-    bool arena_same = true;
     if (!(ar.valid == st.b.size() && memcmp(ar.h, st.b.data(), st.b.size()) == 0)) {
-        arena_same = false;
         memcpy(ar.h, st.b.data(), st.b.size());
         if (debug_sync() & 1) TD_HIP(hipStreamSynchronize(stream));
         if (debug_sync() & 4) fprintf(stderr, "U arena %zu\n", st.b.size());
@@ -777,51 +747,6 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         ar.inflight = true;
         ar.valid = st.b.size();
     }
-    // HIP-graph replay (td_graph_set_option "graph_replay"): unchanged uploaded bytes + unchanged launch list = the very
-    // same kernel launches with the very same arguments; the captured sequence of the last submission is replayed by one
-    // hipGraphLaunch instead of being issued launch by launch.
-    const bool want_graph = fork_g && fork_g->graph_replay && !fork_g->branch_streams && !prof.now;
-    std::vector<uint64_t> gkey;
-    if (want_graph) {
-        gkey.reserve(launches.size() * 4 + cb.zero.size() * 2 + 2);
-        gkey.push_back(upload);
-        gkey.push_back(sync_at);
-        gkey.push_back(cb.sync_bytes);
-        gkey.push_back(cb.esync_bytes);
-        gkey.push_back(cb.one_grid_sources ? 1u : 0u);
-        for (auto& z : cb.zero) { gkey.push_back(z.off); gkey.push_back(z.bytes); }
-        for (auto& L : launches) {
-            gkey.push_back(((uint64_t)(uint32_t)L.fam << 32) | (uint32_t)L.n);
-            gkey.push_back(L.off);
-            gkey.push_back(((uint64_t)L.aux << 32) | (uint32_t)L.level);
-            gkey.push_back(((uint64_t)L.M << 32) | ((uint64_t)L.bl << 1) | (uint64_t)(L.is_scan & 1));
-        }
-        if (arena_same && ar.graph_exec && gkey == ar.graph_key) {
-            const auto tp3r = std::chrono::steady_clock::now();
-            ar.pending_fix = ar.graph_pending;   // (the replayed launches carry the same deferred check)
-            if (!ar.pending_fix.empty()) note_pending(ar, stream, cur_device());
-            TD_HIP(hipGraphLaunch(ar.graph_exec, stream));
-            host_ms[0] += ms_between(tp2, tp3r);
-            host_ms[1] += ms_between(tp3r, std::chrono::steady_clock::now());
-            return 1;
-        }
-        if (ar.graph_exec) { (void)hipGraphExecDestroy(ar.graph_exec); ar.graph_exec = nullptr; }
-        ar.graph_key.clear();
-        TD_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-    }
-    // An error return between BeginCapture and EndCapture would leave the stream capturing (every later call on it then
-    // fails): this guard ends the capture and drops the partial graph on any exit that has not completed it.
-    struct CaptureGuard {
-        hipStream_t s;
-        bool active;
-        ~CaptureGuard() {
-            if (!active) return;
-            hipGraph_t partial = nullptr;
-            (void)hipStreamEndCapture(s, &partial);
-            if (partial) (void)hipGraphDestroy(partial);
-            (void)hipGetLastError();
-        }
-    } capture_guard{stream, want_graph};
     for (auto& z : cb.zero) TD_HIP(hipMemsetAsync(ar.d + upload + z.off, 0, z.bytes, stream));
     if (debug_sync() & 4) { fprintf(stderr, "Z zero %zu\n", cb.zero.size()); (void)hipStreamSynchronize(stream); fprintf(stderr, "ok\n"); }
     // The launches of a level that read no edge buffer -- affine Synth, wavetable voice, SampleLerp, the envelope buffers -- go
@@ -860,8 +785,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
         size_t l0 = 0;
         while (l0 < launches.size() && launches[l0].level == launches[0].level) ++l0;
         long pick0[4];
-        const bool forks = fork_g && fork_g->branch_streams;
-        zero_in_sources = !forks && !launches.empty() && cb.sync_bytes <= ((size_t)1 << 28) && sources_grid(0, l0, pick0) != 0u;
+        zero_in_sources = !launches.empty() && cb.sync_bytes <= ((size_t)1 << 28) && sources_grid(0, l0, pick0) != 0u;
         if (!zero_in_sources) TD_HIP(hipMemsetAsync(ar.d + sync_at, 0, cb.sync_bytes, stream));
     }
     // The tile words of the stand-alone single-pass Normalize launches carry the submission's EPOCH beside their value (a
@@ -869,21 +793,16 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     // earlier submission never compares equal, so the region is not zeroed between launches -- the memset was 2 us of the
     // headline render's 66.  It is zeroed once whenever it lies elsewhere than last time (what was there before is not
     // known to be words), when the arena is new, and before the epoch counter would wrap.  A captured submission
-    // (graph_replay) replays its arguments: it keeps zeroed words and tag 1.
     uint32_t sum_tag = 1u;
-    if (!cb.esync_bytes || want_graph) ar.esync_len = 0;   // (this submission may write anything where the words lay)
+    if (!cb.esync_bytes) ar.esync_len = 0;   // (this submission may write anything where the words lay)
     if (cb.esync_bytes) {
-        if (want_graph) {
+        if (ar.esync_at != esync_at || ar.esync_len != cb.esync_bytes || ar.epoch == 0xFFFFFFFFu) {
             TD_HIP(hipMemsetAsync(ar.d + esync_at, 0, cb.esync_bytes, stream));
-        } else {
-            if (ar.esync_at != esync_at || ar.esync_len != cb.esync_bytes || ar.epoch == 0xFFFFFFFFu) {
-                TD_HIP(hipMemsetAsync(ar.d + esync_at, 0, cb.esync_bytes, stream));
-                ar.esync_at = esync_at;
-                ar.esync_len = cb.esync_bytes;
-                if (ar.epoch == 0xFFFFFFFFu) ar.epoch = 1u;
-            }
-            sum_tag = ++ar.epoch;
+            ar.esync_at = esync_at;
+            ar.esync_len = cb.esync_bytes;
+            if (ar.epoch == 0xFFFFFFFFu) ar.epoch = 1u;
         }
+        sum_tag = ++ar.epoch;
     }
 
     // ---- 4. launch, level by level
@@ -898,20 +817,9 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
     size_t li = 0;
     while (li < launches.size()) {
         size_t lj = li;
-        uint32_t groups = 0;   // bit 0: main chain, bit 1 + i: aux stream i
-        while (lj < launches.size() && launches[lj].level == launches[li].level) {
-            const int a = aux_stream_of(launches[lj].fam);
-            groups |= a < 0 ? 1u : (2u << a);
-            ++lj;
-        }
-        const bool fork = fork_g && fork_g->branch_streams && __builtin_popcount(groups) > 1;
-        if (fork) {
-            TD_HIP(hipEventRecord(fork_g->ev_fork, stream));
-            for (int a = 0; a < td_graph::kAuxStreams; ++a)
-                if (groups & (2u << a)) TD_HIP(hipStreamWaitEvent(fork_g->aux[a], fork_g->ev_fork, 0));
-        }
+        while (lj < launches.size() && launches[lj].level == launches[li].level) ++lj;
         uint64_t in_one_grid = 0;   // bit q - li: launched as a part of the level's k_sources grid
-        if (!fork) {
+        {
             long pick[4];
             const uint32_t M0 = sources_grid(li, lj, pick);
             if (M0) {
@@ -943,8 +851,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 continue;
             }
             const void* d = ar.d + L.off;
-            const int a = aux_stream_of(L.fam);
-            hipStream_t s = (fork && a >= 0) ? fork_g->aux[a] : stream;
+            hipStream_t s = stream;
             Prof pr(prof, L.fam, s);
             if (debug_sync() & 4) fprintf(stderr, "L %s n=%d M=%u bl=%u aux=%x\n", kFamilyName[L.fam], L.n, L.M, L.bl, L.aux);
             struct Crumb { hipStream_t s; ~Crumb() { if (debug_sync() & 4) { (void)hipStreamSynchronize(s); fprintf(stderr, "ok\n"); } } } crumb{s};
@@ -976,27 +883,7 @@ static int submit_chunk(Arena& ar, ChunkBuild& cb, hipStream_t stream, ProfCtx& 
                 case F_AUDIT: launch_band_audit((const AuditHead*)d, L.n, s); break;
             }
         }
-        if (fork) {
-            for (int a = 0; a < td_graph::kAuxStreams; ++a)
-                if (groups & (2u << a)) {
-                    TD_HIP(hipEventRecord(fork_g->ev_join[a], fork_g->aux[a]));
-                    TD_HIP(hipStreamWaitEvent(stream, fork_g->ev_join[a], 0));
-                }
-        }
         li = lj;
-    }
-    if (want_graph) {
-        hipGraph_t graph = nullptr;
-        capture_guard.active = false;
-        TD_HIP(hipStreamEndCapture(stream, &graph));
-        hipGraphExec_t exec = nullptr;
-        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (ie != hipSuccess) return fail(std::string("HIP error: ") + hipGetErrorString(ie) + " at hipGraphInstantiate");
-        ar.graph_exec = exec;
-        ar.graph_key.swap(gkey);
-        ar.graph_pending = ar.pending_fix;
-        TD_HIP(hipGraphLaunch(ar.graph_exec, stream));
     }
     TD_HIP(hipGetLastError());
     if (!ar.pending_fix.empty()) note_pending(ar, stream, cur_device());
@@ -1248,6 +1135,7 @@ int graph_render_chunks(td_graph* g, const td_samplebank* sb, td_flowwbank* fb, 
     if (!settle_before_render(g)) return 0;
     if (!prepare_render(g, n_blocks, bits, want_pcm, &rp)) return 0;
     g->defer_fix = !rp.multi;   // (a later chunk reads the carried max; the f32 copy of a multi-chunk render reads the frames)
+    g->batch_projects = 1;
     const bool guarded = may_be_audited(g);
     if (guarded && !guard_begin(g, sb, fb, n_blocks, is_scan, bits, advance_graph_time, scan_t0, want_pcm)) return 0;
     bool audited = false;
@@ -1327,6 +1215,7 @@ static int batch_render_range(td_batch* b, size_t lo, size_t hi, size_t n_blocks
     for (size_t i = 0; i < P; ++i) {
         td_graph* g = b->graphs[lo + i];
         g->defer_fix = allow_defer && !any_multi;
+        g->batch_projects = P;
         if (may_be_audited(g) &&
             !guard_begin(g, b->sbs[lo + i], b->fbs[lo + i], n_blocks, is_scan, bits, advance_graph_time, 0, want_pcm)) return 0;
     }
@@ -1546,7 +1435,7 @@ void td_graph_free(td_graph* g) {
             }
     }
     const bool has_device_state = g->stream || !g->pool.empty() || !g->wavetables.empty() || g->dstate || g->arena.d || g->d_pcm ||
-                                  g->d_out_f32 || g->d_resampled || g->d_scalar || g->ev_fork;
+                                  g->d_out_f32 || g->d_resampled || g->d_scalar;
     if (has_device_state && hipSetDevice(g->device) == hipSuccess) {
         if (g->stream) (void)hipStreamSynchronize(g->stream);
         else (void)hipDeviceSynchronize();   // (a graph whose stream could not be re-made after td_batch_free)
@@ -1562,12 +1451,6 @@ void td_graph_free(td_graph* g) {
         if (g->guard.d_backup) (void)hipFree(g->guard.d_backup);
         if (g->guard.h_word) (void)hipHostFree(g->guard.h_word);
         free_prof(g->prof);
-        if (g->ev_fork) (void)hipEventDestroy(g->ev_fork);
-        for (int a = 0; a < td_graph::kAuxStreams; ++a)
-            if (g->aux[a]) {
-                (void)hipEventDestroy(g->ev_join[a]);
-                (void)hipStreamDestroy(g->aux[a]);
-            }
         if (g->owns_stream && g->stream) (void)hipStreamDestroy(g->stream);
     }
     drop_pending(g->arena);   // (off the process-wide list whatever happened above: the list holds the arena's address)
@@ -2054,57 +1937,88 @@ int td_graph_band_stats(const td_graph* gc, uint32_t out[3]) {
     return 1;
 }
 
+// ---- engine options.  SEVEN supported keys (include/termdaw_amd.h); everything else an engine ever grew a switch for is either gone
+// (branch streams, HIP-graph replay, the serial-only band-pass: measured slower) or a TEST HOOK under "debug.<name>":
+// value-neutral by construction -- it selects an older or alternative form of a launch, or moves a speculation parameter whose
+// outcome is verified on the device -- and each is pinned by the test named in the header.  td_graph_get_option reads any of them.
+struct OptionRef { const char* key; int kind; void* p; };   // kind 0 bool, 1 int, 2 unsigned, 3 size_t
+static std::vector<OptionRef> option_table(td_graph* g) {
+    return {
+        {"fuse_sources", 0, &g->fuse_sources}, {"packed_samples", 0, &g->packed_samples}, {"band_mode", 1, &g->band_mode},
+        {"band_guard_ppb", 2, &g->band_guard_ppb}, {"sine_mode", 1, &g->sine_mode}, {"output_f32", 0, &g->output_f32},
+        {"max_chunk_frames", 3, &g->max_chunk_frames},
+        {"debug.norm", 1, &g->norm_debug}, {"debug.band_scan", 1, &g->band_scan_debug}, {"debug.one_grid_sources", 0, &g->one_grid_sources},
+        {"debug.inline_adsr", 0, &g->inline_adsr}, {"debug.spec_normalize", 0, &g->spec_normalize},
+        {"debug.single_pass_normalize", 0, &g->single_pass_normalize}, {"debug.fuse_normalize", 0, &g->fuse_normalize},
+        {"debug.table_cache", 0, &g->table_cache}, {"debug.band_serial", 0, &g->band_serial}, {"debug.band_chain", 0, &g->band_chain}, {"debug.band_scan_nf", 1, &g->band_scan_nf},
+        {"debug.band_quick", 2, &g->band_quick}, {"debug.band_short", 2, &g->band_short}, {"debug.band_medium", 2, &g->band_medium},
+        {"debug.band_warmup", 2, &g->band_warmup}, {"debug.band_depth", 2, &g->band_depth},
+    };
+}
 int td_graph_set_option(td_graph* g, const char* key, long value) {
     const std::string k = key ? key : "";
-    if (k == "fuse_sources") { g->fuse_sources = value != 0; return 1; }
-    if (k == "band_parallel") { g->band_parallel = value != 0; return 1; }
+    // (keys with a rule of their own first)
     if (k == "band_mode") {   // 0: exact (default, the parity mode), 1: blocked affine scan (tolerance class), 2: the scan under the guard
         if (value != 0 && value != 1 && value != 2) return fail("band_mode must be 0 (exact), 1 (scan) or 2 (guarded scan)");
         if (g->guard.armed && !drain(g)) return 0;   // (a verdict still out belongs to the mode it was rendered in)
         g->band_mode = (int)value;
         return 1;
     }
-    if (k == "band_guard_ppb") { g->band_guard_ppb = value > 0 ? (unsigned)std::min<long>(value, 1000000000L) : 0u; return 1; }
-    if (k == "band_scan_nf") {
-        if (value != 8 && value != 16) return fail("band_scan_nf must be 8 or 16");
-        g->band_scan_nf = (int)value;
-        return 1;
-    }
-    if (k == "band_scan_debug") { g->band_scan_debug = (int)value; return 1; }
-    if (k == "band_chain") { g->band_chain = value != 0; return 1; }   // scan mode: chains of band-pass vertices in one launch
-    if (k == "band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
-    if (k == "band_short") { g->band_short = value > 0 ? (unsigned)value : 64u; return 1; }
-    if (k == "band_quick") { g->band_quick = value > 0 ? (unsigned)value : 0u; return 1; }
-    if (k == "band_medium") { g->band_medium = value > 0 ? (unsigned)value : 30u; return 1; }
-    if (k == "band_guess_min") { g->band_guess_min = value > 0 ? (unsigned)value : 0u; return 1; }
-    if (k == "band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
-    if (k == "band_scan_depth") { g->band_scan_depth = value > 0 ? (unsigned)value : 64u; return 1; }
-    if (k == "band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
-    if (k == "packed_samples") { g->packed_samples = value != 0; return 1; }
-    if (k == "inline_adsr") { g->inline_adsr = value != 0; return 1; }
-    if (k == "spec_normalize") { g->spec_normalize = value != 0; return 1; }
-    if (k == "single_pass_normalize") { g->single_pass_normalize = value != 0; return 1; }
-    if (k == "norm_debug") { g->norm_debug = (int)value; return 1; }
-    if (k == "fuse_normalize") { g->fuse_normalize = value != 0; return 1; }
-    if (k == "one_grid_sources") { g->one_grid_sources = value != 0; return 1; }
-    if (k == "sine_mode") {   // 0: the tolerance-class device sine (default), 1: glibc's sinf operation for operation (kernels.hip sin_glibc)
+    if (k == "sine_mode") {   // 0: the fast device forms, 1: glibc's sinf operation for operation (kernels.hip sin_glibc), 2: the fast forms under the guard
         if (value != 0 && value != 1 && value != 2) return fail("td_graph_set_option: sine_mode is 0 (fast), 1 (glibc's sinf) or 2 (fast under the guard)");
         if (g->guard.armed && !drain(g)) return 0;   // (a verdict still out belongs to the mode it was rendered in)
         g->sine_mode = (int)value;
         for (auto& v : g->vertices)
-            if (v.kind == K_DEBUG_SINE || v.kind == K_SYNTH) v.exact_sin = value != 0;
+            if (v.kind == K_DEBUG_SINE || v.kind == K_SYNTH) v.exact_sin = value == 1;   // (compile_chunk decides per chunk in mode 2)
         return 1;
     }
-    if (k == "output_f32") { g->output_f32 = value != 0; return 1; }
-    if (k == "table_cache") { g->table_cache = value != 0; return 1; }
-    if (k == "graph_replay") { g->graph_replay = value != 0; return 1; }
-    if (k == "branch_streams") { g->branch_streams = value != 0; return 1; }
+    if (k == "band_guard_ppb") { g->band_guard_ppb = value > 0 ? (unsigned)std::min<long>(value, 1000000000L) : 0u; return 1; }
     if (k == "max_chunk_frames") {
         if (value < 1) return fail("max_chunk_frames must be >= 1");
         g->max_chunk_frames = (size_t)value;
         return 1;
     }
+    if (k == "debug.band_scan_nf") {
+        if (value != 8 && value != 16) return fail("debug.band_scan_nf must be 8 or 16");
+        g->band_scan_nf = (int)value;
+        return 1;
+    }
+    if (k == "debug.band_live_exp") { g->band_live_thr = value >= 38 ? 0.0f : powf(10.0f, -(float)value); return 1; }
+    if (k == "debug.band_short") { g->band_short = value > 0 ? (unsigned)value : 64u; return 1; }
+    if (k == "debug.band_medium") { g->band_medium = value > 0 ? (unsigned)value : 30u; return 1; }
+    if (k == "debug.band_depth") { g->band_depth = value > 0 ? (unsigned)value : 100u; return 1; }
+    if (k == "debug.band_warmup") { g->band_warmup = value > 0 ? (unsigned)value : 150u; return 1; }
+    for (const OptionRef& o : option_table(g)) {
+        if (k != o.key) continue;
+        switch (o.kind) {
+            case 0: *(bool*)o.p = value != 0; break;
+            case 1: *(int*)o.p = (int)value; break;
+            case 2: *(unsigned*)o.p = value > 0 ? (unsigned)value : 0u; break;
+            default: *(size_t*)o.p = value > 0 ? (size_t)value : 0; break;
+        }
+        return 1;
+    }
     return fail("unknown option \"" + k + "\"");
+}
+int td_graph_get_option(const td_graph* g, const char* key, long* value) {
+    const std::string k = key ? key : "";
+    for (const OptionRef& o : option_table(const_cast<td_graph*>(g))) {
+        if (k != o.key) continue;
+        switch (o.kind) {
+            case 0: *value = *(const bool*)o.p ? 1 : 0; break;
+            case 1: *value = *(const int*)o.p; break;
+            case 2: *value = (long)*(const unsigned*)o.p; break;
+            default: *value = (long)*(const size_t*)o.p; break;
+        }
+        return 1;
+    }
+    return fail("unknown option \"" + k + "\"");
+}
+// (the option keys, for tests that walk them: n-th key or NULL)
+const char* td_graph_option_key(size_t n) {
+    static td_graph dummy_for_keys;
+    static const std::vector<OptionRef> t = option_table(&dummy_for_keys);
+    return n < t.size() ? t[n].key : nullptr;
 }
 
 // ---- Batch (no reference counterpart: the reference renders one project per process; this is the loop a

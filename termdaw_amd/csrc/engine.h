@@ -203,10 +203,6 @@ struct Arena {
     bool inflight = false;
     size_t valid = 0;          // bytes of `h` that `d` currently mirrors
     size_t device_bytes = 0;
-    // HIP-graph replay (option "graph_replay"): the launch sequence of the last submission, captured; valid while the
-    // uploaded bytes (descriptors: every pointer and parameter) and the launch list are unchanged
-    hipGraphExec_t graph_exec = nullptr;
-    std::vector<uint64_t> graph_key;
     // Single-pass Normalize launches (SumDesc modes 4 / 5) whose k_norm_fix was NOT enqueued behind them (the vertex is the
     // last thing its submission computes): a tile whose bounded wait gives up sets *h_flag (page-locked host memory, d_flag =
     // its device address); settle_arena() looks at the word once the stream has drained and launches these then.
@@ -214,7 +210,6 @@ struct Arena {
     uint32_t* d_flag = nullptr;
     struct PendingFix { size_t off; int n; uint32_t M, bl; };
     std::vector<PendingFix> pending_fix;
-    std::vector<PendingFix> graph_pending;   // ... of the captured submission (graph_replay): a replay queues the same deferred fix
     size_t fix_runs = 0;       // how often that happened (td_graph_norm_fix_runs)
     // While pending_fix is non-empty the arena is on a process-wide list (engine.cpp: note_pending / unlist_arena), so that
     // whoever frees device memory such a fix would read -- a SampleBank's slabs -- can settle it first.
@@ -348,10 +343,6 @@ struct td_graph {
     // ---- device side ----
     int device = 0;
     hipStream_t stream = nullptr;
-    static constexpr int kAuxStreams = 7;      // one per independent launch family of a level (branch streams)
-    hipStream_t aux[kAuxStreams] = {};
-    hipEvent_t ev_fork = nullptr, ev_join[kAuxStreams] = {};
-    bool branch_streams = false;               // measured: cross-stream fork/join costs more than it overlaps
     bool plan_dirty = true;
     std::vector<size_t> order;                // reachable vertices, topological (inputs first)
     std::vector<int> level;                   // per vertex, -1 = unreachable
@@ -370,6 +361,7 @@ struct td_graph {
     tde::Arena arena;
     tde::ChunkBuild build;
     td_batch* batch = nullptr;                // set by td_batch_add: the graph shares the batch's stream
+    size_t batch_projects = 0;                // (set per render) projects of the submission this graph compiles into; 0 / 1: alone
     bool owns_stream = true;
     // outputs of the last render
     void* d_pcm = nullptr;
@@ -387,7 +379,6 @@ struct td_graph {
     bool packed_samples = true;                // inlined sources read the packed 16-bit sample form when it exists
     bool inline_adsr = true;                   // a one-input, one-consumer Adsr vertex is evaluated by its consumer's sum
     bool output_f32 = true;                    // 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames
-    bool graph_replay = false;                 // replay the captured launch sequence of an unchanged submission (measured: no gain)
     bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
     bool one_grid_sources = true;              // a level's source launches (affine Synth, wavetable voice, SampleLerp) and the envelope launch go out as ONE grid (k_sources)
@@ -396,14 +387,12 @@ struct td_graph {
     int norm_debug = 0;                        // (tests) bit 0: every single-pass Normalize tile gives up its wait at once -> k_norm_fix
     bool defer_fix = true;                     // (set per render) this render is one chunk: the output vertex' k_norm_fix may wait for settle()
     float band_live_thr = 1e-9f;               // energy from before the short window / energy inside it below which it is enough
-    unsigned band_guess_min = 4096;            // the guess is used where the short warm-up is at least this long (frames)
-    unsigned band_scan_depth = 64;             // band_mode 1: look-back until (1 - gamma)^(tile K) <= e^-band_scan_depth
     unsigned band_depth = 100;                 // the guess chains block responses until (1 - gamma)^(256 K) <= e^-band_depth
     unsigned band_medium = 30;                 // medium warm-up = band_medium / gamma frames (guess + an alive window)
     unsigned band_quick = 12;                  // quick warm-up = band_quick / gamma frames, taken with the block-response guess (0: no guess)
     unsigned band_short = 40;                  // short warm-up = band_short / gamma frames
     unsigned band_warmup = 150;                // long warm-up = band_warmup / gamma frames (speed only, never exactness)
-    bool band_parallel = true;                 // speculative-segment band-pass (exact); 0 = serial kernel only
+    bool band_serial = false;                  // (tests, debug.band_serial) every band-pass vertex on the serial kernel -- otherwise the fallback of cut-offs below 5 Hz and block pulls
     int sine_mode = 1;                         // 1 (a bare td_graph's default, like band_mode 0: the reference's bytes): debug_sine / synth evaluate glibc's sinf operation for operation and adsr.rs's own divisions; 0: the device sine of the tolerance class (<= 3.3e-7 from sinf) and the affine / one-grid Synth forms, unguarded; 2 (the front-end's default): the fast forms under the guard -- k_sine_probe measures their deviation at the vertex, the audit carries it to the output, over the bound the render is done again in mode 1's form
     int band_mode = 0;                         // 0: exact (bit-identical to the reference's serial loop), 1: blocked affine scan
                                                //    (tolerance class, <= 1e-6 RMS; one launch per band-pass vertex),

@@ -14,7 +14,7 @@ namespace tdk {
 constexpr int kThreads = 256;       // 4 wave64 per workgroup
 constexpr int kTileFrames = 1024;
 constexpr uint32_t kBandMaxSegs = 131072;   // k_band_fix keeps its mismatch bitmap in LDS
-constexpr uint32_t kBandMaxS = 1024;        // ... and stages one segment of input / output there   // frames per workgroup tile: 2 x float4 (2 frames each) per thread
+constexpr uint32_t kBandMaxS = 1024;        // ... so chunks beyond 33 M frames take longer segments (any multiple of 256 works: compile.cpp plan_band picks longer ones for batches)   // frames per workgroup tile: 2 x float4 (2 frames each) per thread
 
 // Vertex epilogue: Sample::apply_angle then Sample::apply_gain (sample.rs:97-114, order fixed at
 // extensions.rs:262-263).  Amplitudes are computed on the host with libm; flags carry the skip

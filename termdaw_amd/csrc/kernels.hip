@@ -2344,7 +2344,9 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     // Every lane of the wave walks the same number of steps -- the longest warm-up any of its quads picked (a
     // longer warm-up than needed never hurts) -- over its OWN window [start - w, start).  Quads whose window is
     // cut short by the chunk start begin at frame 0 with the exact state and simply finish earlier.
-    uint32_t w_wave = my_w;
+    // (a quad whose window the chunk start cuts short asks for no more than the frames it has: with segments of several
+    // thousand frames the first wave's early quads would otherwise send its later ones all the way back to frame 0)
+    uint32_t w_wave = min(my_w, start);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) w_wave = max(w_wave, (uint32_t)__shfl_xor((int)w_wave, off, 64));
     const uint32_t my_begin = start > w_wave ? start - w_wave : 0u;
@@ -2425,7 +2427,17 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     constexpr uint32_t kQStride = 132;   // floats per quad slot: 32 frames x 4 states + 4 pad
     __shared__ __attribute__((aligned(16))) float ys_l[(kThreads / 4) * kQStride];
     __shared__ float2 xf_l[kThreads / 4];
-    if (__all((start + d.S <= M) ? 1 : 0) != 0) {
+    // Every quad takes its whole 32-frame pieces this way -- the chunk's last segment too, which is rarely a whole one (round 6:
+    // it used to send its whole wave through the per-step form below, ~150 ns a frame: unnoticed behind a 256-frame segment's
+    // warm-up, the longest thing in the launch behind a 4 096-frame one).  The wave runs as many pieces as its longest quad has;
+    // a quad with fewer keeps stepping on clamped loads and stores nothing, its state is taken where its own pieces end.
+    const uint32_t whole_q = (end - start) & ~31u;   // (quad-uniform; quads past the last segment mirror it)
+    uint32_t len_w = whole_q;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) len_w = max(len_w, (uint32_t)__shfl_xor((int)len_w, off, 64));
+    bool same = true, zero = true;
+    uint32_t n_done = 0u;                            // frames of this quad's segment the piece form has covered
+    if (len_w != 0u) {
         const uint32_t quad = threadIdx.x >> 2, lane = threadIdx.x & 63u, wq0 = (threadIdx.x >> 6) * 16u;
         float* myq = ys_l + quad * kQStride + c;
         const float xr_first = quad_bcast<1>(x_first);
@@ -2462,20 +2474,24 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         const PanGain pg = d.pg;
         const uint32_t S = d.S;
         uint32_t m0_[8];          // frame of slot i at p = 0 (quads past the end mirror the last segment)
+        uint32_t slot_end[8];     // one past the last frame slot i's segment takes this way (0: a quad past the last segment)
         const float* ys_rd[8];    // the slot's four states in the wave's LDS staging
         float2 xo[8], x0r[8];
-        uint32_t live_slots = 0u, not_same = 0u, not_zero = 0u;   // bit i: slot i
+        uint32_t not_same = 0u, not_zero = 0u;   // bit i: slot i
 #pragma unroll
         for (uint32_t i = 0; i < 8u; ++i) {
             const uint32_t idx = i * 64u + lane, sq = idx >> 5, j = idx & 31u, sraw = wave_seg0 + sq;
-            m0_[i] = min(sraw, d.nseg - 1u) * S + j;
+            const uint32_t s0_ = min(sraw, d.nseg - 1u) * S;
+            m0_[i] = s0_ + j;
+            slot_end[i] = sraw < d.nseg ? s0_ + ((min(s0_ + S, M) - s0_) & ~31u) : 0u;
             ys_rd[i] = ys_l + (wq0 + sq) * kQStride + j * 4u;
-            live_slots |= (sraw < d.nseg ? 1u : 0u) << i;
-            xo[i] = gload2(x_in + m0_[i]);
+            xo[i] = gload2(x_in + min(m0_[i], M - 1u));
         }
-        for (uint32_t p = 0; p < S; p += 32u) {
+        float y_cap = y;
+        for (uint32_t p = 0; p < len_w; p += 32u) {
             TD_BAND_STEP8W(a0, 0) TD_BAND_STEP8W(a1, 8) TD_BAND_STEP8W(a2, 16) TD_BAND_STEP8W(a3, 24)
-            if (p + 32u < S) {   // the next 32 frames' input flies during (b)
+            if (p + 32u == whole_q) y_cap = y;   // (this quad's own pieces end here)
+            if (p + 32u < len_w) {   // the next 32 frames' input flies during (b)
                 a0 = fetchq(start + p + 32u); a1 = fetchq(start + p + 40u);
                 a2 = fetchq(start + p + 48u); a3 = fetchq(start + p + 56u);
             }
@@ -2484,15 +2500,17 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint32_t m = m0_[i] + p;
                 const float2 x = xo[i];
-                if (p + 32u < S) xo[i] = gload2(x_in + m + 32u);
+                if (p + 32u < len_w) xo[i] = gload2(x_in + min(m + 32u, M - 1u));
                 const float4 s = *reinterpret_cast<const float4*>(ys_rd[i]);
                 if (p == 0u) x0r[i] = xf_l[wq0 + ((i * 64u + lane) >> 5)];
                 const float2 x0 = x0r[i];
                 const bool sm = __float_as_uint(x.x) == __float_as_uint(x0.x) && __float_as_uint(x.y) == __float_as_uint(x0.y);
                 const bool zr = x.x == 0.0f && x.y == 0.0f;
-                not_same |= (sm ? 0u : 1u) << i;
-                not_zero |= (zr ? 0u : 1u) << i;
-                if ((live_slots >> i) & 1u) gstore2(out_p + m, epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), pg));
+                if (m < slot_end[i]) {
+                    not_same |= (sm ? 0u : 1u) << i;
+                    not_zero |= (zr ? 0u : 1u) << i;
+                    gstore2(out_p + m, epilogue(band_out(kf, x.x, x.y, s.x, s.y, s.z, s.w), pg));
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         }
@@ -2506,15 +2524,13 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
             if ((uint32_t)bz != 0u) zero_mask &= ~(1u << (2u * i));
             if ((uint32_t)(bz >> 32) != 0u) zero_mask &= ~(2u << (2u * i));
         }
-        if (live) d.seg_final[seg * 4u + c] = y;
-        if (c == 0u && live) {
-            const uint32_t q = quad & 15u;
-            d.seg_flags[seg] = ((same_mask >> q) & 1u) | (((zero_mask >> q) & 1u) << 1);
-            d.seg_x0[seg] = make_float2(x_first, xr_first);
-        }
-        return;
+        y = y_cap;
+        n_done = whole_q;
+        const uint32_t q = quad & 15u;
+        same = ((same_mask >> q) & 1u) != 0u;    // (so far: the frames below go on from here, per channel)
+        zero = ((zero_mask >> q) & 1u) != 0u;
     }
-    bool same = true, zero = true;
+    // ... and what is left of the segment -- fewer than 32 frames, or all of it in a chunk of a few frames -- step by step
     auto step = [&](uint32_t m, float l, float r) {
         if (m >= end) return;
         const float x = ch ? r : l;
@@ -2524,9 +2540,12 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         const float2 o = band_out(kf, l, r, quad_bcast<0>(y), quad_bcast<1>(y), quad_bcast<2>(y), quad_bcast<3>(y));
         if (c == 0u && live) gstore2(d.out + m, epilogue(o, d.pg));
     };
-    if ((start & 7u) == 0u) {
-        float4 a = fetch8(start);
-        for (n = start; n < end; n += 8u) {
+    const uint32_t n0 = start + n_done;
+    if (n0 >= end) {
+        // (nothing left)
+    } else if ((n0 & 7u) == 0u) {
+        float4 a = fetch8(n0);
+        for (n = n0; n < end; n += 8u) {
             const float4 nx = fetch8(n + 8u);
             const float l0 = quad_bcast<0>(a.x), r0 = quad_bcast<0>(a.y), l1 = quad_bcast<0>(a.z), r1 = quad_bcast<0>(a.w);
             const float l2 = quad_bcast<1>(a.x), r2 = quad_bcast<1>(a.y), l3 = quad_bcast<1>(a.z), r3 = quad_bcast<1>(a.w);
@@ -2537,7 +2556,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
             a = nx;
         }
     } else {
-        for (n = start; n < end; ++n) { const float2 x = d.x[n]; step(n, x.x, x.y); }
+        for (n = n0; n < end; ++n) { const float2 x = d.x[n]; step(n, x.x, x.y); }
     }
     if (live) d.seg_final[seg * 4u + c] = y;
     const float s0 = quad_bcast<0>(same ? 1.0f : 0.0f), s1 = quad_bcast<1>(same ? 1.0f : 0.0f);

@@ -17,8 +17,8 @@ pytestmark = pytest.mark.gpu
 def _scan_build(p, api, **opts):
     built = p.build(api)
     built[2].set_option("band_mode", 1)
-    for k, v in opts.items():
-        built[2].set_option(k, v)
+    for k, v in opts.items():   # (keyword names other than the supported options stand for the header's "debug." test hooks)
+        built[2].set_option(k if k in ("max_chunk_frames", "band_guard_ppb", "output_f32") else "debug." + k, v)
     return built
 
 
@@ -62,7 +62,7 @@ def test_recomputed_predecessors_give_the_same_bits(gpu_api, nf):
     published values give."""
     p = _gappy_project(20.0, 9000.0, True, seconds=3.0)
     normal = p.render(gpu_api, built=_scan_build(p, gpu_api, band_scan_nf=nf))
-    forced = p.render(gpu_api, built=_scan_build(p, gpu_api, band_scan_nf=nf, band_scan_debug=1))
+    forced = p.render(gpu_api, built=_scan_build(p, gpu_api, band_scan_nf=nf, band_scan=1))
     assert np.array_equal(_bits(normal[1]), _bits(forced[1]))
     assert np.array_equal(normal[0], forced[0])
 

@@ -98,7 +98,7 @@ def test_config2_120s_grid_beyond_the_resident_capacity(gpu_api, oracle, debug):
     sb, fb, g = p.build(gpu_api)
     for k, v in BENCH_OPTS.items():
         g.set_option(k, v)
-    g.set_option("norm_debug", debug)
+    g.set_option("debug.norm", debug)
     osb, ofb, og = p.build(oracle)
     for rep in range(2):
         fb.set_time(0)
@@ -124,7 +124,7 @@ def test_forced_give_up_in_the_resident_grid_forms(gpu_api, oracle, shape):
     else:
         p = W.config1(seconds=0.2)
     sb, fb, g = p.build(gpu_api)
-    g.set_option("norm_debug", 1)
+    g.set_option("debug.norm", 1)
     osb, ofb, og = p.build(oracle)
     if shape == "one_block":
         for _ in range(p.cs):
@@ -141,7 +141,7 @@ def test_forced_give_up_in_the_resident_grid_forms(gpu_api, oracle, shape):
         assert g.get_normalization_value("sum") == og.get_normalization_value("sum")
     assert g.norm_fix_runs() >= 2
     # pipelined: two fresh renders queued back to back, results read afterwards -- the second's fix is the one that counts
-    g.set_option("norm_debug", 1)
+    g.set_option("debug.norm", 1)
     for _ in range(2):
         g.reset_normalize_vertices()
         fb.set_time(0)
@@ -174,22 +174,6 @@ def test_bench_one_rank_over_rccl():
     assert out["ranks"]["n"] == 1 and out["ranks"]["exchange_ms"] >= 0.0 and out["ranks"]["start_skew_us"] == 0.0
 
 
-def test_forced_give_up_under_graph_replay(gpu_api, oracle):
-    """Engine option graph_replay 1 replays the captured launches of an unchanged submission; the deferred check launch of a
-    single-pass Normalize is not part of that capture -- it must still run when the replayed launch gives up."""
-    p = W.config1(seconds=3.0)
-    sb, fb, g = p.build(gpu_api)
-    g.set_option("graph_replay", 1)
-    g.set_option("norm_debug", 1)
-    osb, ofb, og = p.build(oracle)
-    ref = og.render_all(osb, ofb, p.cs, 16)
-    for rep in range(4):   # (the first submission captures, the later ones replay)
-        g.reset_normalize_vertices()
-        fb.set_time(0)
-        assert_bit_exact(g.render_all(sb, fb, p.cs, 16), ref)
-    assert g.norm_fix_runs() >= 4
-
-
 def test_handles_freed_with_a_deferred_check_pending(gpu_api):
     """A render whose deferred check launch is still pending (forced give-up, no sync yet) followed by freeing the graph --
     alone and as a member of a batch -- settles first: no launch on freed state, no crash, the survivors still render."""
@@ -197,7 +181,7 @@ def test_handles_freed_with_a_deferred_check_pending(gpu_api):
     for in_batch in (False, True):
         built = [p.build(gpu_api) for _ in range(2)]
         for sb, fb, g in built:
-            g.set_option("norm_debug", 1)
+            g.set_option("debug.norm", 1)
         batch = None
         if in_batch:
             batch = gpu_api.Batch()
@@ -231,7 +215,7 @@ def test_a_bank_freed_before_the_deferred_check_has_run(gpu_api):
     got = []
     for free_early in (True, False):
         sb, fb, g = p.build(gpu_api)
-        g.set_option("norm_debug", 1)
+        g.set_option("debug.norm", 1)
         g.render_all_async(sb, fb, p.cs, 16)
         if free_early:
             del sb
@@ -253,7 +237,7 @@ def test_a_member_rendered_on_its_own_then_the_batch_is_freed(gpu_api, oracle):
     built = [p.build(gpu_api) for _ in range(2)]
     batch = gpu_api.Batch()
     for b in built:
-        b[2].set_option("norm_debug", 1)
+        b[2].set_option("debug.norm", 1)
         batch.add(*b)
     sb, fb, g = built[0]
     g.render_all_async(sb, fb, p.cs, 16)
@@ -305,10 +289,6 @@ def test_tile_words_carry_the_submissions_epoch(gpu_api, oracle):
     for _ in range(2):
         both()
     g.set_option("max_chunk_frames", 1 << 24)
-    g.set_option("graph_replay", 1)
-    for _ in range(3):
-        both()
-    g.set_option("graph_replay", 0)
     for _ in range(3):
         both()
     assert g.norm_fix_runs() == 0

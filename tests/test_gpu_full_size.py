@@ -133,7 +133,7 @@ def test_low_cutoff_band_pass_with_block_response_guess(gpu_api, oracle, lo, hi,
         assert_bit_exact(p.render(gpu_api, built=built), p.render(oracle, built=obuilt))
     # the same with the guess switched off: same bytes
     b2 = p.build(gpu_api)
-    b2[2].set_option("band_quick", 0)
+    b2[2].set_option("debug.band_quick", 0)
     assert_bit_exact(p.render(gpu_api, built=b2), p.render(oracle))
 
 

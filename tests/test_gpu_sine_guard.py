@@ -169,7 +169,7 @@ def test_a_batch_settles_every_projects_verdict(gpu_api, oracle):
     """td_batch_*: projects probed in one merged k_sine_probe launch; the one forced over the bound is done again alone."""
     import ctypes as C
     P = 3
-    projects = [W.synth_project(seconds=1.0 + 0.0 * i) for i in range(P)]
+    projects = [W.config3(seconds=1.0) for i in range(P)]      # (estimate ~8e-8: under the bound unless forced)
     refs = [q.render(oracle)[0] for q in projects]
     batch = gpu_api.Batch()
     graphs = []

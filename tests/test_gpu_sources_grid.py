@@ -29,8 +29,8 @@ def _render(api, p, opts, cs=None):
     (lambda: W.config4(seconds=3.0, depth=30), 3, {"k_sampsyn", "k_sample_lerp", "k_adsr_env"}),
 ])
 def test_one_grid_is_the_separate_launches_bit_for_bit(gpu_api, mk, parts, gone, band_mode):
-    (a0, a1), fam_a = _render(gpu_api, mk(), {"band_mode": band_mode, "one_grid_sources": 1})
-    (b0, b1), fam_b = _render(gpu_api, mk(), {"band_mode": band_mode, "one_grid_sources": 0})
+    (a0, a1), fam_a = _render(gpu_api, mk(), {"band_mode": band_mode, "debug.one_grid_sources": 1})
+    (b0, b1), fam_b = _render(gpu_api, mk(), {"band_mode": band_mode, "debug.one_grid_sources": 0})
     for x, y in ((a0, b0), (a1, b1)):
         assert np.array_equal(x[0], y[0]) and np.array_equal(_bits(x[1]), _bits(y[1]))
     assert fam_a["k_sources"][1] == 2 and not (gone & set(fam_a)), fam_a        # one launch per render instead of `parts`

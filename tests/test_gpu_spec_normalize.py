@@ -24,8 +24,8 @@ def test_scanned_render_takes_the_single_pass(gpu_api, oracle, spec, single):
     p = W.config2(seconds=2.0)
     sb, fb, g = p.build(gpu_api)
     osb, ofb, og = p.build(oracle)
-    g.set_option("spec_normalize", spec)
-    g.set_option("single_pass_normalize", single)
+    g.set_option("debug.spec_normalize", spec)
+    g.set_option("debug.single_pass_normalize", single)
     fresh_two_pass = not (spec and single)
     got, fam = _families(g, lambda: g.render_all(sb, fb, p.cs, 16))
     # un-scanned: the running peak -- in ONE launch (k_norm1 / k_sum16w mode 5: the grid is resident at once, the tiles hand
@@ -138,7 +138,7 @@ def test_fresh_single_pass_normalize_is_value_identical(gpu_api, oracle, project
         p.connect("inner", "out")
         p.set_output("out")
     gb, ob = p.build(gpu_api), p.build(oracle)
-    gb[2].set_option("single_pass_normalize", single)
+    gb[2].set_option("debug.single_pass_normalize", single)
     if project == "config2_edge":
         gb[2].set_option("fuse_sources", 0)
     for rep in range(2):

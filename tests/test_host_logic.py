@@ -262,3 +262,34 @@ def test_headline_block_is_the_generated_one():
     want = h.block()
     for name in ("README.md", "DESIGN.md"):
         assert h.current(os.path.join(ROOT, name)) == want, name
+
+
+def test_the_two_default_sets_differ_in_two_keys(api):
+    """include/termdaw_amd.h: seven supported engine options; a bare td_graph (what a Rust host binds: the reference's bytes) and a
+    State's graph (the front-end: the stated tolerance, checked per render) differ in exactly band_mode (0 | 2) and sine_mode
+    (1 | 2) -- every other key, the test hooks under "debug." included, has ONE default."""
+    import ctypes as C
+    keys = []
+    while True:
+        k = api.lib().td_graph_option_key(len(keys))
+        if not k:
+            break
+        keys.append(k.decode())
+    public = [k for k in keys if not k.startswith("debug.")]
+    assert sorted(public) == sorted(["fuse_sources", "packed_samples", "band_mode", "band_guard_ppb", "sine_mode", "output_f32", "max_chunk_frames"])
+    assert len(keys) <= 32 and len(set(keys)) == len(keys)
+    g = api.Graph(1024, 48000)
+    s = api.State("", 48000, 1024)
+    sg = api.Graph.__new__(api.Graph)
+    sg.h = api.lib().td_state_graph(s.h)
+    diff = {}
+    for k in keys:
+        a, b = g.get_option(k), api.Graph.get_option(sg, k)
+        if a != b:
+            diff[k] = (a, b)
+    sg.h = None   # (the State owns it)
+    assert diff == {"band_mode": (0, 2), "sine_mode": (1, 2)}, diff
+    with pytest.raises(api.TermdawError):
+        g.set_option("branch_streams", 1)      # gone in round 6
+    with pytest.raises(api.TermdawError):
+        g.get_option("no_such_key")

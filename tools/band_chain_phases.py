@@ -32,7 +32,7 @@ if __name__ == "__main__":
         return g.render_all(sb, fb, p.cs, 16)
     for _ in range(3):
         render()
-    g.set_option("band_scan_debug", 4)
+    g.set_option("debug.band_scan", 4)
     pcm, f = render()
     st = np.ascontiguousarray(f).view(np.uint64).reshape(-1)          # one u64 per frame
     WT = 1024

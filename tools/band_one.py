@@ -11,8 +11,8 @@ p.add_sampleloop("l", 0.5, 0.0, "a")
 p.add_bandpass("bp", 1.0, 0.0, 1.0, 20.0, 18000.0, True)
 p.add_normalize("out", 1.0, 0.0)
 p.connect("l", "bp"); p.connect("bp", "out"); p.set_output("out")
-for opts in ({"band_quick": 0, "band_short": 40}, {"band_quick": 16}, {"band_quick": 12}, {"band_quick": 10}, {"band_quick": 8},
-             {"band_quick": 1, "band_medium": 1}):   # (the last one: hardly any warm-up walk -- what the launch costs besides it)
+for opts in ({"debug.band_quick": 0, "debug.band_short": 40}, {"debug.band_quick": 16}, {"debug.band_quick": 12}, {"debug.band_quick": 10}, {"debug.band_quick": 8},
+             {"debug.band_quick": 1, "debug.band_medium": 1}):   # (the last one: hardly any warm-up walk -- what the launch costs besides it)
     sb, fb, g = p.build(api)
     for k, v in opts.items(): g.set_option(k, v)
     g.render_all(sb, fb, p.cs, 16, want_f32=False, want_pcm=False)

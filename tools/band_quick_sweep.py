@@ -6,8 +6,8 @@ from termdaw_amd import api, workloads as W
 
 def run(p, quick, reps=3, depth=100):
     sb, fb, g = p.build(api)
-    g.set_option("band_quick", quick)
-    g.set_option("band_depth", depth)
+    g.set_option("debug.band_quick", quick)
+    g.set_option("debug.band_depth", depth)
     def render():
         g.reset_normalize_vertices(); fb.set_time(0); g.set_time(0)
         g.render_all_async(sb, fb, p.cs, 16)

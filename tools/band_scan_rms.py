@@ -16,7 +16,7 @@ if __name__ == "__main__":
         p = mk()
         ref = p.render(oracle)
         out = []
-        for opts in ({"band_mode": 1}, {"band_mode": 1, "band_chain": 0}, {"band_mode": 1, "band_scan_nf": 8}):
+        for opts in ({"band_mode": 1}, {"band_mode": 1, "debug.band_chain": 0}, {"band_mode": 1, "debug.band_scan_nf": 8}):
             b = p.build(api)
             for k, v in opts.items():
                 b[2].set_option(k, v)

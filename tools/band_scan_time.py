@@ -51,4 +51,4 @@ if __name__ == "__main__":
             for nf in (16, 8):
                 for dbg in (0, 2):
                     run("%s %g-%g nf%d dbg%d" % (kind, lo, hi, nf, dbg), project(kind, lo, hi),
-                        {"band_mode": 1, "fuse_sources": 0, "band_scan_nf": nf, "band_scan_debug": dbg})
+                        {"band_mode": 1, "fuse_sources": 0, "debug.band_scan_nf": nf, "debug.band_scan": dbg})

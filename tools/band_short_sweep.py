@@ -6,7 +6,7 @@ from termdaw_amd import api, workloads as W
 for name, p in (("config4", W.config4()), ("config3", W.config3()), ("drum60", W.drum_project(seconds=60.0)), ("synth60", W.synth_project(seconds=60.0))):
     for x in (40, 32, 28, 24, 20, 17):
         sb, fb, g = p.build(api)
-        g.set_option("band_short", x)
+        g.set_option("debug.band_short", x)
         g.render_all(sb, fb, p.cs, 16, want_f32=False, want_pcm=False)
         t0 = time.perf_counter()
         for _ in range(3):

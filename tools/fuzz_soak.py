@@ -64,7 +64,7 @@ for seed in range(lo_seed, hi_seed):
         gb[2].set_option("sine_mode", 2)   # (the front-end's default since round 6: the fast sine kinds under the guard too)
     if exact_sine:
         gb[2].set_option("sine_mode", 1)
-    for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=norm_debug=1
+    for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=debug.norm=1
         gb[2].set_option(kv.split("=")[0], int(kv.split("=")[1]))
     for ki, scan in enumerate((False, True, False)):
         gp, gf = p.render(api, built=gb, scan=scan)

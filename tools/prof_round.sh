@@ -35,7 +35,7 @@ for c in c3 c4; do
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}guard_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
 done
 # ... and with every source family launched on its own (engine option one_grid_sources 0): k_synth / k_sampsyn / k_adsr_env by themselves
-export TD_OPTS=one_grid_sources=0
+export TD_OPTS=debug.one_grid_sources=0
 for c in c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}sep -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}sep.log 2>&1
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}sep_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1

@@ -6,7 +6,7 @@ from termdaw_amd import api, workloads as W
 
 def run(name, p, reps=None):
     sb, fb, g = p.build(api)
-    for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=band_mode=1,band_scan_nf=8
+    for kv in filter(None, os.environ.get("TD_OPTS", "").split(",")):   # e.g. TD_OPTS=band_mode=1,debug.band_scan_nf=8
         k, v = kv.split("=")
         g.set_option(k, int(v))
     def render():
