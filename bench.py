@@ -49,8 +49,8 @@ SECONDS = 60.0
 N_SRC = 64
 PROF_EVERY = 8
 PREWARM_S = 0.25           # untimed, before the W warm-up steps: steady device clocks (see time_batch)
-PROFILE_TAG = "r05"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
-PROFILE_TAG_PREV = "r04"   # ... or, until this round's passes are committed, the previous round's (the entry says which file)
+PROFILE_TAG = "r06"        # profiles/<tag>_*: the rocprofv3 passes `traffic_profiled` / `valu_profiled` come from
+PROFILE_TAG_PREV = "r05"   # ... or, until this round's passes are committed, the previous round's (the entry says which file)
 
 
 def algorithmic_bytes_per_frame(k, fused, packed):
@@ -414,6 +414,8 @@ def other_configs(api, workloads, ub, chain_ns):
         opts = {} if mode is None else {"band_mode": {"scan": 1, "guard": 2}.get(mode, 0)}
         if mode == "exact+sine":   # what a bare td_graph does when nothing is set: every kind the reference's bytes (glibc's sinf on the device)
             opts["sine_mode"] = 1
+        if mode == "guard":        # the front-end's two defaults: the scan AND the fast sine kinds under the guard (k_sine_probe in the render)
+            opts["sine_mode"] = 2
         ms, kernels, hosts, built = time_project(p, api, opts, reps)
         g = built[2]
         dom = kernels[0]
@@ -433,8 +435,9 @@ def other_configs(api, workloads, ub, chain_ns):
                                        "exact+sine: the exact band-pass kernels AND engine option sine_mode 1 -- the oscillators evaluate glibc's sinf operation "
                                        "for operation (kernels.hip sin_glibc): the whole render bit for bit the oracle's (tests/test_gpu_sine_exact.py); "
                                        "what a bare td_graph does with nothing set" if mode == "exact+sine" else
-                                       "guard: the scan kernels under the guard (band_mode 2, the front-end's default): every render estimates its own "
-                                       "deviation and is redone with the exact kernels when over 2e-7 RMS (tests/test_gpu_band_guard.py)" if mode == "guard" else
+                                       "guard: the front-end's defaults -- the scan kernels (band_mode 2) and the fast sine kinds (sine_mode 2) under the guard: every "
+                                       "render estimates / measures its own deviation and is redone with the exact kernels and glibc's sinf when over 2e-7 RMS "
+                                       "(tests/test_gpu_band_guard.py, tests/test_gpu_sine_guard.py)" if mode == "guard" else
                                        "scan: blocked affine scan (k_band_scan / k_band_chain), tolerance class: <= 1e-6 RMS and +-1 LSB against the "
                                        "oracle (tests/test_gpu_band_scan.py; measured RMS per chain depth: profiles/%s_scan_rms.txt)" % PROFILE_TAG)
         vkey = name if mode in (None, "exact") else name + "_scan"   # (the guarded launches are priced with the scan entry's counters)
@@ -648,22 +651,22 @@ def compact(o):
         rr = {"bound": r.get("bound"), "kernel": r.get("rocprof_kernel"), "avg_ms": r.get("avg_ms"), "achieved": r.get("achieved"),
               "peak": r.get("peak"), "unit": r.get("unit"), "frac": r.get("frac"), "traffic": r.get("traffic")}
         tp = r.get("traffic_profiled") or {}
-        if tp:
-            rr["traffic_profiled"] = {"bytes": tp.get("bytes_per_launch"), "l2_hit": tp.get("l2_hit_rate"), "avg_us_rocprof": tp.get("avg_us_rocprof"),
-                                      "file": tp.get("profile")}
-        for k in ("bytes_per_frame", "ceiling_ms", "frac_of_ubench_ceiling", "ubench_ceiling_GBs", "hbm_compulsory_bytes", "hbm_compulsory_frac",
+        if tp:   # (flat: the driver's parser keeps the scalars of this object)
+            rr["traffic_avg_us_rocprof"] = tp.get("avg_us_rocprof")
+        for k in ("bytes_per_frame", "frac_of_ubench_ceiling", "ubench_ceiling_GBs", "hbm_compulsory_bytes", "hbm_compulsory_frac",
                   "wasted_vs_compulsory", "traffic_source", "l2_hit_profiled", "frac_l2_stream", "peak_l2_stream_GBs", "frac_gather_rows",
                   "peak_gather_rows_GBs", "valu_issue_ms", "frac_valu_issue",
-                  "frac_of_l2_peak", "frac_of_measured_copy", "measured_copy_GBs", "copy_GBs", "cold_tables"):
+                  "frac_of_measured_copy", "measured_copy_GBs"):
             if k in r:
                 rr[k] = r[k]
+        cg = r.get("copy_GBs") or {}
+        if cg:
+            rr["copy_own_kernel_GBs"], rr["copy_torch_GBs"] = cg.get("own_float4_kernel"), cg.get("torch_copy_")
         ct = r.get("cold_tables") or {}
         if "ms_per_render" in ct:   # (flat: a consumer that keeps only the scalars of this object keeps these)
             rr["cold_ms_per_render"] = ct["ms_per_render"]
             rr["cold_projects"] = ct.get("projects")
             rr["warm_ms_per_render"] = ct.get("warm_ms_per_render")
-        if "l2_mall_split" in r:
-            rr["l2_mall_split"] = {"floor_ms": r["l2_mall_split"]["floor_ms"], "l2_hit": r["l2_mall_split"]["l2_hit_rate_profiled"]}
         rr["note"] = NOTES + "#roofline"
         c["roofline"] = rr
     if "cpu_baseline" in o:
@@ -1007,7 +1010,7 @@ def main():
                     roofline["frac_valu_issue"] = round(roofline["valu_issue_ms"] / dom["avg_ms"], 4)
             if dom.get("traffic") and dom.get("hbm_compulsory_bytes"):
                 roofline["wasted_vs_compulsory"] = round(dom["traffic"] / dom["hbm_compulsory_bytes"], 2)
-                roofline["traffic_source"] = "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 half-count] + WRITE_SIZE, per launch)" % tp_tag
+                roofline["traffic_source"] = "profiles/%s_pmc_summary.json" % tp_tag   # (rocprofv3 --pmc FETCH_SIZE x 2 [gfx950 half-count] + WRITE_SIZE, per launch: NOTES.md#roofline)
             if fused and packed and dom["kernel"] == "k_sum":
                 # two hardware-denominated readings beside the measured ceiling (guide figures only, no ubench):
                 #  frac_of_l2_peak: the gathered + written bytes against the aggregate L2 bandwidth;
@@ -1037,7 +1040,7 @@ def main():
                     roofline["frac_l2_stream"] = round(stream_floor_ms / dom["avg_ms"], 4)
                     roofline["peak_l2_stream_GBs"] = round(gathered / (stream_floor_ms * 1e-3) / 1e9, 1)
                     roofline["l2_hit_profiled"] = hit
-                    roofline["bound"] = "l2 stream + infinity-cache (hits at 34.5 TB/s, misses at 8.6 TB/s)"
+                    roofline["bound"] = "l2 stream + infinity cache"   # (hits at 34.5 TB/s, misses at 8.6 TB/s: NOTES.md#roofline)
                     roofline["peak"] = roofline["peak_l2_stream_GBs"]
                     roofline["frac"] = roofline["frac_l2_stream"]
                 else:

@@ -216,7 +216,7 @@ def test_bench_line_compact_form_fits_the_drivers_tail():
     compacts to well under the 6 KB the driver's stored tail holds, with the derived-mode entries ahead of `configs`."""
     import json
     import bench
-    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_full.json")))
+    full = json.load(open(os.path.join(ROOT, "profiles", "r06_bench_full.json")))
     full["config"]["normalize_id"] = "one launch"
     full["config"]["parallelism_id"] = "project p on rank p mod N; one RCCL all-reduce(max) of the 1-entry peak table"
     c = bench.compact(full)
@@ -227,7 +227,7 @@ def test_bench_line_compact_form_fits_the_drivers_tail():
         assert k in c, k
     # (`bound` names what `peak` is: "hbm" / "mfma", or the cache level whose gather rate it is for a launch the caches serve)
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(c["roofline"])
-    assert c["roofline"]["bound"] in ("hbm", "mfma") or "gather" in c["roofline"]["bound"]
+    assert c["roofline"]["bound"] in ("hbm", "mfma") or "gather" in c["roofline"]["bound"] or "l2 stream" in c["roofline"]["bound"]
     assert "model" not in c["config"] and "workload" in c["config"]
     keys = list(c)
     assert keys.index("edge_buffer_mode") < keys.index("configs") and keys.index("config5") < keys.index("configs")
@@ -252,13 +252,13 @@ def test_the_complete_rust_binding_follows_the_header():
 
 def test_headline_block_is_the_generated_one():
     """README.md and DESIGN.md quote ONE end-of-round headline: the block tools/headline.py makes of the committed driver-form
-    bench line (profiles/r05_bench_k20.json).  A hand-edited or stale figure fails here."""
+    bench line (profiles/r06_bench_k20.json).  A hand-edited or stale figure fails here."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("headline", os.path.join(ROOT, "tools", "headline.py"))
     h = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(h)
     if not os.path.exists(h.SRC):
-        pytest.skip("no committed r05 driver-form bench line yet")
+        pytest.skip("no committed r06 driver-form bench line yet")
     want = h.block()
     for name in ("README.md", "DESIGN.md"):
         assert h.current(os.path.join(ROOT, name)) == want, name

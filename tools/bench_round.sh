@@ -1,6 +1,6 @@
 #!/bin/bash
 # The round's bench lines (GPU box): bash tools/bench_round.sh <tag>  ->  gpurun_out/<tag>_bench{_k20,,_full,_nofuse,_batch64}.json
-T=${1:-r05}
+T=${1:-r06}
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_k20.json 2> gpurun_out/${T}_b1.err
 python bench.py > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_b2.err
 python bench.py --full --steps 200 --warmup 20 > gpurun_out/${T}_bench_full.json 2> gpurun_out/${T}_b3.err

@@ -3,7 +3,7 @@
 #   gpurun_out/pmc_<tag>_<mode>_*/  separate --pmc passes: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum | VALU counters
 #   gpurun_out/pmc_<tag>_c3_VALU, _c4_VALU   the same VALU pass for configs 3 and 4 (tools/time_configs.py); ..scan: band_mode 1; ..sep: one_grid_sources 0
 # then tools/pmc_summary.py <tag> writes profiles/<tag>_pmc_summary.json and profiles/<tag>_valu.json.
-TAG=${1:-r03}
+TAG=${1:-r06}
 R=/root/repo
 cd /tmp && export TMPDIR=/tmp
 B="--no-cpu-baseline --no-extras"
@@ -28,8 +28,8 @@ for c in c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}scan -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}scan.log 2>&1
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}scan_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
 done
-# ... under the guard (band_mode 2, the front-end's default: k_band_chain<.., true>, the verdict in the launch)
-export TD_OPTS=band_mode=2
+# ... under the guard (band_mode 2 + sine_mode 2, the front-end's defaults: k_band_chain<.., true>, k_sine_probe, the verdict in the launch)
+export TD_OPTS=band_mode=2,sine_mode=2
 for c in c3 c4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${TAG}_${c}guard -- python3 $R/tools/time_configs.py $c > $R/gpurun_out/prof_${TAG}_${c}guard.log 2>&1
   rocprofv3 --pmc $VALU --output-format csv -d $R/gpurun_out/pmc_${TAG}_${c}guard_VALU -- python3 $R/tools/time_configs.py $c > /dev/null 2>&1
