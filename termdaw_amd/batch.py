@@ -70,12 +70,31 @@ class PeakExchange:
         self.n_total = per_rank * world
         self.comm = None
         live = dist is not None and dist.is_initialized()
+        self.fallback = None       # why the library's own RCCL communicator is not in use (None: it is, or none is needed)
         if comm is not None:
             self.comm = comm
         elif live and on_device:
-            box = [api.comm_unique_id() if rank == 0 else None]
+            # rank 0 makes the id, torch.distributed carries its 128 bytes (a Rust host: a socket); every rank joins.  The ranks
+            # then agree on the outcome -- an all-reduce(min) of "my td_comm_init worked" -- so that either ALL of them run the
+            # library's collective or all of them say loudly that they do not (`fallback`, bench.py's exchange_backend) and run
+            # the same reduction through torch.distributed on the library's device table instead of hanging in a half-made job.
+            import torch
+            err = ""
+            try:
+                box = [api.comm_unique_id() if rank == 0 else None]
+            except api.TermdawError as e:
+                box, err = [None], str(e)
             dist.broadcast_object_list(box, src=0)
-            self.comm = api.Comm(box[0], rank, world)          # ncclCommInitRank: returns when every rank has joined
+            if box[0] is not None:
+                try:
+                    self.comm = api.Comm(box[0], rank, world)   # ncclCommInitRank: returns when every rank has joined
+                except api.TermdawError as e:
+                    err = str(e)
+            ok = torch.tensor([1 if self.comm is not None else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                self.comm = None
+                self.fallback = "td_comm_init failed on a rank (%s): torch.distributed all_reduce on the library's table" % (err or "another rank")
         elif live:
             import torch
 
@@ -85,17 +104,30 @@ class PeakExchange:
             self.comm = api.Comm.over_host(allreduce_max, rank, world)
 
     def backend(self):
+        if self.fallback:
+            return "torch-rccl (FALLBACK: %s)" % self.fallback
         return self.comm.backend() if self.comm is not None else "none"
 
     def exchange(self):
+        if self.fallback:   # (never on the test boxes: see __init__) the round-5 form: the engine fills torch's tensor, torch reduces it
+            import torch
+            if getattr(self, "_t", None) is None:
+                self._t = torch.zeros(self.n_total, dtype=torch.float32, device="cuda")
+            self.batch.peak_table_device(self._t.data_ptr(), self.n_total, first=self.rank, stride=self.world)
+            self.batch.sync()
+            self.dist.all_reduce(self._t, op=self.dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+            return
         self.batch.exchange_peaks(self.comm, self.per_rank)   # table kernel + collective, enqueued on the batch's stream
         self.batch.sync()                                      # the reduced table stands in device memory
 
     def is_collective(self):
         """True when exchange() runs an all-reduce over more than one rank (it then also is a barrier between them)."""
-        return self.comm is not None and self.world > 1
+        return (self.comm is not None or self.fallback is not None) and self.world > 1
 
     def host(self):
+        if self.fallback:
+            return self._t.cpu().numpy()
         return self.batch.peak_table(self.n_total)
 
     def __call__(self):

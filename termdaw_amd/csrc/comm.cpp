@@ -34,6 +34,7 @@ Rccl& lib() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        if (getenv("TD_RCCL_DISABLE")) { r.why = "switched off by TD_RCCL_DISABLE"; return; }   // (tests: the callers' behaviour without RCCL)
         const char* env = getenv("TD_RCCL_LIB");
         const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {

@@ -174,6 +174,21 @@ def test_bench_one_rank_over_rccl():
     assert out["ranks"]["n"] == 1 and out["ranks"]["exchange_ms"] >= 0.0 and out["ranks"]["start_skew_us"] == 0.0
 
 
+def test_bench_says_so_when_the_librarys_communicator_cannot_be_made():
+    """Without RCCL behind the library (TD_RCCL_DISABLE: what a missing or broken librccl looks like) the ranks agree that
+    td_comm_init failed and run the reduction through torch.distributed on the engine's table -- and the line says so, loudly."""
+    env = dict(os.environ, TD_BENCH_FORCE_DIST="1", TD_RCCL_DISABLE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549", RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline", "--projects-per-gpu", "2", "--seconds", "6"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][-1])
+    assert out["exchange_backend"].startswith("torch-rccl (FALLBACK") and "TD_RCCL_DISABLE" in out["exchange_backend"]
+    assert out["peak_table_entries"] == 2 and all(v > 0 for v in out["peak_table"])
+
+
 def test_handles_freed_with_a_deferred_check_pending(gpu_api):
     """A render whose deferred check launch is still pending (forced give-up, no sync yet) followed by freeing the graph --
     alone and as a member of a batch -- settles first: no launch on freed state, no crash, the survivors still render."""
