@@ -538,7 +538,7 @@ static int pull_state(td_graph* g) {
 }
 
 int ensure_buffers(td_graph* g, size_t frames) {
-    frames += frames & 1;
+    frames = (frames + 3) & ~(size_t)3;   // (whole fours: the planar-in-4 copy of a band-pass vertex' input covers the last, partial four too)
     if (frames > g->cap_frames) {
         if (!drain(g)) return 0;
         for (float2* p : g->pool) {

@@ -61,6 +61,14 @@ TD_DEV void store_pair(float2* p, uint32_t m, uint32_t M, float4 v) {
     if (m < M) gstore4(p + m, v);
 }
 
+// The planar-in-4 copy of a stereo stream (a band-pass vertex' materialised input sum): every aligned four frames as
+// {l0 l1 l2 l3}{r0 r1 r2 r3}, same word addresses as the interleaved four.  Frame m: two dwords, 16 bytes apart.
+TD_DEV float2 q4_frame(const float* q, uint32_t m) {
+    const float* p = q + (size_t)(m >> 2) * 8u + (m & 3u);
+    return make_float2(gload1(p), gload1(p + 4));
+}
+TD_DEV float q4_chan(const float* q, uint32_t m, uint32_t ch) { return gload1(q + (size_t)(m >> 2) * 8u + (m & 3u) + 4u * ch); }
+
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // A double moved across lanes by DPP (two 32-bit moves on the VALU; no trip through the LDS crossbar as __shfl takes).
 // Lanes whose source lies outside the row / wave, or that the row mask leaves out, receive 0.
@@ -566,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
             store_quant_pair(d.pcm, d.qmode, m0, M, s0, d.amplitude);
             store_quant_pair(d.pcm, d.qmode, m1, M, s1, d.amplitude);
         }
-    } else {
+    } else if (d.out) {   // (mode 2 -- a band-pass vertex' input sum -- keeps only the planar copy since round 6)
         store_pair(d.out, m0, M, a0);
         store_pair(d.out, m1, M, a1);
     }
@@ -574,17 +582,20 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
         if (!quad_map) {
             // planar-in-4 copy: lanes 2u / 2u+1 hold frames 4u..4u+3; the even lane assembles the L word, the
             // odd lane the R word, each with its neighbour's two values (DPP quad_perm [1,0,3,2]) and stores
-            // it at its own word address.  Only whole blocks are written (the warm-up never reads others).
+            // it at its own word address.  The chunk's last, partial four frames too (the buffer is padded to whole fours;
+            // frames at or beyond M are written as 0): the planar copy is the ONLY copy the band-pass kernels read.
             auto nb = [](float v) {
                 return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
             };
             const bool odd = (threadIdx.x & 1u) != 0u;
+            if (m0 >= M) a0 = make_float4(0.f, 0.f, 0.f, 0.f); else if (m0 + 1u >= M) { a0.z = 0.f; a0.w = 0.f; }
+            if (m1 >= M) a1 = make_float4(0.f, 0.f, 0.f, 0.f); else if (m1 + 1u >= M) { a1.z = 0.f; a1.w = 0.f; }
             const float n0x = nb(a0.x), n0y = nb(a0.y), n0z = nb(a0.z), n0w = nb(a0.w);
             const float n1x = nb(a1.x), n1y = nb(a1.y), n1z = nb(a1.z), n1w = nb(a1.w);
             const float4 q0 = odd ? make_float4(n0y, n0w, a0.y, a0.w) : make_float4(a0.x, a0.z, n0x, n0z);
             const float4 q1 = odd ? make_float4(n1y, n1w, a1.y, a1.w) : make_float4(a1.x, a1.z, n1x, n1z);
-            if ((m0 | 3u) < M) gstore4(d.out_q4 + m0, q0);
-            if ((m1 | 3u) < M) gstore4(d.out_q4 + m1, q1);
+            if ((m0 & ~3u) < M) gstore4(d.out_q4 + m0, q0);
+            if ((m1 & ~3u) < M) gstore4(d.out_q4 + m1, q1);
         }
         if (d.rp && !quad_map) {
             // block responses for k_band_spec's warm-up guess (BandRespParam): weights gamma (1 - gamma)^(255 - i) in double
@@ -2229,20 +2240,12 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
     const uint32_t ch = c & 1u;
     const float gam = (c & 2u) ? d.hgamma : d.lgamma;
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
-    const float* __restrict__ xf = reinterpret_cast<const float*>(d.x);
+    const float* __restrict__ qf = reinterpret_cast<const float*>(d.xq4);   // the planar-in-4 input: the only copy (round 6)
     const uint32_t start = seg * d.S;
     const uint32_t end = min(start + d.S, M);
     // exact state at the chunk's first frame: carried, or seeded from buf[0] (extensions.rs:664-670)
-    const float y_true0 = (d.state->first || d.first_override) ? gload1(xf + ch) : gload1(reinterpret_cast<const float*>(d.state) + c);
-    // Input fetch: the four lanes of a quad load four consecutive 16-byte words (8 frames, 64 B) with ONE
-    // instruction and hand them round with DPP quad broadcasts -- one vector-memory instruction per 8
-    // steps instead of 8, which is what the address path of 16 independent streams per wave can sustain.
-    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(d.x);
-    const uint32_t M2 = (M + 1u) >> 1;                       // 16-byte words in the (even-padded) buffer
-    auto fetch8 = [&](uint32_t frame) -> float4 {            // frame is a multiple of 8
-        const uint32_t w = (frame >> 1) + c;
-        return gload4(x4 + min(w, M2 - 1u));   // clamped: frames past the end are never stepped over
-    };
+    const float y_true0 = (d.state->first || d.first_override) ? q4_chan(qf, 0u, ch) : gload1(reinterpret_cast<const float*>(d.state) + c);
+    const uint32_t M2 = ((M + 3u) & ~3u) >> 1;               // 16-byte words of the planar copy (padded to whole fours)
     // warm-up: recurrence only, fed from the planar-in-4 copy: lane c of the quad loads 16-byte word c of an
     // 8-frame group = {L 0..3 | R 0..3 | L 4..7 | R 4..7}, so step j of the group needs register j & 3 of lane
     // (j >> 2) * 2 + ch -- a DPP quad_perm ([0,1,0,1] / [2,3,2,3]) applied right in the subtract's operand.
@@ -2391,7 +2394,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         }
         y = (float)yd;
     } else {
-        y = gload1(xf + 2u * my_begin + ch);
+        y = q4_chan(qf, my_begin, ch);
     }
     if (n + 32u <= start && (n & 31u) == 0u) {
         // three register sets in rotation (no copies): each batch of 32 steps runs on loads issued two batches
@@ -2422,10 +2425,10 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         for (; n + 8u <= start; n += 8u) { TD_BAND_STEP8(fetchq(n)) }
 #undef TD_BAND_STEP8
 #undef TD_BAND_S
-    for (; n < start; ++n) y = y + gam * (gload1(xf + 2u * n + ch) - y);
+    for (; n < start; ++n) y = y + gam * (q4_chan(qf, n, ch) - y);
     if (live) d.seg_start[seg * 4u + c] = y;
     // the segment itself: recurrence + output
-    const float x_first = gload1(xf + 2u * start + ch);
+    const float x_first = q4_chan(qf, start, ch);
     // Fast form (every quad of the wave owns a whole segment): the wave alternates between
     //   (a) 32 steps of the bare recurrence, like the warm-up, each lane dropping its state after every step
     //       into LDS (one ds_write per step; quad slots padded to 528 B so a wave's 64 lanes hit 64 banks), and
@@ -2477,7 +2480,6 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         // first frames, the descriptor's pointers and pan / gain (read through `d` they would be re-fetched by scalar loads
         // after every global store, which may alias the descriptor for all the compiler knows) -- is worked out once, and
         // the segments' "constant" / "zero" verdicts are eight ballots after the last piece instead of two per slot.
-        const float2* __restrict__ const x_in = d.x;
         float2* __restrict__ const out_p = d.out;
         const PanGain pg = d.pg;
         const uint32_t S = d.S;
@@ -2493,7 +2495,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
             m0_[i] = s0_ + j;
             slot_end[i] = sraw < d.nseg ? s0_ + ((min(s0_ + S, M) - s0_) & ~31u) : 0u;
             ys_rd[i] = ys_l + (wq0 + sq) * kQStride + j * 4u;
-            xo[i] = gload2(x_in + min(m0_[i], M - 1u));
+            xo[i] = q4_frame(qf, min(m0_[i], M - 1u));
         }
         float y_cap = y;
         for (uint32_t p = 0; p < len_w; p += 32u) {
@@ -2508,7 +2510,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
             for (uint32_t i = 0; i < 8u; ++i) {
                 const uint32_t m = m0_[i] + p;
                 const float2 x = xo[i];
-                if (p + 32u < len_w) xo[i] = gload2(x_in + min(m + 32u, M - 1u));
+                if (p + 32u < len_w) xo[i] = q4_frame(qf, min(m + 32u, M - 1u));
                 const float4 s = *reinterpret_cast<const float4*>(ys_rd[i]);
                 if (p == 0u) x0r[i] = xf_l[wq0 + ((i * 64u + lane) >> 5)];
                 const float2 x0 = x0r[i];
@@ -2548,24 +2550,7 @@ __global__ __launch_bounds__(kThreads) void k_band_spec(const BandSpecDesc* __re
         const float2 o = band_out(kf, l, r, quad_bcast<0>(y), quad_bcast<1>(y), quad_bcast<2>(y), quad_bcast<3>(y));
         if (c == 0u && live) gstore2(d.out + m, epilogue(o, d.pg));
     };
-    const uint32_t n0 = start + n_done;
-    if (n0 >= end) {
-        // (nothing left)
-    } else if ((n0 & 7u) == 0u) {
-        float4 a = fetch8(n0);
-        for (n = n0; n < end; n += 8u) {
-            const float4 nx = fetch8(n + 8u);
-            const float l0 = quad_bcast<0>(a.x), r0 = quad_bcast<0>(a.y), l1 = quad_bcast<0>(a.z), r1 = quad_bcast<0>(a.w);
-            const float l2 = quad_bcast<1>(a.x), r2 = quad_bcast<1>(a.y), l3 = quad_bcast<1>(a.z), r3 = quad_bcast<1>(a.w);
-            const float l4 = quad_bcast<2>(a.x), r4 = quad_bcast<2>(a.y), l5 = quad_bcast<2>(a.z), r5 = quad_bcast<2>(a.w);
-            const float l6 = quad_bcast<3>(a.x), r6 = quad_bcast<3>(a.y), l7 = quad_bcast<3>(a.z), r7 = quad_bcast<3>(a.w);
-            step(n, l0, r0); step(n + 1u, l1, r1); step(n + 2u, l2, r2); step(n + 3u, l3, r3);
-            step(n + 4u, l4, r4); step(n + 5u, l5, r5); step(n + 6u, l6, r6); step(n + 7u, l7, r7);
-            a = nx;
-        }
-    } else {
-        for (n = n0; n < end; ++n) { const float2 x = d.x[n]; step(n, x.x, x.y); }
-    }
+    for (n = start + n_done; n < end; ++n) { const float2 x = q4_frame(qf, n); step(n, x.x, x.y); }
     if (live) d.seg_final[seg * 4u + c] = y;
     const float s0 = quad_bcast<0>(same ? 1.0f : 0.0f), s1 = quad_bcast<1>(same ? 1.0f : 0.0f);
     const float z0 = quad_bcast<0>(zero ? 1.0f : 0.0f), z1 = quad_bcast<1>(zero ? 1.0f : 0.0f);
@@ -2601,7 +2586,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
     const float gam = (c & 2u) ? d.hgamma : d.lgamma;
     const BandCoef kf = band_coef(d.lgamma, d.hgamma, d.pass);
     // (read once: through `d` they would be re-fetched by scalar loads after every global store of the loops below)
-    const float2* __restrict__ const x_in = d.x;
+    const float* __restrict__ const qf = reinterpret_cast<const float*>(d.xq4);   // (the planar-in-4 input)
     float2* const out_p = d.out;
     const PanGain pg = d.pg;
     const uint32_t S = d.S;
@@ -2640,7 +2625,7 @@ TD_DEV void band_fix_cascade(const BandSpecDesc& d, uint32_t M, uint32_t seg, ui
         while (n < len && !parked && !coalesced) {
             // the next 64 frames of input (most repairs park or coalesce within the first few frames)
             const uint32_t cl = min(64u, len - n);
-            if (lane < cl) xs[lane] = gload2(x_in + start + n + lane);
+            if (lane < cl) xs[lane] = q4_frame(qf, start + n + lane);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             uint32_t k = 0;
             while (k < cl && !parked && !coalesced) {
@@ -2870,7 +2855,7 @@ TD_DEV void band_fill_tiles(const BandSpecDesc& d, uint32_t M, uint32_t* claim_s
             if (j == kNoJob) continue;
             const BandJob jb = d.jobs[j];
             if (m < jb.begin || m >= jb.end) continue;
-            const float2 x = d.x[m];
+            const float2 x = q4_frame(reinterpret_cast<const float*>(d.xq4), m);
             d.out[m] = epilogue(band_out(kf, x.x, x.y, jb.y[0], jb.y[1], jb.y[2], jb.y[3]), d.pg);
         }
     }

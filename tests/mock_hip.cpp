@@ -100,7 +100,7 @@ static void touch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl) {
         if (d[i].mode == 2u) touch_w(d[i].peaks, (size_t)((frames + 255) / 256) * 4);
         if (d[i].mode >= 4u) { touch_w(d[i].sync, (size_t)std::max<uint32_t>(nb, 1) * 8); touch_w(d[i].host_flag, 4); }
         if (d[i].qmode) touch_w(d[i].pcm, (size_t)frames * 2 * (d[i].qmode == 1u ? 2 : 4));
-        if (d[i].out_q4) touch_w(d[i].out_q4, (size_t)frames * sizeof(float2));
+        if (d[i].out_q4) touch_w(d[i].out_q4, (size_t)((frames + 3) & ~3u) * sizeof(float2));   // (the planar copy covers the last, partial four frames)
         if (d[i].rp) { touch(d[i].rp, sizeof(BandRespParam)); touch_w(d[i].rp->resp, (size_t)((frames + 255) / 256) * 4 * sizeof(double)); }
     }
 }
@@ -211,7 +211,7 @@ static void touch_spec(const BandSpecDesc* d, int n, uint32_t frames) {
     touch_descs(d, n);
     for (int i = 0; i < n; ++i) {
         const BandSpecDesc& x = d[i];
-        touch(x.x, (size_t)frames * sizeof(float2)); touch(x.xq4, (size_t)frames * sizeof(float2)); touch_w(x.out, (size_t)frames * sizeof(float2));
+        if (x.x) abort();   /* (round 6: no interleaved copy) */ touch(x.xq4, (size_t)((frames + 3) & ~3u) * sizeof(float2)); touch_w(x.out, (size_t)frames * sizeof(float2));
         touch_w(x.state, sizeof(BandState));
         touch_w(x.seg_start, (size_t)x.nseg * 16); touch_w(x.seg_final, (size_t)x.nseg * 16); touch_w(x.seg_flags, (size_t)x.nseg * 4);
         touch_w(x.seg_x0, (size_t)x.nseg * 8); touch_w(x.jobs, (size_t)x.nseg * sizeof(BandJob)); touch_w(x.seg_job, (size_t)x.nseg * 4);
