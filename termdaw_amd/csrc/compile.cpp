@@ -109,6 +109,7 @@ struct VTables {   // per-vertex compile result: offsets into the vertex' table 
     size_t raw_istart_off = 0, raw_ivoff_off = 0, raw_voices_off = 0, raw_tile_first_off = 0;   // (TableCache: a probed affine Synth vertex)
     uint32_t raw_n_int = 0;
     size_t probe_v_off = 0;   // (a probed sine / Synth vertex) per sample of k_sine_probe: its frame's voice range in the raw table
+    float hz_max = 0.0f;      // (Synth) the largest |hz| of any voice record of the tables (NaN: +inf): SynthDesc::small_args
 };
 
 static PanGain make_pg(float gain, float angle) {
@@ -222,13 +223,23 @@ static void put_intervals(IntervalView ib, Staging& st, VTables& vt) {
         tile_first[t] = it;
     }
     vt.tile_first_off = st.put(tile_first);
-    {   // tiles with an interval start strictly inside them first (IntervalTab::tile_order)
+    {   // IntervalTab::tile_order: the costliest tiles first -- a tile's cost is a pass of the voice loop per interval it holds
+        // frames of (the tiles with an interval start strictly inside them: the waves that take the per-interval passes), each as
+        // long as the interval has voices.  Longest first, the grid's last workgroups are the cheap ones -- the tiles between two
+        // chords -- and the CUs run dry together (round 6: config 3's k_sources 80 -> 77 us; before: multi-interval tiles first, the
+        // rest in timeline order).
         const size_t nt = tile_first.size() - 1;
-        std::vector<uint32_t> order, light;
-        order.reserve(nt);
-        for (size_t t = 0; t < nt; ++t) (tile_first[t + 1] > tile_first[t] + (ib.istart[tile_first[t + 1]] == (t + 1) * kTileFrames ? 1u : 0u)
-                                             ? order : light).push_back((uint32_t)t);
-        order.insert(order.end(), light.begin(), light.end());
+        std::vector<uint64_t> cost(nt);
+        for (size_t t = 0; t < nt; ++t) {
+            uint32_t last = tile_first[t + 1];
+            if (last > tile_first[t] && ib.istart[last] == (t + 1) * kTileFrames) --last;   // (the next tile's first interval starts exactly there)
+            uint64_t c = 0;
+            for (uint32_t i = tile_first[t]; i <= last; ++i) c += (uint64_t)(ib.ivoff[i + 1] - ib.ivoff[i]) + 2u;
+            cost[t] = c;
+        }
+        std::vector<uint32_t> order(nt);
+        for (size_t t = 0; t < nt; ++t) order[t] = (uint32_t)t;
+        std::stable_sort(order.begin(), order.end(), [&cost](uint32_t a, uint32_t b) { return cost[a] > cost[b]; });
         vt.tile_order_off = st.put(order);
     }
     vt.istart_off = st.put(ib.istart);
@@ -416,13 +427,18 @@ static void synth_refine_affine(const Vertex& v, IntervalBuilder& raw, size_t bl
             const size_t ia = a - blk0;
             for (size_t q = 0; q < nv; ++q) {
                 const float hz = vo[q].x, vel = vo[q].y, env_t = vo[q].z, rel_t = vo[q].w;
+                const size_t head = rec.size();
                 rec.push_back(make_float4(hz, env_t, 0.0f, 0.0f));
+                uint32_t live = 0;   // bit o: oscillator o's record is not A = B = 0 (a piece that is identically 0 adds nothing: the kernel skips it)
                 for (int o = 0; o < 3; ++o) {
                     if (conf_of[o] < 0) { rec.push_back(make_float4(0.f, 0.f, 0.f, 0.f)); continue; }
                     const AdsrConfD& c = osc[o]->adsr;
                     const double K = (double)vel * (double)osc[o]->volume * amp * shape[o];
-                    rec.push_back(synth_osc_piece(c, synth_piece(c, env_t, rel_t, ia, srf), rel_t, K));
+                    const float4 piece = synth_osc_piece(c, synth_piece(c, env_t, rel_t, ia, srf), rel_t, K);
+                    rec.push_back(piece);
+                    if (!(piece.z == 0.0f && piece.w == 0.0f)) live |= 1u << o;
                 }
+                memcpy(&rec[head].z, &live, 4);   // (a bit pattern in a float's place: read by the scalar unit, never by an FP instruction)
             }
             if (ci == cuts.size()) break;
             a = cuts[ci++];
@@ -477,6 +493,8 @@ static int compile_synth(Vertex& v, const td_flowwbank* fb, const std::vector<Bl
                       v.notes.end());
     }
     if (impossible) return fail("Synth: impossible release stage note");
+    vt.hz_max = 0.0f;
+    for (const float4& n : ib.voices) vt.hz_max = fabsf(n.x) <= vt.hz_max ? vt.hz_max : (n.x == n.x ? fabsf(n.x) : INFINITY);
     if (v.kind == K_SYNTH && synth_affine_ok(v)) {
         ib.finish();
         std::vector<uint32_t> istart, ivoff;
@@ -946,6 +964,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                 tc->tile_order_off = t.tile_order_off;
                 tc->raw_istart_off = t.raw_istart_off; tc->raw_ivoff_off = t.raw_ivoff_off; tc->raw_voices_off = t.raw_voices_off;
                 tc->raw_tile_first_off = t.raw_tile_first_off; tc->raw_n_int = t.raw_n_int; tc->probe_v_off = t.probe_v_off;
+                tc->hz_max = t.hz_max;
                 tc->end_state.clear();
                 save_state(v, tc->end_state);
                 tc->key = key;
@@ -960,6 +979,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
         o.tile_order_off = tc->tile_order_off;
         o.raw_istart_off = tc->raw_istart_off; o.raw_ivoff_off = tc->raw_ivoff_off; o.raw_voices_off = tc->raw_voices_off;
         o.raw_tile_first_off = tc->raw_tile_first_off; o.raw_n_int = tc->raw_n_int; o.probe_v_off = tc->probe_v_off;
+        o.hz_max = tc->hz_max;
     }
 
     // ---- 2. descriptors: walk levels, assign edge buffers
@@ -1269,6 +1289,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
         x.pg = make_pg(v.gain, v.angle);
         x.affine = synth_affine_ok(v) ? 1u : 0u;   // (the tables then hold affine records: compile_synth)
         x.exact_sin = v.exact_sin ? 1u : 0u;
+        x.small_args = ((double)(t0 + M + 2) / (double)sr) * (double)vt[vi].hz_max * 6.2831854 < 1.3e7 ? 1u : 0u;
         {
             auto same = [](const AdsrConfD& a, const AdsrConfD& b) { return memcmp(&a, &b, sizeof(AdsrConfD)) == 0; };
             const bool sq = v.square.volume > 0.0f, tf = v.topflat.volume > 0.0f;

@@ -102,6 +102,7 @@ struct TableCache {
     size_t raw_istart_off = 0, raw_ivoff_off = 0, raw_voices_off = 0, raw_tile_first_off = 0;
     uint32_t raw_n_int = 0;
     size_t probe_v_off = 0;   // ... and k_sine_probe's per-sample voice ranges (ProbeDesc::ranges)
+    float hz_max = 0.0f;      // (Synth) the tables' largest |hz|: SynthDesc::small_args
 };
 
 struct Vertex {

@@ -1232,6 +1232,28 @@ TD_DEV f2 sin_any2(f2 arg) {
     return q * sgn;
 }
 TD_DEV float sin_any(float arg) { return sin_any2((f2)(arg)).x; }
+// The same for arguments below 2^22 half turns (1.3e7 rad; SynthDesc::small_args: the host has looked at the chunk's last frame and
+// the tables' largest hz).  n = rint(arg / pi) comes out of ONE fused step: arg / pi + 1.5 * 2^23 is rounded to an integer by
+// the addition itself, and the sum's last mantissa bit is n's parity -- shifted to the top and ADDED to r's pattern it flips r's
+// sign (v_lshl_add_u32), in front of the odd polynomial, whose result is canonical again.  14 instructions per frame pair
+// instead of 18 (round 6; same reduction, same polynomial: the two agree except where rint saw a tie).
+TD_DEV f2 sin_small2(f2 arg) {
+    const f2 big = (f2)(12582912.0f);
+    const f2 t = fma2(arg, (f2)(0.318309886f), big);
+    const f2 n = t - big;
+    f2 r = fma2(-n, (f2)(3.14159274f), arg);
+    r = fma2(-n, (f2)(-8.74227766e-8f), r);
+    const f2 r2 = r * r;
+    f2 rs;
+    rs.x = __uint_as_float((__float_as_uint(t.x) << 31) + __float_as_uint(r.x));
+    rs.y = __uint_as_float((__float_as_uint(t.y) << 31) + __float_as_uint(r.y));
+    f2 p = (f2)(-2.5052108385441718775e-8f);                 // -1/11!
+    p = fma2(p, r2, (f2)(2.7557319223985890653e-6f));        //  1/9!
+    p = fma2(p, r2, (f2)(-1.9841269841269841270e-4f));       // -1/7!
+    p = fma2(p, r2, (f2)(8.3333333333333333333e-3f));        //  1/5!
+    p = fma2(p, r2, (f2)(-1.6666666666666666667e-1f));       // -1/3!
+    return fma2(rs, r2 * p, rs);
+}
 
 // sin of an f32 argument EXACTLY as glibc's sinf returns it (engine option "sine_mode" 1).  The reference's `f32::sin`
 // (extensions.rs:450,501) is libm's sinf; glibc's (2.28 and later: sysdeps/ieee754/flt-32/s_sinf.c + sincosf.h, the ARM
@@ -1598,79 +1620,108 @@ TD_DEV void synth_quad(const SynthDesc& d, uint32_t ma, uint32_t mb, uint32_t M,
 // SHARE_TR: the triangle's conf is the top-flat's (BASELINE config 3's shape): same (s1, s2), one u for both.
 typedef float f4c __attribute__((ext_vector_type(4)));
 // An oscillator whose record holds A = B = 0 -- its envelope piece is identically 0: a hit-shaped envelope behind its decay, BASELINE
-// config 3's square oscillator 99 % of the time -- adds `c * 0` to the sum, i.e. nothing (c is finite); the test is on the
-// record's bits (scalar unit), the skipped block a uniform branch (round 6).
-TD_DEV bool osc_live(const f4c q) { const float a = q.z, b = q.w; return ((__float_as_uint(a) | __float_as_uint(b)) << 1) != 0u; }
-template <bool SQ, bool TF, bool TR, bool SHARE_TR>
-TD_DEV f2 synth_pair_affine(const f4c q0, const f4c q1, const f4c q2, const f4c q3, float zsq, float ztf, float tf_bias, f2 time, f2 off, f2 acc) {
-    const f2 th = time * q0.x;
-    const f2 t = q0.y + off;
-    const bool l1 = SQ && osc_live(q1), l2 = TF && osc_live(q2), l3 = TR && osc_live(q3);
-    f2 sn = (f2)(0.0f);
-    if (l1 || l2) { asm volatile(""); sn = sin_any2(th * (2.0f * kPi)); }
+// config 3's square oscillator most of the time -- adds `c * 0` to the sum, i.e. nothing (c is finite); the host says so in the
+// voice's first record (bits 0..2 of its third word), the skipped block is a uniform branch (round 6).
+// (clang 19 note: __builtin_bit_cast of a vector ELEMENT (`q.z`) reads element 0 -- copy the element to a scalar first.)
+// (one voice, the lane's TWO frame pairs: every test on the record -- scalar unit, one per CU -- is made once for both)
+template <bool SQ, bool TF, bool TR, bool SHARE_TR, bool SMALL>
+TD_DEV void synth_quad_affine_voice(const f4c q0, const f4c q1, const f4c q2, const f4c q3, float zsq, float ztf, float tf_bias,
+                                    f2 time_a, f2 off_a, f2 time_b, f2 off_b, f2& acc_a, f2& acc_b) {
+    const f2 tha = time_a * q0.x, thb = time_b * q0.x;
+    const f2 t_a = q0.y + off_a, t_b = q0.y + off_b;
+    const float lz = q0.z;   // (the host's verdict per oscillator, bits 0..2: synth_refine_affine)
+    const uint32_t live = __float_as_uint(lz);
+    const bool l1 = SQ && (live & 1u), l2 = TF && (live & 2u), l3 = TR && (live & 4u);
+    f2 sna = (f2)(0.0f), snb = (f2)(0.0f);
+    if (l1 || l2) {
+        asm volatile("");
+        sna = SMALL ? sin_small2(tha * (2.0f * kPi)) : sin_any2(tha * (2.0f * kPi));
+        snb = SMALL ? sin_small2(thb * (2.0f * kPi)) : sin_any2(thb * (2.0f * kPi));
+    }
     if (l1) {
         asm volatile("");
-        const f2 ek = fma2((t - q1.x) - q1.y, (f2)(q1.w), (f2)(q1.z));
-        f2 c;   // clamp(sn, -z, z) as ONE v_med3_f32 (sn is finite: a polynomial of a finite argument)
-        c.x = __builtin_amdgcn_fmed3f(sn.x, -zsq, zsq);
-        c.y = __builtin_amdgcn_fmed3f(sn.y, -zsq, zsq);
-        acc = fma2(c, ek, acc);
+        const f2 eka = fma2((t_a - q1.x) - q1.y, (f2)(q1.w), (f2)(q1.z)), ekb = fma2((t_b - q1.x) - q1.y, (f2)(q1.w), (f2)(q1.z));
+        f2 ca, cb;   // clamp(sn, -z, z) as ONE v_med3_f32 (sn is finite: a polynomial of a finite argument)
+        ca.x = __builtin_amdgcn_fmed3f(sna.x, -zsq, zsq);
+        ca.y = __builtin_amdgcn_fmed3f(sna.y, -zsq, zsq);
+        cb.x = __builtin_amdgcn_fmed3f(snb.x, -zsq, zsq);
+        cb.y = __builtin_amdgcn_fmed3f(snb.y, -zsq, zsq);
+        acc_a = fma2(ca, eka, acc_a);
+        acc_b = fma2(cb, ekb, acc_b);
     }
-    f2 utf = (f2)(0.0f);
-    if (l2 || (SHARE_TR && l3)) utf = (t - q2.x) - q2.y;
+    f2 utfa = (f2)(0.0f), utfb = (f2)(0.0f);
+    if (l2 || (SHARE_TR && l3)) { utfa = (t_a - q2.x) - q2.y; utfb = (t_b - q2.x) - q2.y; }
     if (l2) {
         asm volatile("");
-        const f2 ek = fma2(utf, (f2)(q2.w), (f2)(q2.z));
-        f2 m;   // min(sn, z) as the median of (sn, z, -inf): no canonicalising v_max in front of it
-        m.x = __builtin_amdgcn_fmed3f(sn.x, ztf, -__builtin_inff());
-        m.y = __builtin_amdgcn_fmed3f(sn.y, ztf, -__builtin_inff());
-        acc = fma2(m + tf_bias, ek, acc);
+        const f2 eka = fma2(utfa, (f2)(q2.w), (f2)(q2.z)), ekb = fma2(utfb, (f2)(q2.w), (f2)(q2.z));
+        f2 ma, mb;   // min(sn, z) as the median of (sn, z, -inf): no canonicalising v_max in front of it
+        ma.x = __builtin_amdgcn_fmed3f(sna.x, ztf, -__builtin_inff());
+        ma.y = __builtin_amdgcn_fmed3f(sna.y, ztf, -__builtin_inff());
+        mb.x = __builtin_amdgcn_fmed3f(snb.x, ztf, -__builtin_inff());
+        mb.y = __builtin_amdgcn_fmed3f(snb.y, ztf, -__builtin_inff());
+        acc_a = fma2(ma + tf_bias, eka, acc_a);
+        acc_b = fma2(mb + tf_bias, ekb, acc_b);
     }
     if (l3) {
         asm volatile("");
-        const f2 u = SHARE_TR ? utf : (t - q3.x) - q3.y;
-        const f2 ek = fma2(u, (f2)(q3.w), (f2)(q3.z));
-        f2 fl = th + 0.5f;
-        fl.x = floorf(fl.x);
-        fl.y = floorf(fl.y);
-        const f2 dd = th - fl;
-        f2 w;   // 4 |d| - 1: the absolute value rides as a source modifier of a plain v_fma_f32 (written out: left to itself the
+        const f2 ua = SHARE_TR ? utfa : (t_a - q3.x) - q3.y, ub = SHARE_TR ? utfb : (t_b - q3.x) - q3.y;
+        const f2 eka = fma2(ua, (f2)(q3.w), (f2)(q3.z)), ekb = fma2(ub, (f2)(q3.w), (f2)(q3.z));
+        f2 fla = tha + 0.5f, flb = thb + 0.5f;
+        fla.x = floorf(fla.x); fla.y = floorf(fla.y);
+        flb.x = floorf(flb.x); flb.y = floorf(flb.y);
+        const f2 da = tha - fla, db = thb - flb;
+        f2 wa, wb;   // 4 |d| - 1: the absolute value rides as a source modifier of a plain v_fma_f32 (written out: left to itself the
         // compiler clears the sign bits with two v_and and packs the two FMAs -- 5.6 ns of issue instead of 2.1)
-        asm("v_fma_f32 %0, |%1|, 4.0, -1.0" : "=v"(w.x) : "v"(dd.x));
-        asm("v_fma_f32 %0, |%1|, 4.0, -1.0" : "=v"(w.y) : "v"(dd.y));
-        acc = fma2(w, ek, acc);
+        asm("v_fma_f32 %0, |%1|, 4.0, -1.0" : "=v"(wa.x) : "v"(da.x));
+        asm("v_fma_f32 %0, |%1|, 4.0, -1.0" : "=v"(wa.y) : "v"(da.y));
+        asm("v_fma_f32 %0, |%1|, 4.0, -1.0" : "=v"(wb.x) : "v"(db.x));
+        asm("v_fma_f32 %0, |%1|, 4.0, -1.0" : "=v"(wb.y) : "v"(db.y));
+        acc_a = fma2(wa, eka, acc_a);
+        acc_b = fma2(wb, ekb, acc_b);
     }
-    return acc;
 }
 // all voices of interval `it` for the lane's two frame pairs (uniform: the records come in through scalar loads)
-template <bool SQ, bool TF, bool TR, bool SHARE_TR>
+typedef float f16c __attribute__((ext_vector_type(16)));
+template <bool SQ, bool TF, bool TR, bool SHARE_TR, bool SMALL>
 TD_DEV void synth_interval_affine(const SynthDesc& d, uint32_t it_, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
     const uint32_t it = (uint32_t)__builtin_amdgcn_readfirstlane((int)it_);   // (wave-uniform by construction: say so)
     const uint32_t TD_CONST* off_c = (const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.ivoff;
     const uint32_t v0 = off_c[it], v1 = off_c[it + 1u];
     const float zsq = d.square.param, ztf = d.topflat.param, tf_bias = (1.0f - ztf) / 2.0f;
-    const f4c TD_CONST* vc = (const f4c TD_CONST*)(const TD_CONST char*)d.tab.voices;
-    f4c q0 = vc[4u * v0], q1 = vc[4u * v0 + 1u], q2 = vc[4u * v0 + 2u], q3 = vc[4u * v0 + 3u];   // (v0 == v1: the table ends with spare records)
+    // a voice's four records are 64 consecutive bytes: ONE scalar load (and one address) per voice -- as four 16-byte loads
+    // they were four 64-bit address computations on the scalar unit, which the CU's four SIMDs share
+    const f16c TD_CONST* vc = (const f16c TD_CONST*)(const TD_CONST char*)d.tab.voices + v0;
+    f16c q = *vc;   // (v0 == v1: the table ends with spare records)
+    // (the first record waited for HERE: with it still in flight at the loop's head the compiler's wait lands behind the loop's own
+    // load -- every trip then waits for the record it has just asked for instead of finding it a trip later)
+    asm volatile("" :: "s"(q));
     for (uint32_t v = v0; v < v1; ++v) {
-        // (the next record's scalar loads: the compiler sinks them to the top of the next trip; issuing them by hand -- an
-        // s_load_dwordx16 a trip ahead -- was measured in round 6 and changes nothing: six waves per SIMD cover the round trip)
-        const f4c n0 = vc[4u * v + 4u], n1 = vc[4u * v + 5u], n2 = vc[4u * v + 6u], n3 = vc[4u * v + 7u];
-        a = synth_pair_affine<SQ, TF, TR, SHARE_TR>(q0, q1, q2, q3, zsq, ztf, tf_bias, ta, oa, a);
-        b = synth_pair_affine<SQ, TF, TR, SHARE_TR>(q0, q1, q2, q3, zsq, ztf, tf_bias, tb, ob, b);
-        q0 = n0; q1 = n1; q2 = n2; q3 = n3;
+        // (the next voice's load: the compiler sinks it to the top of the next trip; issuing it by hand a trip ahead was measured
+        // in round 6 and changes nothing: six waves per SIMD cover the round trip)
+        ++vc;
+        const f16c n = *vc;
+        synth_quad_affine_voice<SQ, TF, TR, SHARE_TR, SMALL>(__builtin_shufflevector(q, q, 0, 1, 2, 3), __builtin_shufflevector(q, q, 4, 5, 6, 7),
+                                                             __builtin_shufflevector(q, q, 8, 9, 10, 11), __builtin_shufflevector(q, q, 12, 13, 14, 15),
+                                                             zsq, ztf, tf_bias, ta, oa, tb, ob, a, b);
+        q = n;
     }
 }
-TD_DEV void synth_interval_affine_any(const SynthDesc& d, uint32_t it, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
+template <bool SMALL>
+TD_DEV void synth_interval_affine_kinds(const SynthDesc& d, uint32_t it, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
     const bool sq = d.square.volume > 0.0f, tf = d.topflat.volume > 0.0f, tr = d.triangle.volume > 0.0f;   // (uniform)
     if (sq && tf && tr) {
-        if (d.tf_env_src == 0u && d.tr_env_src == 2u) synth_interval_affine<true, true, true, true>(d, it, ta, tb, oa, ob, a, b);
-        else synth_interval_affine<true, true, true, false>(d, it, ta, tb, oa, ob, a, b);
-    } else if (sq && tf) synth_interval_affine<true, true, false, false>(d, it, ta, tb, oa, ob, a, b);
-    else if (sq && tr) synth_interval_affine<true, false, true, false>(d, it, ta, tb, oa, ob, a, b);
-    else if (tf && tr) synth_interval_affine<false, true, true, false>(d, it, ta, tb, oa, ob, a, b);
-    else if (sq) synth_interval_affine<true, false, false, false>(d, it, ta, tb, oa, ob, a, b);
-    else if (tf) synth_interval_affine<false, true, false, false>(d, it, ta, tb, oa, ob, a, b);
-    else if (tr) synth_interval_affine<false, false, true, false>(d, it, ta, tb, oa, ob, a, b);
+        if (d.tf_env_src == 0u && d.tr_env_src == 2u) synth_interval_affine<true, true, true, true, SMALL>(d, it, ta, tb, oa, ob, a, b);
+        else synth_interval_affine<true, true, true, false, SMALL>(d, it, ta, tb, oa, ob, a, b);
+    } else if (sq && tf) synth_interval_affine<true, true, false, false, SMALL>(d, it, ta, tb, oa, ob, a, b);
+    else if (sq && tr) synth_interval_affine<true, false, true, false, SMALL>(d, it, ta, tb, oa, ob, a, b);
+    else if (tf && tr) synth_interval_affine<false, true, true, false, SMALL>(d, it, ta, tb, oa, ob, a, b);
+    else if (sq) synth_interval_affine<true, false, false, false, SMALL>(d, it, ta, tb, oa, ob, a, b);
+    else if (tf) synth_interval_affine<false, true, false, false, SMALL>(d, it, ta, tb, oa, ob, a, b);
+    else if (tr) synth_interval_affine<false, false, true, false, false>(d, it, ta, tb, oa, ob, a, b);   // (no sine in a triangle)
+}
+TD_DEV void synth_interval_affine_any(const SynthDesc& d, uint32_t it, f2 ta, f2 tb, f2 oa, f2 ob, f2& a, f2& b) {
+    if (d.small_args) synth_interval_affine_kinds<true>(d, it, ta, tb, oa, ob, a, b);   // (uniform)
+    else synth_interval_affine_kinds<false>(d, it, ta, tb, oa, ob, a, b);
 }
 TD_DEV uint32_t wave_min_u32(uint32_t v) {
 #pragma unroll
