@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "kernels.h"
 
@@ -88,7 +89,16 @@ static void touch_terms(const InTerm* ins, uint32_t k, uint32_t frames) {
 static void touch_interval_tab(const IntervalTab& t, uint32_t frames) {
     touch(t.istart, (size_t)t.n_int * 4);
     touch(t.ivoff, ((size_t)t.n_int + 1) * 4);
-    touch(t.tile_first, (size_t)((frames + kTileFrames - 1) / kTileFrames) * 4);
+    const size_t nt = (frames + kTileFrames - 1) / kTileFrames;
+    touch(t.tile_first, nt * 4);
+    if (t.tile_order) {   // (costliest tiles first, compile.cpp put_intervals) a permutation of the chunk's tiles
+        touch(t.tile_order, nt * 4);
+        std::vector<char> seen(nt, 0);
+        for (size_t i = 0; i < nt; ++i) {
+            if (t.tile_order[i] >= nt || seen[t.tile_order[i]]) abort();
+            seen[t.tile_order[i]] = 1;
+        }
+    }
 }
 static void touch_sum(const SumDesc* d, int n, uint32_t frames, uint32_t bl) {
     touch_descs(d, n);
@@ -268,7 +278,25 @@ void launch_debug_sine(const SineDesc* d, int n, uint32_t frames, uint32_t, hipS
 }
 void launch_synth(const SynthDesc* d, int n, uint32_t frames, bool, hipStream_t) {
     touch_descs(d, n);
-    for (int i = 0; i < n; ++i) { touch_interval_tab(d[i].tab, frames); touch_w(d[i].out, (size_t)frames * sizeof(float2)); }
+    for (int i = 0; i < n; ++i) {
+        touch_interval_tab(d[i].tab, frames); touch_w(d[i].out, (size_t)frames * sizeof(float2));
+        const IntervalTab& t = d[i].tab;
+        const size_t nv = t.ivoff[t.n_int];
+        if (d[i].affine) {   // four records per voice, read as ONE 64-byte load a voice ahead: a spare voice behind the last; the host's liveness bits
+            touch(t.voices, (nv + 1) * 4 * sizeof(float4));
+            if (d[i].exact_sin) abort();
+            for (size_t v = 0; v < nv; ++v) {
+                uint32_t live; memcpy(&live, &t.voices[4 * v].z, 4);
+                for (int o = 0; o < 3; ++o) {
+                    const float4& r = t.voices[4 * v + 1 + o];
+                    if (((live >> o) & 1u) != (uint32_t)!(r.z == 0.0f && r.w == 0.0f)) abort();
+                }
+                if (live >> 3) abort();
+            }
+        } else {
+            touch(t.voices, nv * sizeof(float4));
+        }
+    }
 }
 void launch_sampsyn(const SampsynDesc* d, int n, uint32_t frames, hipStream_t) {
     touch_descs(d, n);

@@ -85,3 +85,35 @@ def test_affine_and_generic_vertices_in_one_graph(gpu_api, oracle, chunk):
     ok = np.isfinite(of)
     assert np.sqrt(np.mean((gf[ok].astype(np.float64) - of[ok].astype(np.float64)) ** 2)) <= 1e-6
     assert np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1
+
+
+@pytest.mark.parametrize("start_s", [0, 161, 400])
+def test_sine_arguments_on_both_sides_of_the_half_turn_bound(gpu_api, oracle, start_s):
+    """The affine form's sine rounds to half turns by adding 1.5 * 2^23 while the host can bound the chunk's arguments
+    below 2^22 half turns (SynthDesc::small_args), and by v_rndne beyond: a 12.5 kHz voice passes that bound 164.95 s
+    into the timeline.  Rendered from 0 s (every chunk below), from 161 s in one-second chunks (the first three below,
+    the rest above) and from 400 s (all above; arguments of 3e7 rad, an f32 ulp of 2 rad -- the rounding of
+    `time * hz * 2 pi` IS the signal there, extensions.rs:501)."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(6.0)
+    ev = []
+    for k in range(6):
+        t = start_s + 0.05 + k
+        ev += [(t, 127.0, 0.5), (t + 0.7, 127.0, 0.0), (t + 0.1, 52.0 + k, 0.4), (t + 0.8, 52.0 + k, 0.0)]
+    ev.sort(key=lambda e: e[0])
+    p.event_files["n"] = np.array(ev, np.float32)
+    p.load_midi_floww("n", "n")
+    p.add_synth("syn", 0.9, 0.0, "n", 0.4, 0.3, HIT, 1.0, 0.8, NOTE, 0.5, NOTE)
+    p.add_sum("out", 1.0, 0.0)
+    p.connect("syn", "out")
+    p.set_output("out")
+    res = []
+    for backend in (gpu_api, oracle):
+        sb, fb, g = p.build(backend)
+        if backend is gpu_api:
+            g.set_option("max_chunk_frames", 48000)
+        fb.set_time(start_s * 48000)
+        g.set_time(start_s * 48000)
+        res.append(g.render_all(sb, fb, p.cs, p.bd))
+    assert np.abs(res[1][1]).max() > 0.05
+    assert_close(res[0], res[1])
