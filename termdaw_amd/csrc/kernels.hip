@@ -435,6 +435,16 @@ TD_DEV void sum_terms16(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4&
 // more of the timeline resident per XCD at any moment = more of the concurrently running tiles touch the same
 // lines of a looping source while they are still in L2.  The packed form carries 15 wrap frames, so one modulo
 // per source and lane is enough.
+// Which frames a lane owns (round 6).  NQ < 4: 4 NQ consecutive ones from m.  NQ == 4 (BASELINE config 2's fused launch): quad q =
+// frames m + 256 q of the wave's 1 024, m = the wave's base + 4 lane -- every load instruction of the wave reads ONE KILOBYTE IN ONE
+// PIECE.  With sixteen consecutive frames per lane a lane's four 16-byte loads lie 64 bytes from the next lane's: every load
+// instruction touches 64 separate 64-byte pieces and takes a quarter of each, and the lines have to stay in the CU's L1 until the
+// fourth instruction has had its quarter (tools/ubench/gather_shape.hip, config 2's 737 MB with the arithmetic taken out: 52 us in
+// that shape, 40 us in this one with two sources' loads in flight -- in the old shape a second source in flight LOSES).
+template <int NQ>
+TD_DEV uint32_t quad_frame(uint32_t m, int q) { return NQ == 4 ? m + 256u * (uint32_t)q : m + 4u * (uint32_t)q; }
+template <int NQ>
+TD_DEV uint32_t pair_frame(uint32_t m, int p) { return quad_frame<NQ>(m, p >> 1) + 2u * (uint32_t)(p & 1); }
 template <int NQ>
 TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4 acc[2 * NQ]) {
     f2v c[4 * NQ];
@@ -456,11 +466,30 @@ TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4
     auto gather = [&](uint32_t j, uint32_t w[4 * NQ]) {
         const uint32_t len = (uint32_t)ins[j].len;
         const uint32_t idx = barrett_mod((uint32_t)ins[j].t0 + m, len, ins[j].magic);
+        if (NQ == 4) {
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(ins[j].p);
+            if (len > 256u) {   // (uniform) quad q starts 256 frames behind quad q - 1: one wrap at most
+                uint32_t i = idx;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    loop16_quad(p, len, i, w + 4 * q);
+                    i += 256u;
+                    i = min(i, i - len);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) loop16_quad(p, len, barrett_mod((uint32_t)ins[j].t0 + m + 256u * (uint32_t)q, len, ins[j].magic), w + 4 * q);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < NQ; ++q) loop16_quad(reinterpret_cast<const uint32_t*>(ins[j].p), len, idx + 4u * q, w + 4 * q);
     };
     uint32_t j = 0;
-    constexpr int B = NQ >= 4 ? 1 : (NQ == 2 ? 2 : 4);   // sources per batch: 16 x 16-byte loads in flight per lane... 4 x NQ
+    // sources per batch: 16 x 16-byte loads in flight per lane (NQ == 4, round 6: four sources since every load instruction reads whole
+    // lines -- in the old shape a second source in flight lost; 1 / 2 / 3 / 4 sources: 63.1 / 64.5 / 62.9 / 61.9 us on config 2, a
+    // batch of 64 projects 71.4 -> 65.6 us per project)
+    constexpr int B = 4;
     for (; j + B <= k; j += B) {
         uint32_t w[B][4 * NQ];
 #pragma unroll
@@ -470,7 +499,7 @@ TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4
     }
     for (; j < k; ++j) { uint32_t w[4 * NQ]; gather(j, w); add_term(j, w); }
 #pragma unroll
-    for (int q = 0; q < 2 * NQ; ++q) acc[q] = zero_tail(make_float4(c[2 * q].x, c[2 * q].y, c[2 * q + 1].x, c[2 * q + 1].y), m + 2u * q, M);
+    for (int q = 0; q < 2 * NQ; ++q) acc[q] = zero_tail(make_float4(c[2 * q].x, c[2 * q].y, c[2 * q + 1].x, c[2 * q + 1].y), pair_frame<NQ>(m, q), M);
 }
 
 // the same for all-f32 looping sources (kind 1): 4 * NQ consecutive frames per lane = 2 * NQ 16-byte loads per source
@@ -720,7 +749,10 @@ __global__ __launch_bounds__(kThreads) void k_sum(const SumDesc* __restrict__ de
 template <int NQ, bool PACKED = true>
 __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__ descs, uint32_t M, uint32_t tag) {
     const SumDesc& d = descs[blockIdx.y];
-    const uint32_t m = blockIdx.x * (kTileFrames * NQ) + 4u * NQ * threadIdx.x;
+    // (the lane's frames: quad_frame / pair_frame above -- NQ == 4 with packed sources: four quads 256 frames apart inside the wave's block)
+    constexpr int SH = (NQ == 4 && PACKED) ? 4 : 1;   // (the frame shape's tag: 1 = consecutive)
+    const uint32_t m = SH == 4 ? blockIdx.x * (kTileFrames * NQ) + (threadIdx.x >> 6) * kTileFrames + 4u * (threadIdx.x & 63u)
+                               : blockIdx.x * (kTileFrames * NQ) + 4u * NQ * threadIdx.x;
     // (mode 4: the carried max, read before anything else -- the last tile replaces it once every tile has published)
     const float spec_init_early = d.mode >= 4 ? (d.use_init ? d.init_max : gload1(&d.state->max)) : 0.0f;
     float4 a[2 * NQ];
@@ -728,12 +760,12 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
     else sum_terms32w<NQ>(term_tab(d.ins), d.k, m, M, a);
     if (d.mode == 0) {
 #pragma unroll
-        for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, epilogue4(a[q], d.pg));
+        for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, pair_frame<SH>(m, q), M, epilogue4(a[q], d.pg));
         return;
     }
     float pk = 0.0f;   // block peaks are those of the RAW sum
 #pragma unroll
-    for (int q = 0; q < 2 * NQ; ++q) if (m + 2u * q < M) pk = absmax4(pk, a[q]);
+    for (int q = 0; q < 2 * NQ; ++q) if (pair_frame<SH>(m, q) < M) pk = absmax4(pk, a[q]);
     float spec_init = 0.0f;
     if (d.mode >= 4) {
         // Single-pass RUNNING-PEAK normalize (fresh renders: `*max = buf_max.max(*max)` block by block, extensions.rs:321-329)
@@ -806,14 +838,14 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
     if (d.mode >= 3) {
         if (d.out) {   // (nullptr: nobody reads the f32 form of this output vertex -- engine option "output_f32" 0)
 #pragma unroll
-            for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
+            for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, pair_frame<SH>(m, q), M, a[q]);
         }
         if (d.qmode == 1u) {
             // int16 PCM: the lane's 4 * NQ frames are 16 * NQ contiguous bytes -> one 16-byte store per 4 frames
             uint32_t* o = reinterpret_cast<uint32_t*>(d.pcm);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const uint32_t mm = m + 4u * q;
+                const uint32_t mm = quad_frame<SH>(m, q);
                 if (mm + 3u < M) {
                     const float4 v0 = a[2 * q], v1 = a[2 * q + 1];
                     u4v w;
@@ -829,11 +861,11 @@ __global__ __launch_bounds__(kThreads) void k_sum16w(const SumDesc* __restrict__
             }
         } else if (d.qmode) {
 #pragma unroll
-            for (int q = 0; q < 2 * NQ; ++q) store_quant_pair(d.pcm, d.qmode, m + 2u * q, M, a[q], d.amplitude);
+            for (int q = 0; q < 2 * NQ; ++q) store_quant_pair(d.pcm, d.qmode, pair_frame<SH>(m, q), M, a[q], d.amplitude);
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, m + 2u * q, M, a[q]);
+        for (int q = 0; q < 2 * NQ; ++q) store_pair(d.out, pair_frame<SH>(m, q), M, a[q]);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         d.init_copy[0] = d.mode >= 4 ? spec_init_early : (d.use_init ? d.init_max : d.state->max);

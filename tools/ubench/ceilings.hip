@@ -43,6 +43,7 @@ __global__ __launch_bounds__(256) void k_gather(const Tab* __restrict__ tabs_gen
     const Tab UB_CONST* tabs = (const Tab UB_CONST*)(const UB_CONST char*)(tabs_generic + (size_t)blockIdx.y * k);
     out += (size_t)blockIdx.y * 2 * ((size_t)M + 64);
     const uint32_t m = blockIdx.x * (1024u * NQ) + 4u * NQ * threadIdx.x;
+    const uint32_t mw = blockIdx.x * (1024u * NQ) + (threadIdx.x >> 6) * 1024u + 4u * (threadIdx.x & 63u);   // (NQ == 4: the lane's first quad)
     uint32_t acc[4 * NQ];
 #pragma unroll
     for (int f = 0; f < 4 * NQ; ++f) acc[f] = 0u;
@@ -54,6 +55,16 @@ __global__ __launch_bounds__(256) void k_gather(const Tab* __restrict__ tabs_gen
             const uint32_t len = tabs[j + u].len;
             const uint32_t idx = barrett_mod(tabs[j + u].t0 + m, len, tabs[j + u].magic);
             const uint32_t UB_GLOBAL* g = (const uint32_t UB_GLOBAL*)(const UB_GLOBAL char*)tabs[j + u].p;
+            if (NQ == 4) {   // the engine's shape since round 6 (kernels.hip quad_frame): quad q = frames 256 q + 4 lane of the wave's 1 024
+                uint32_t i = barrett_mod(tabs[j + u].t0 + mw, len, tabs[j + u].magic);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    w[u][q] = *(const u4v_u UB_GLOBAL*)(g + i);
+                    i += 256u;
+                    i = len > 256u ? min(i, i - len) : barrett_mod(i, len, tabs[j + u].magic);
+                }
+                continue;
+            }
 #pragma unroll
             for (int q = 0; q < NQ; ++q) w[u][q] = *(const u4v_u UB_GLOBAL*)(g + idx + 4u * q);
         }
@@ -71,7 +82,7 @@ __global__ __launch_bounds__(256) void k_gather(const Tab* __restrict__ tabs_gen
         const uint32_t UB_GLOBAL* g = (const uint32_t UB_GLOBAL*)(const UB_GLOBAL char*)tabs[j].p;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const u4v_u w = *(const u4v_u UB_GLOBAL*)(g + idx + 4u * q);
+            const u4v_u w = *(const u4v_u UB_GLOBAL*)(g + (NQ == 4 ? barrett_mod(tabs[j].t0 + mw + 256u * q, len, tabs[j].magic) : idx + 4u * q));
             acc[4 * q + 0] ^= w.x; acc[4 * q + 1] ^= w.y; acc[4 * q + 2] ^= w.z; acc[4 * q + 3] ^= w.w;
         }
     }
