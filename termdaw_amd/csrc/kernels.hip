@@ -441,6 +441,13 @@ TD_DEV void sum_terms16(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4&
 // instruction touches 64 separate 64-byte pieces and takes a quarter of each, and the lines have to stay in the CU's L1 until the
 // fourth instruction has had its quarter (tools/ubench/gather_shape.hip, config 2's 737 MB with the arithmetic taken out: 52 us in
 // that shape, 40 us in this one with two sources' loads in flight -- in the old shape a second source in flight LOSES).
+// 256 mod len on the scalar unit (len, magic are a source's: uniform): a quad's index = the one before + this, wrapped ONCE, whatever
+// the loop's length -- no branch on `len > 256` in the gather (behind a branch the compiler's waits for the loads in flight fall
+// back to "all of them")
+TD_DEV uint32_t step256(uint32_t len, uint32_t magic) {
+    const uint32_t r = 256u - __umulhi(256u, magic) * len;   // (magic = floor(2^32 / len): the quotient is short by 1 at most)
+    return r >= len ? r - len : r;
+}
 template <int NQ>
 TD_DEV uint32_t quad_frame(uint32_t m, int q) { return NQ == 4 ? m + 256u * (uint32_t)q : m + 4u * (uint32_t)q; }
 template <int NQ>
@@ -455,6 +462,8 @@ TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4
         sc.x = ins[j].scale_l; sc.y = ins[j].scale_r;
         am.x = ins[j].pg.l_amp; am.y = ins[j].pg.r_amp;
         gn.x = gn.y = ins[j].pg.gain;
+        // (the three multipliers stay scalar operands of the packed multiplies: copied to vector registers first -- three vector
+        // register pairs read per v_pk_mul_f32 -- the launch measures 58.7 -> 59.6 (gain only) -> 63 us (all three), round 6)
 #pragma unroll
         for (int f = 0; f < 4 * NQ; ++f) {
             f2v v = cvt16(w[f]) * sc;
@@ -468,17 +477,13 @@ TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4
         const uint32_t idx = barrett_mod((uint32_t)ins[j].t0 + m, len, ins[j].magic);
         if (NQ == 4) {
             const uint32_t* p = reinterpret_cast<const uint32_t*>(ins[j].p);
-            if (len > 256u) {   // (uniform) quad q starts 256 frames behind quad q - 1: one wrap at most
-                uint32_t i = idx;
+            const uint32_t step = step256(len, ins[j].magic);
+            uint32_t i = idx;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) {
-                    loop16_quad(p, len, i, w + 4 * q);
-                    i += 256u;
-                    i = min(i, i - len);
-                }
-            } else {
-#pragma unroll
-                for (int q = 0; q < NQ; ++q) loop16_quad(p, len, barrett_mod((uint32_t)ins[j].t0 + m + 256u * (uint32_t)q, len, ins[j].magic), w + 4 * q);
+            for (int q = 0; q < NQ; ++q) {
+                loop16_quad(p, len, i, w + 4 * q);
+                i += step;
+                i = min(i, i - len);
             }
             return;
         }
@@ -487,8 +492,15 @@ TD_DEV void sum_terms16w(TermTab ins, uint32_t k, uint32_t m, uint32_t M, float4
     };
     uint32_t j = 0;
     // sources per batch: 16 x 16-byte loads in flight per lane (NQ == 4, round 6: four sources since every load instruction reads whole
-    // lines -- in the old shape a second source in flight lost; 1 / 2 / 3 / 4 sources: 63.1 / 64.5 / 62.9 / 61.9 us on config 2, a
-    // batch of 64 projects 71.4 -> 65.6 us per project)
+    // lines -- in the old shape a second source in flight lost: 1 / 2 / 3 / 4 sources 63.1 / 64.5 / 62.9 / 61.9 us on config 2;
+    // with the wrap made branch-free, step256 above, 58.9 us).  Measured and dropped: the same loads as a ROLLING pipeline -- the
+    // next sources' loads issued while this one's frames are added, two or four register sets in rotation, records a source ahead --
+    // 68 us: the memory side serves a wave's burst of sixteen loads followed by silence faster than a steady trickle.
+    // (Also measured and dropped, same instruction mix to the last VALU operation: the four records of a batch as explicit,
+    // non-overlapping scalar loads behind ONE wait -- the compiler's own loads pack `t0` into the unused half of `len`'s register
+    // pair and wait five times in a row at the head of every batch -- 58.2 -> 69.4 us on the same box, with 64-byte records as
+    // well; and the NEXT batch's records asked for behind this batch's vector loads: 112 scalar registers, spills, 68.6 us.  A
+    // start-up stagger of the workgroups that share a CU (0 / 0.8 / 1.6 us) moves nothing.)
     constexpr int B = 4;
     for (; j + B <= k; j += B) {
         uint32_t w[B][4 * NQ];
