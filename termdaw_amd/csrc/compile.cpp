@@ -226,8 +226,8 @@ static void put_intervals(IntervalView ib, Staging& st, VTables& vt) {
     {   // IntervalTab::tile_order: the costliest tiles first -- a tile's cost is a pass of the voice loop per interval it holds
         // frames of (the tiles with an interval start strictly inside them: the waves that take the per-interval passes), each as
         // long as the interval has voices.  Longest first, the grid's last workgroups are the cheap ones -- the tiles between two
-        // chords -- and the CUs run dry together (round 6: config 3's k_sources 80 -> 77 us; before: multi-interval tiles first, the
-        // rest in timeline order).
+        // chords -- and the CUs run dry together (round 6: the tests' 60-voice project 72 -> 65 us, config 3's k_sources -1 us; before:
+        // multi-interval tiles first, the rest in timeline order).
         const size_t nt = tile_first.size() - 1;
         std::vector<uint64_t> cost(nt);
         for (size_t t = 0; t < nt; ++t) {

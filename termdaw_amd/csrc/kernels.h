@@ -196,9 +196,10 @@ struct IntervalTab {
     const uint32_t* tile_first;   // [tiles] index of the interval holding each 1024-frame tile's first frame
     uint32_t n_int;
     uint32_t pad;
-    // [tiles] a permutation of the tiles, those with an interval start strictly inside them first: their waves take the
-    // per-frame form (~3x the time of a uniform wave) and should start at the head of the launch, not straggle at its
-    // tail (k_synth: 0.198 -> 0.14 ms on BASELINE config 3).  nullptr: identity.
+    // [tiles] a permutation of the tiles, the costliest first (compile.cpp put_intervals: a tile costs a pass of the voice loop per
+    // interval it holds frames of, each as long as the interval has voices): the expensive ones start at the head of the launch,
+    // the grid's last workgroups are the cheap ones.  (Round 3: the tiles with an interval start inside them first, k_synth
+    // 0.198 -> 0.14 ms on BASELINE config 3; round 6: by cost.)  nullptr: identity.
     const uint32_t* tile_order;
 };
 

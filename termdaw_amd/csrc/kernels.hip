@@ -1808,7 +1808,7 @@ TD_DEV void synth_quad_affine(const SynthDesc& d, uint32_t ma, uint32_t mb, uint
 // spill into the voice loop and lose)
 __global__ __launch_bounds__(kThreads, 6) void k_synth(const SynthDesc* __restrict__ descs, uint32_t M) {
     const SynthDesc& d = descs[blockIdx.y];
-    // (tiles whose waves take the per-frame form go first: IntervalTab::tile_order)
+    // (the costliest tiles go first: IntervalTab::tile_order)
     const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[blockIdx.x] : blockIdx.x;
     const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
@@ -1950,7 +1950,7 @@ TD_DEV float sampsyn_voice(const SampsynDesc& d, const float4 n, float off) {   
     return s;
 }
 TD_DEV void sampsyn_block(const SampsynDesc& d, uint32_t bx, uint32_t M) {
-    // (tiles with an interval start inside them first, as in k_synth: IntervalTab::tile_order)
+    // (the costliest tiles first, as in k_synth: IntervalTab::tile_order)
     const uint32_t tile = d.tab.tile_order ? ((const uint32_t TD_CONST*)(const TD_CONST char*)d.tab.tile_order)[bx] : bx;
     const uint32_t m0 = tile * kTileFrames + 2 * threadIdx.x;
     const uint32_t m1 = m0 + kTileFrames / 2;
