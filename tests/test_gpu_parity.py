@@ -532,3 +532,41 @@ def test_wide_loop_sums_on_long_timelines(gpu_api, oracle, bits, seconds, bl):
     gb, ob = p.build(gpu_api), p.build(oracle)
     for scan in (False, True):
         assert_bit_exact(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
+
+
+@pytest.mark.parametrize("lens", [(1, 2, 3, 255, 256, 257, 1000), (64, 128, 511, 512, 513, 40001)])
+def test_wide_loop_sums_over_loops_shorter_than_a_quad_step(gpu_api, oracle, lens):
+    """k_sum16w<4> (timelines of >= 2 600 tiles) gives a lane four quads 256 frames apart; the index of a quad is the one
+    before + 256 mod len, wrapped once (kernels.hip step256) -- loops of 1 .. 257 frames, where 256 mod len is not 256, an odd
+    and an even number of sources (the four-source batches' tail), into a Normalize (mode 5: the fused single-pass form, the
+    PCM straight out of the registers) and a plain Sum."""
+    p = W.ProjectScript(48000, 1024)
+    p.set_length(58.0)
+    for k, n in enumerate(lens):
+        p.assets["s%d" % k] = W.Asset(W.noise_int16(4100 + k, n))
+        p.load_sample("s%d" % k, "s%d" % k, "")
+        p.add_sampleloop("v%d" % k, 0.4 + 0.15 * k, -70.0 + 25.0 * k, "s%d" % k)
+    p.add_normalize("out", 1.0, 0.0)
+    p.add_sum("mix", 0.7, 20.0)
+    for k in range(len(lens)):
+        p.connect("v%d" % k, "out")
+        p.connect("v%d" % k, "mix")
+    p.add_sum("final", 1.0, 0.0)
+    p.connect("out", "final")
+    p.connect("mix", "final")
+    p.set_output("final")
+    gb, ob = p.build(gpu_api), p.build(oracle)
+    for scan in (False, True):
+        assert_bit_exact(p.render(gpu_api, built=gb, scan=scan), p.render(oracle, built=ob, scan=scan))
+    # ... and as the output vertex itself: the launch's own quantiser
+    p2 = W.ProjectScript(48000, 1024)
+    p2.set_length(58.0)
+    for k, n in enumerate(lens):
+        p2.assets["s%d" % k] = W.Asset(W.noise_int16(4100 + k, n))
+        p2.load_sample("s%d" % k, "s%d" % k, "")
+        p2.add_sampleloop("v%d" % k, 0.4 + 0.15 * k, -70.0 + 25.0 * k, "s%d" % k)
+    p2.add_normalize("out", 1.0, 0.0)
+    for k in range(len(lens)):
+        p2.connect("v%d" % k, "out")
+    p2.set_output("out")
+    assert_bit_exact(p2.render(gpu_api), p2.render(oracle))
