@@ -235,6 +235,8 @@ size_t td_cached_memory_bytes(void);
  *     (the two-launch Normalize forms; tests/test_gpu_spec_normalize.py, test_gpu_band_scan.py) /
  *   debug.inline_adsr 0|1 (an Adsr vertex materialised instead of read through; tests/test_gpu_parity.py) /
  *   debug.one_grid_sources 0|1 (a level's source launches one by one instead of as k_sources; tests/test_gpu_sources_grid.py) /
+ *   debug.inline_probe 0|1 (sine_mode 2: k_sine_probe as a launch of its own instead of inside the guarded chain launch's tiles;
+ *     tests/test_gpu_sine_guard.py) /
  *   debug.table_cache 0|1 (event tables recompiled every render; tests/test_gpu_parity.py) /
  *   debug.band_chain 0|1, debug.band_scan_nf 8|16, debug.band_scan n (scan mode: one launch per vertex, frames per lane, bit 0
  *     = every look-back poll times out and predecessors are recomputed; tests/test_gpu_band_scan.py) /

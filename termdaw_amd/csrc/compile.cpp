@@ -1304,6 +1304,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     const uint32_t probe_lg = probe_stride_log2(M);
     const uint32_t probe_stride = 1u << probe_lg, probe_n = (uint32_t)((M + probe_stride - 1) / probe_stride), probe_groups = (probe_n + 15u) / 16u;
     std::vector<std::pair<size_t, size_t>> probe_src;   // (vertex, scratch offset of its ProbeDesc::noise)
+    std::vector<size_t> probe_desc_off;                 // ... and where its ProbeDesc stands in the arena
     for (int lv = 0; lv < g->n_levels; ++lv) {
         std::vector<size_t> fam_v[F_COUNT];
         std::vector<float2*> level_tmp;            // scratch edge buffers that live for this level only
@@ -1636,6 +1637,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
                         const size_t no = scratch((size_t)probe_groups * 16 * sizeof(float));
                         scratch_field(po, offsetof(ProbeDesc, noise), no);
                         probe_src.push_back({vs[i], no});
+                        probe_desc_off.push_back(po);
                     }
                     add_launch(fam, off, (int)vs.size(), probe_groups, lv);
                     continue;
@@ -2156,8 +2158,19 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
     if (in_launch) {
         // ONE guarded launch and it ends in the Normalize vertex: the launch gives the verdict itself (BandScanDesc::nz_acc)
         const size_t o = audit_src[0].desc_off;
+        // One probed vertex, a sample every 256 frames: sixteen samples per tile of the launch = one workgroup of k_sine_probe's --
+        // the tiles evaluate their own (BandScanDesc::nz_probe) and the probe launch is taken off the list again.
+        bool inl = g->inline_probe && probe_src.size() == 1 && probe_lg == 8u;
+        if (inl) {
+            size_t at = cb.launches.size();
+            for (size_t l = 0; l < cb.launches.size(); ++l)
+                if (cb.launches[l].fam == F_PROBE && cb.launches[l].off == probe_desc_off[0] && cb.launches[l].n == 1) at = l;
+            if (at == cb.launches.size()) inl = false;
+            else cb.launches.erase(cb.launches.begin() + (long)at);
+        }
         for (size_t q = 0; q < probe_src.size(); ++q) {
-            scratch_field(o, offsetof(BandScanDesc, nz_extra) + q * sizeof(const float*), probe_src[q].second);
+            if (inl) ptr_field(o, offsetof(BandScanDesc, nz_probe), probe_desc_off[q]);
+            else scratch_field(o, offsetof(BandScanDesc, nz_extra) + q * sizeof(const float*), probe_src[q].second);
             const float g2 = (float)probe_g2[q];
             memcpy(&st.b[o + offsetof(BandScanDesc, nz_xg2) + q * sizeof(float)], &g2, 4);
         }

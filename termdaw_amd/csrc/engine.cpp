@@ -1947,7 +1947,7 @@ static std::vector<OptionRef> option_table(td_graph* g) {
         {"fuse_sources", 0, &g->fuse_sources}, {"packed_samples", 0, &g->packed_samples}, {"band_mode", 1, &g->band_mode},
         {"band_guard_ppb", 2, &g->band_guard_ppb}, {"sine_mode", 1, &g->sine_mode}, {"output_f32", 0, &g->output_f32},
         {"max_chunk_frames", 3, &g->max_chunk_frames},
-        {"debug.norm", 1, &g->norm_debug}, {"debug.band_scan", 1, &g->band_scan_debug}, {"debug.one_grid_sources", 0, &g->one_grid_sources},
+        {"debug.norm", 1, &g->norm_debug}, {"debug.band_scan", 1, &g->band_scan_debug}, {"debug.one_grid_sources", 0, &g->one_grid_sources}, {"debug.inline_probe", 0, &g->inline_probe},
         {"debug.inline_adsr", 0, &g->inline_adsr}, {"debug.spec_normalize", 0, &g->spec_normalize},
         {"debug.single_pass_normalize", 0, &g->single_pass_normalize}, {"debug.fuse_normalize", 0, &g->fuse_normalize},
         {"debug.table_cache", 0, &g->table_cache}, {"debug.band_serial", 0, &g->band_serial}, {"debug.band_chain", 0, &g->band_chain}, {"debug.band_scan_nf", 1, &g->band_scan_nf},

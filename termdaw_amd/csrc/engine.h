@@ -382,6 +382,7 @@ struct td_graph {
     bool output_f32 = true;                    // 0: a Normalize output vertex rendered to PCM keeps no f32 copy of its frames
     bool table_cache = true;                   // event tables: reuse across renders / across identical vertices of a chunk
     bool spec_normalize = true;                // renders after a normalize scan use the speculative single-pass normalize
+    bool inline_probe = true;                  // (sine_mode 2) one probed vertex behind the graph's one guarded chain launch: the launch's tiles evaluate the probe's samples themselves (test hook "debug.inline_probe" 0: k_sine_probe as a launch of its own)
     bool one_grid_sources = true;              // a level's source launches (affine Synth, wavetable voice, SampleLerp) and the envelope launch go out as ONE grid (k_sources)
     bool fuse_normalize = true;                // band_mode 1: a Normalize vertex right behind a scan launch is evaluated by that launch (BandScanDesc::norm)
     bool single_pass_normalize = true;         // fresh renders of wide all-loop sums find the running peak inside the sum launch (SumDesc mode 4)

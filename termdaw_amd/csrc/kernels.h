@@ -450,6 +450,11 @@ struct BandScanDesc {
     const float* nz_extra[2];
     float nz_xg2[2];
     uint32_t nz_xcnt, pad6;
+    // ... measured BY THIS LAUNCH (round 6): with one probed vertex and a sample every 256 frames a tile's 4 096 frames hold sixteen
+    // sample frames -- one workgroup of k_sine_probe's -- and the tile evaluates them itself, right behind its ticket (the probed
+    // vertex' output is complete: it was written by an earlier launch), keeps the sixteen energies in LDS and adds them to its
+    // verdict: no k_sine_probe launch (10 us of BASELINE config 3's 114).  nz_extra[0] is nullptr then; nz_xg2[0] as above.
+    const struct ProbeDesc* nz_probe;
 };
 // The guard's verdict (engine option "band_mode" 2): one workgroup per graph adds up what its scan launches estimated, carried to
 // the graph's output -- a static gain per launch (the host walks the graph: pan / gain of everything downstream) and, where the

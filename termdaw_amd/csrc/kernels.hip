@@ -1851,10 +1851,10 @@ template <int K>
 TD_DEV float row_shl(float v) {   // lane i of a row of 16 receives lane i + K's value (lanes past the row's end: 0)
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x100 + K, 0xF, 0xF, true));
 }
-__global__ __launch_bounds__(kThreads) void k_sine_probe(const ProbeDesc* __restrict__ descs, uint32_t M) {
-    const ProbeDesc& p = descs[blockIdx.y];
+// sample `idx` of the chunk, lane `sub` of its row of sixteen: the sample's energy x the frames it stands for, in the row's lane 0
+// (0 for a sample whose frame lies beyond the chunk)
+TD_DEV float probe_energy(const ProbeDesc& p, uint32_t idx, uint32_t sub, uint32_t M) {
     const uint32_t lg = p.stride_log2, stride = 1u << lg;
-    const uint32_t idx = blockIdx.x * 16u + (threadIdx.x >> 4), sub = threadIdx.x & 15u;   // the sample stands for frames [idx << lg, (idx + 1) << lg)
     const uint32_t m = probe_frame(idx, lg);
     const bool valid = m < M;                                    // (the last sample's frame may lie beyond the chunk: nothing measured)
     const uint32_t mc = valid ? m : 0u;
@@ -1885,15 +1885,19 @@ __global__ __launch_bounds__(kThreads) void k_sine_probe(const ProbeDesc* __rest
         TD_PROBE_ADD(8) TD_PROBE_ADD(9) TD_PROBE_ADD(10) TD_PROBE_ADD(11) TD_PROBE_ADD(12) TD_PROBE_ADD(13) TD_PROBE_ADD(14) TD_PROBE_ADD(15)
 #undef TD_PROBE_ADD
     }
-    if (sub == 0u && (idx << lg) < M) {
-        float e = 0.0f;
-        if (valid) {
-            const PanGain& pg = synth ? p.syn.pg : p.sine.pg;
-            const float2 want = epilogue(make_float2(acc, acc), pg);
-            e = fmaxf(probe_dev2(got.x, want.x), probe_dev2(got.y, want.y));
-        }
-        p.noise[idx] = e * (float)min(stride, M - (idx << lg));
+    float e = 0.0f;
+    if (sub == 0u && valid) {
+        const PanGain& pg = synth ? p.syn.pg : p.sine.pg;
+        const float2 want = epilogue(make_float2(acc, acc), pg);
+        e = fmaxf(probe_dev2(got.x, want.x), probe_dev2(got.y, want.y)) * (float)min(stride, M - (idx << lg));
     }
+    return e;
+}
+__global__ __launch_bounds__(kThreads) void k_sine_probe(const ProbeDesc* __restrict__ descs, uint32_t M) {
+    const ProbeDesc& p = descs[blockIdx.y];
+    const uint32_t idx = blockIdx.x * 16u + (threadIdx.x >> 4), sub = threadIdx.x & 15u;   // the sample stands for frames [idx << lg, (idx + 1) << lg)
+    const float e = probe_energy(p, idx, sub, M);
+    if (sub == 0u && (idx << p.stride_log2) < M) p.noise[idx] = e;
 }
 void launch_sine_probe(const ProbeDesc* d, int n_desc, uint32_t frames, uint32_t n_groups, hipStream_t s) {   // n_groups: workgroups, 16 samples each
     if (n_desc > 0 && n_groups > 0) hipLaunchKernelGGL(k_sine_probe, dim3(n_groups, (uint32_t)n_desc), dim3(kThreads), 0, s, d, frames);
@@ -3564,6 +3568,11 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
     if (tid == 0u) tile_s = atomicAdd(d.ticket, 1u);
     __syncthreads();
     const uint32_t tile = tile_s;
+    __shared__ float nzx_s[16];   // (GUARD, BandScanDesc::nz_probe) the tile's sixteen sample energies
+    if (GUARD && d.nz_probe) {    // (uniform) the tile's share of k_sine_probe's work: a sample every 256 frames, sixteen in the tile
+        const float e = probe_energy(*d.nz_probe, tile * 16u + (tid >> 4), tid & 15u, M);
+        if ((tid & 15u) == 0u) nzx_s[tid >> 4] = e;   // (read at the chain's end: barriers in between)
+    }
     if (tile == 0u) {
         // The carried states, before anybody can have replaced them: the wave holding the chunk's last frame stores a
         // stage's new state only after it has seen the word set below.
@@ -4100,7 +4109,12 @@ __global__ __launch_bounds__(kThreads, 3) void k_band_chain(const BandScanDesc* 
             if (nzs) {
                 // ... and what the graph's probed sine vertices measured at their own outputs (k_sine_probe, earlier on the stream;
                 // BandScanDesc::nz_extra), through the same 1 / max: this wave-tile's share of its probe group's energy
-                if (dl->nz_extra[0] && wt0 < M) {   // (uniform)
+                if (dl->nz_probe) {   // (uniform) measured by this tile at its start: samples 4 wave .. 4 wave + 3 are this wave-tile's
+                    float xe = lane_e < 4u ? nzx_s[wave * 4u + lane_e] * dl->nz_xg2[0] : 0.0f;
+                    xe += __shfl_xor(xe, 1, 64);
+                    xe += __shfl_xor(xe, 2, 64);
+                    e += xe * gq * gq;   // (lanes 0 .. 3 hold the sum; lane 0 is the one that counts below)
+                } else if (dl->nz_extra[0] && wt0 < M) {   // (uniform)
                     const uint32_t cnt = dl->nz_xcnt, i0 = wt * cnt + lane_e;   // this wave-tile's samples: cnt <= 64, one a lane
                     const uint32_t ns = (M + (uint32_t)kTileFrames / cnt - 1u) / ((uint32_t)kTileFrames / cnt);
                     float xe = 0.0f;

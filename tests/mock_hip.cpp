@@ -188,6 +188,13 @@ static void touch_scan(const BandScanDesc* d, int n, uint32_t frames, bool chain
         if (x.noise) {   // (per wave-tile in the chain launch, per workgroup tile in k_band_scan)
             touch_w(x.noise, (size_t)(chain ? (frames + kTileFrames - 1) / kTileFrames : x.n_tiles) * 4);
             if (x.nz_sync) { touch_w(x.nz_sync, (size_t)x.n_tiles * 8); touch_w(x.nz_host, 8); }
+            if (x.nz_probe) {   // (the launch's tiles evaluate the probe's samples themselves: one probed vertex, a sample per 256 frames)
+                touch(x.nz_probe, sizeof(ProbeDesc));
+                if (x.nz_probe->stride_log2 != 8u || x.nz_extra[0]) abort();
+                const IntervalTab& t = x.nz_probe->kind ? x.nz_probe->syn.tab : x.nz_probe->sine.tab;
+                touch_interval_tab(t, frames);
+                touch(x.nz_probe->ranges, (size_t)((frames + 255) / 256) * 8);
+            }
             for (int q = 0; q < 2; ++q)   // (sine_mode 2: the probed sine vertices' energies, nz_xcnt samples per wave-tile)
                 if (x.nz_extra[q]) {
                     if (!x.nz_xcnt || x.nz_xcnt > 64u || (kTileFrames % x.nz_xcnt)) abort();

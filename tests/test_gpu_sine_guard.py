@@ -84,6 +84,34 @@ def test_config3_passes_untouched(gpu_api, oracle):
     assert plain[2].band_guard_stats()["last_est"] < st["last_est"]      # (the band-pass estimate alone)
 
 
+def test_the_chain_launch_measures_the_probes_samples_itself(gpu_api, oracle):
+    """Config 3's shape at 60 s: one probed vertex, a sample every 256 frames -- the guarded chain launch's tiles evaluate their own
+    sixteen samples (BandScanDesc::nz_probe) and no k_sine_probe launch is left; test hook debug.inline_probe 0 brings the launch
+    back: the same bytes, the same estimate (the same sample energies, summed in another order); in chunks of one block the stride is
+    16 and the probe stays a launch of its own."""
+    p = W.config3(seconds=12.0)
+    res = {}
+    for inl in (1, 0):
+        gb = _front_end_modes(p, gpu_api)
+        gb[2].set_option("debug.inline_probe", inl)
+        gb[2].set_profiling(1)
+        pcm, f = p.render(gpu_api, built=gb)
+        fam = gb[2].kernel_times()
+        gb[2].set_profiling(0)
+        st = gb[2].band_guard_stats()
+        assert st["audits"] == 1 and st["redos"] == 0, st
+        assert ("k_sine_probe" in fam) == (inl == 0), fam
+        res[inl] = (pcm, f, st["last_est"])
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(_bits(res[0][1]), _bits(res[1][1]))
+    assert abs(res[0][2] - res[1][2]) <= 1e-4 * res[0][2], (res[0][2], res[1][2])
+    gb = _front_end_modes(p, gpu_api)
+    gb[2].set_option("max_chunk_frames", 1024)
+    gb[2].set_profiling(1)
+    pcm, f = p.render(gpu_api, built=gb)
+    assert "k_sine_probe" in gb[2].kernel_times()
+    assert np.abs(pcm.astype(np.int64) - res[1][0].astype(np.int64)).max() <= 1   # (another chunking of the scan class: not the same bits)
+
+
 def test_the_round_5_outlier_through_the_front_end_with_nothing_set(gpu_api, oracle, tmp_path):
     """Seed 123475 -- 2.6e-6 RMS in every mode round 5 had short of sine_mode 1: now over the bound by the probe's own measurement,
     rendered again, and the oracle's bits; through td_state_* with nothing set, plain, scanned and continued."""
