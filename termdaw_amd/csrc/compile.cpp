@@ -1289,7 +1289,7 @@ int compile_chunk(td_graph* g, const td_samplebank* sb, const td_flowwbank* fb,
         x.pg = make_pg(v.gain, v.angle);
         x.affine = synth_affine_ok(v) ? 1u : 0u;   // (the tables then hold affine records: compile_synth)
         x.exact_sin = v.exact_sin ? 1u : 0u;
-        x.small_args = ((double)(t0 + M + 2) / (double)sr) * (double)vt[vi].hz_max * 6.2831854 < 1.3e7 ? 1u : 0u;
+        x.small_args = ((double)(t0 + M + 2) / (double)sr) * (double)vt[vi].hz_max * 6.2831854 < 2.0e6 ? 1u : 0u;
         {
             auto same = [](const AdsrConfD& a, const AdsrConfD& b) { return memcmp(&a, &b, sizeof(AdsrConfD)) == 0; };
             const bool sq = v.square.volume > 0.0f, tf = v.topflat.volume > 0.0f;

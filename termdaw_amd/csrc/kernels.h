@@ -233,7 +233,8 @@ struct SynthDesc {
     // rel_t) per voice, envelopes evaluated per frame (confs that can reach the `res <= -1.0` escape, zero-length pieces)
     uint32_t affine;
     uint32_t exact_sin;   // 1: the oscillators' sine is glibc's sinf, operation for operation (kernels.hip sin_glibc; engine option "sine_mode"); affine is 0 then    // 1 (host: compile.cpp synth_desc_of): every sine argument of the chunk, (t0 + m) / sr * hz * 2 pi over the tables' largest hz,
-    // stays below 1.3e7 rad = 2^22 half turns -- the affine form's sine then rounds to half turns by adding 1.5 * 2^23 (sin_small2)
+    // stays below 2e6 rad -- the affine form's sine then rounds to half turns by adding 1.5 * 2^23 and takes a degree-9 polynomial
+    // fitted to the reduced range that bound leaves (sin_small2); beyond: sin_any2
     uint32_t small_args, pad_sa;
 };
 

@@ -1276,11 +1276,11 @@ TD_DEV f2 sin_any2(f2 arg) {
     return q * sgn;
 }
 TD_DEV float sin_any(float arg) { return sin_any2((f2)(arg)).x; }
-// The same for arguments below 2^22 half turns (1.3e7 rad; SynthDesc::small_args: the host has looked at the chunk's last frame and
-// the tables' largest hz).  n = rint(arg / pi) comes out of ONE fused step: arg / pi + 1.5 * 2^23 is rounded to an integer by
+// The same for arguments below 2e6 rad (SynthDesc::small_args: the host has looked at the chunk's last frame and the tables'
+// largest hz; the rounding trick itself holds to 2^22 half turns, 1.3e7 rad: the bound is the polynomial's, below).  n = rint(arg / pi) comes out of ONE fused step: arg / pi + 1.5 * 2^23 is rounded to an integer by
 // the addition itself, and the sum's last mantissa bit is n's parity -- shifted to the top and ADDED to r's pattern it flips r's
-// sign (v_lshl_add_u32), in front of the odd polynomial, whose result is canonical again.  14 instructions per frame pair
-// instead of 18 (round 6; same reduction, same polynomial: the two agree except where rint saw a tie).
+// sign (v_lshl_add_u32), in front of the odd polynomial, whose result is canonical again.  13 instructions per frame pair
+// instead of 18 (round 6; same reduction, a polynomial one degree-step shorter: below).
 TD_DEV f2 sin_small2(f2 arg) {
     const f2 big = (f2)(12582912.0f);
     const f2 t = fma2(arg, (f2)(0.318309886f), big);
@@ -1291,11 +1291,14 @@ TD_DEV f2 sin_small2(f2 arg) {
     f2 rs;
     rs.x = __uint_as_float((__float_as_uint(t.x) << 31) + __float_as_uint(r.x));
     rs.y = __uint_as_float((__float_as_uint(t.y) << 31) + __float_as_uint(r.y));
-    f2 p = (f2)(-2.5052108385441718775e-8f);                 // -1/11!
-    p = fma2(p, r2, (f2)(2.7557319223985890653e-6f));        //  1/9!
-    p = fma2(p, r2, (f2)(-1.9841269841269841270e-4f));       // -1/7!
-    p = fma2(p, r2, (f2)(8.3333333333333333333e-3f));        //  1/5!
-    p = fma2(p, r2, (f2)(-1.6666666666666666667e-1f));       // -1/3!
+    // (degree 9, the closest to sin in the maximum norm on |r| <= pi/2 + 0.1: tools/sin_minimax.py -- 9e-9; the whole function
+    // against sin() in double over [0, 2e6]: max 1.2e-7, RMS 2.2e-8.  fl(1 / pi) is short by 4e-8 of itself: at 2e6 rad the
+    // quotient is off by 0.026 and |r| reaches pi/2 + 0.08 -- the host's bound.  sin_any2's product-then-rint quotient is off by
+    // up to half a turn at 1e7 rad and keeps the Taylor polynomial, which degrades more gently outside its range.)
+    f2 p = (f2)(2.580226009740727e-06f);
+    p = fma2(p, r2, (f2)(-0.00019797123968601227f));
+    p = fma2(p, r2, (f2)(0.008332878351211548f));
+    p = fma2(p, r2, (f2)(-0.16666650772094727f));
     return fma2(rs, r2 * p, rs);
 }
 

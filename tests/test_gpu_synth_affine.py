@@ -87,11 +87,11 @@ def test_affine_and_generic_vertices_in_one_graph(gpu_api, oracle, chunk):
     assert np.abs(gp.astype(np.int64) - op.astype(np.int64)).max() <= 1
 
 
-@pytest.mark.parametrize("start_s", [0, 161, 400])
+@pytest.mark.parametrize("start_s", [0, 23, 400])
 def test_sine_arguments_on_both_sides_of_the_half_turn_bound(gpu_api, oracle, start_s):
     """The affine form's sine rounds to half turns by adding 1.5 * 2^23 while the host can bound the chunk's arguments
-    below 2^22 half turns (SynthDesc::small_args), and by v_rndne beyond: a 12.5 kHz voice passes that bound 164.95 s
-    into the timeline.  Rendered from 0 s (every chunk below), from 161 s in one-second chunks (the first three below,
+    below 2e6 rad (SynthDesc::small_args), and by v_rndne beyond: a 12.5 kHz voice passes that bound 25.4 s
+    into the timeline.  Rendered from 0 s (every chunk below), from 23 s in one-second chunks (the first two below,
     the rest above) and from 400 s (all above; arguments of 3e7 rad, an f32 ulp of 2 rad -- the rounding of
     `time * hz * 2 pi` IS the signal there, extensions.rs:501)."""
     p = W.ProjectScript(48000, 1024)
